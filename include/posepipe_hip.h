@@ -1,0 +1,213 @@
+/*
+ * posepipe_hip.h -- C ABI of libposepipe_hip.so: the MI355X (gfx950) hot path of
+ * PosePipe's detect/track -> top-down 2D -> 3D lifting cascade.
+ *
+ * The reference (peabody124/PosePipeline) has no FFI for this path: its boundary is the
+ * Python calling convention between DataJoint `make()` methods and the wrapper functions
+ *   pose_pipeline/wrappers/mmtrack.py:8      mmtrack_bounding_boxes(file_path, method)
+ *   pose_pipeline/wrappers/mmpose.py:26      mmpose_top_down_person(key, method)
+ *   pose_pipeline/wrappers/videopose3d.py:19 process_videopose3d(key, batch_size, transform_coco)
+ * whose arithmetic lives in un-vendored third-party packages (mmpose / mmdet / mmtrack /
+ * VideoPose3D / OpenCV).  Each entry point below names the reference line(s) or third-party
+ * op it replaces.  posepipeline_amd/wrappers/ holds the drop-in Python callables that bind
+ * these symbols through ctypes (see INTEGRATION.md for the stub a maintainer would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative pp_status on failure; the message is
+ *     available from pp_last_error() (thread-local).
+ *   - all array arguments are caller-owned, contiguous, with explicit dims.  `mem` says whether
+ *     the pointers are host (PP_MEM_HOST: the library stages them through its own device
+ *     buffers) or device (PP_MEM_DEVICE: used in place, e.g. a torch tensor's data_ptr()).
+ *   - one HIP stream per ctx; calls on one ctx are not thread-safe, distinct ctxs are.
+ *   - no torch / C++ types cross this boundary.
+ */
+#ifndef POSEPIPE_HIP_H
+#define POSEPIPE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PP_ABI_VERSION 1
+
+typedef enum {
+    PP_OK = 0,
+    PP_ERR_ARG = -1,      /* bad argument */
+    PP_ERR_HIP = -2,      /* HIP runtime error (no GPU, launch failure, OOM ...) */
+    PP_ERR_STATE = -3,    /* object used in the wrong state */
+    PP_ERR_UNSUPPORTED = -4
+} pp_status;
+
+typedef enum { PP_MEM_HOST = 0, PP_MEM_DEVICE = 1 } pp_mem_kind;
+
+typedef struct pp_ctx pp_ctx;   /* device + stream + scratch */
+typedef struct pp_net pp_net;   /* a compiled layer program + resident weights/activations */
+typedef struct pp_tracker pp_tracker; /* host-side multi-object tracker state */
+
+/* ---- library / context ------------------------------------------------------------------ */
+int pp_abi_version(void);
+const char* pp_last_error(void);
+int pp_device_count(void);                         /* 0 when no HIP device is visible */
+int pp_ctx_create(int device, pp_ctx** out);       /* fails with PP_ERR_HIP when there is no GPU */
+void pp_ctx_destroy(pp_ctx* ctx);
+int pp_ctx_set_stream(pp_ctx* ctx, void* hip_stream); /* adopt an external hipStream_t (e.g. torch's) */
+int pp_ctx_synchronize(pp_ctx* ctx);
+/* HIP-event timer on the ctx stream (bench.py's roofline leg): start/stop bracket launches. */
+int pp_timer_start(pp_ctx* ctx);
+int pp_timer_stop(pp_ctx* ctx, float* elapsed_ms); /* synchronises on the stop event */
+/* raw device memory helpers so that a host language without a HIP binding can keep data resident */
+int pp_malloc(pp_ctx* ctx, size_t bytes, void** dptr);
+int pp_free(pp_ctx* ctx, void* dptr);
+int pp_memcpy_h2d(pp_ctx* ctx, void* dst, const void* src, size_t bytes);
+int pp_memcpy_d2h(pp_ctx* ctx, void* dst, const void* src, size_t bytes);
+
+/* ---- layer programs (backbones) ----------------------------------------------------------
+ * A network is a straight-line program of ops over numbered NHWC fp32 activation buffers.
+ * Replaces the third-party forward passes reached from
+ *   wrappers/mmpose.py:75  (mmpose TopDown.forward_test -> HRNet, arch spec
+ *                           3rdparty/mmpose/config/top_down/darkpose/coco/hrnet_w48_coco_384x288_dark.py:44-79)
+ *   wrappers/mmtrack.py:45 (mmdet FasterRCNN, 3rdparty/mmtracking/_base_/models/faster_rcnn_r50_fpn.py:1-112)
+ *   wrappers/videopose3d.py:82 (VideoPose3D TemporalModel, wrappers/videopose3d.py:46-50)
+ * Convolutions run as implicit GEMM on v_mfma_f32_16x16x4_f32 with BatchNorm folded into
+ * (weight, bias) and bias / residual adds / ReLU / nearest-upsample-accumulate fused in the
+ * epilogue.  The fp32 MFMA accumulates each output as a k-ordered fmaf chain over
+ * k = (kh, kw, cin), which is exactly what oracle/conv_ref.c does, so results are bit-exact.
+ */
+typedef enum {
+    PP_OP_CONV = 1,      /* conv2d (conv1d when H == 1), see pp_op fields */
+    PP_OP_MAXPOOL = 2,   /* kh x kw max pool, -inf padding (ResNet stem 3x3 s2 p1; FPN P6 1x1 s2) */
+    PP_OP_ROIALIGN = 3,  /* reserved for the detector program */
+    PP_OP_COPY = 4       /* buffer copy (same dims) */
+} pp_op_type;
+
+#define PP_RELU_NONE 0
+#define PP_RELU_LAST 1   /* y = relu(conv + bias + res...) */
+#define PP_RELU_FIRST 2  /* y = res + relu(conv + bias)   (VideoPose3D blocks) */
+
+typedef struct pp_op {
+    int32_t type;
+    int32_t in, out;          /* buffer ids */
+    int32_t res1, res2;       /* residual buffer ids, -1 = none; order: ((acc+bias) + res1) + res2 */
+    int32_t cin, cout;        /* cin % 4 == 0 (pad the blob); cout arbitrary */
+    int32_t kh, kw, stride, pad_h, pad_w, dil_h, dil_w;
+    int32_t relu;             /* PP_RELU_* */
+    int32_t up_log2;          /* write each output to a 2^up x 2^up patch of `out` (nearest upsample) */
+    int32_t out_nchw;         /* 1: write `out` as [n][cout][H][W] planes (heatmaps) */
+    int32_t res1_shift;       /* read res1 at (h >> s, w >> s)  (FPN top-down add) */
+    int32_t res1_off_w;       /* read res1 at w + off (VideoPose3D centre-cropped residual) */
+    int64_t w_off, b_off;     /* float offsets into the weight blob: W[K][cout_pad16], bias[cout_pad16] */
+} pp_op;
+
+typedef struct pp_buf {
+    int32_t h, w, c;          /* per-sample dims */
+} pp_buf;
+
+/* weights: host pointer to the flat fp32 blob (copied to the device once).  max_batch fixes the
+ * size of the resident activation arena. */
+int pp_net_create(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, int n_bufs,
+                  const float* weights, size_t n_weights, int max_batch, pp_net** out);
+void pp_net_destroy(pp_net* net);
+/* device address of activation buffer `buf` (batch-major, then the pp_buf layout) */
+int pp_net_buffer(pp_net* net, int buf, void** dptr, size_t* bytes_per_sample);
+/* run ops [first, last) for `batch` samples; inputs must already be in their buffers */
+int pp_net_run(pp_net* net, int batch, int first_op, int last_op);
+/* convenience: copy `in` into buffer in_buf, run everything, copy buffer out_buf to `out` */
+int pp_net_forward(pp_net* net, int batch, int in_buf, const float* in, int out_buf, float* out,
+                   int mem);
+/* capture ops [0, n_ops) at `batch` into a hipGraph and replay it on later pp_net_run calls */
+int pp_net_capture(pp_net* net, int batch);
+/* per-op elapsed time of the last profiled run (HIP events around each op), ms; NULL-safe */
+int pp_net_profile(pp_net* net, int batch, float* ms_per_op);
+
+/* single convolution on caller-provided device/host buffers (tests, VideoPose3D, FC layers).
+ * x: [n][hin][win][cin]; w: [kh*kw*cin][cout_pad16]; bias: [cout_pad16]; y per op flags. */
+int pp_conv2d(pp_ctx* ctx, const pp_op* op, int n, int hin, int win, const float* x,
+              const float* w, const float* bias, const float* res1, const float* res2, float* y,
+              int res1_h, int res1_w, int mem);
+
+/* ---- top-down pre-processing --------------------------------------------------------------
+ * Replaces mmpose `_box2cs` + `TopDownAffine` (cv2.warpAffine INTER_LINEAR, border 0) + ToTensor +
+ * NormalizeTensor reached from wrappers/mmpose.py:75 (pipeline spec
+ * hrnet_w48_coco_384x288_dark.py:87-90,129-144); in-tree twin utils/bounding_box.py:32-53.
+ * frames: [n_frames][h][w][3] u8.  For person i: frame_idx[i], bbox_tlwh[i] (x,y,w,h doubles;
+ * NaN = absent -> the output sample is all zeros and valid[i] = 0).
+ * lut: [3][256] fp32 = ((v/255) - mean[c]) / std[c] computed by the caller in fp32.
+ * chan_map[c] = source channel feeding output channel c (reproduces the reference's double
+ * BGR<->RGB swap, wrappers/mmpose.py:73).
+ * out: [n_out][out_h][out_w][4] fp32 NHWC (4th channel 0); with flip != 0, n_out = 2*n_person and
+ * sample n_person+i is sample i mirrored in W (`img.flip(3)` of flip_test).
+ * center_scale: [n_person][4] fp32 = (cx, cy, sx, sy) as mmpose `_box2cs` returns them.
+ * crop_u8 (optional, may be NULL): [n_person][out_h][out_w][3] the warped u8 crop (parity tests).
+ */
+int pp_crop_affine_normalize(pp_ctx* ctx, const uint8_t* frames, int n_frames, int h, int w,
+                             const int32_t* frame_idx, const double* bbox_tlwh, int n_person,
+                             int out_w, int out_h, const float* lut, const int32_t* chan_map,
+                             int flip, float* out, float* center_scale, uint8_t* crop_u8,
+                             int32_t* valid, int mem);
+
+/* ---- flip-merge + heatmap decode ------------------------------------------------------------
+ * Replaces mmpose head `inference_model` flip_back/shift/average (test_cfg
+ * hrnet_w48_coco_384x288_dark.py:81-85) and `keypoints_from_heatmaps` reached from
+ * wrappers/mmpose.py:75; in-tree statement of the DARK maths: utils/inference.py:27-114.
+ * hm: [n][k][h][w] fp32; hm_flip: same for the mirrored input or NULL (no flip test).
+ * flip_perm: [k] channel permutation applied to hm_flip (COCO left/right pairs).
+ * post: 0 = 'default' (+-0.25 px), 1 = 'unbiased' (DARK, blur_kernel e.g. 17).
+ * center_scale: [n][4] as above.  kpts: [n][k][3] fp32 = (x_px, y_px, maxval).
+ * merged (optional): [n][k][h][w] the averaged heatmap (parity tests).
+ */
+int pp_flip_merge_decode(pp_ctx* ctx, const float* hm, const float* hm_flip, int n, int k, int h,
+                         int w, const int32_t* flip_perm, int shift_heatmap, int post,
+                         int blur_kernel, const float* center_scale, float* kpts, float* merged,
+                         int mem);
+
+/* ---- NMS -------------------------------------------------------------------------------------
+ * Replaces mmcv-full `nms` / `batched_nms` reached from the Faster-RCNN RPN and RoI head
+ * (faster_rcnn_r50_fpn.py:101-109): boxes [n][4] x1y1x2y2 fp32, scores [n]; suppress IoU > thr,
+ * area = w*h; keep[] receives indices in descending score order, *n_keep their count.
+ * convention 1 = in-tree deep_sort preprocessing.non_max_suppression
+ * (wrappers/deep_sort_yolov4/deep_sort/preprocessing.py:5-70: tlwh boxes, +1 areas,
+ * overlap = inter / area_other).
+ */
+int pp_nms(pp_ctx* ctx, const float* boxes, const float* scores, int n, float iou_thr,
+           int convention, int32_t* keep, int32_t* n_keep, int mem);
+
+/* ---- tracker (host) ---------------------------------------------------------------------------
+ * Replaces the association stage of wrappers/mmtrack.py:45 (mmtrack SortTracker) with the one
+ * tracker whose source is in the reference tree: wrappers/deep_sort_yolov4/deep_sort/
+ * (tracker.py:10-131, track.py, kalman_filter.py:14-217, linear_assignment.py:14-186,
+ * iou_matching.py:7-84).  float64 throughout, scipy-compatible Hungarian tie-breaking.
+ * mode 0 = in-tree DeepSORT semantics without appearance features (IoU-only association);
+ * mode 1 = mmtrack-style SORT (ids from 0, tentative handling as SURVEY.md A6; unpinned).
+ */
+int pp_tracker_create(int mode, double max_iou_distance, int max_age, int n_init, pp_tracker** out);
+void pp_tracker_destroy(pp_tracker* t);
+/* dets_tlwh: [n_det][4] float64, conf: [n_det].  Outputs (capacity cap): confirmed, just-updated
+ * tracks as the reference's parser emits them: ids, tlwh (Kalman mean), and the matched
+ * detection index.  Returns the number of tracks written through *n_out. */
+int pp_tracker_step(pp_tracker* t, const double* dets_tlwh, const double* conf, int n_det,
+                    int cap, int64_t* track_id, double* tlwh, int32_t* det_idx, int32_t* n_out);
+/* debugging / parity: dump all live tracks (id, state, hits, age, time_since_update, mean[8], cov[64]) */
+int pp_tracker_dump(pp_tracker* t, int cap, int64_t* ids, int32_t* state4, double* mean8,
+                    double* cov64, int32_t* n_out);
+/* scipy.optimize.linear_sum_assignment restated (rectangular, float64); row4col/col4row sized
+ * by n_rows / n_cols; returns assignment pairs sorted by row like scipy. */
+int pp_linear_sum_assignment(const double* cost, int n_rows, int n_cols, int32_t* rows,
+                             int32_t* cols, int32_t* n_pairs);
+
+/* ---- 3D lifting -----------------------------------------------------------------------------
+ * Replaces VideoPose3D TemporalModelOptimized1f + ChunkedGenerator windows reached from
+ * wrappers/videopose3d.py:66-85, computed in the equivalent whole-clip dilated form.
+ * net: a program built for the dilated form (posepipeline_amd.models.videopose3d).
+ * kpts2d_norm: [n_frames][17][2] fp32 already screen-normalised (videopose3d.py:26-37);
+ * out: [n_frames][17][3] fp32.  Edge replication by 121 frames is done on the device.
+ */
+int pp_videopose3d_lift(pp_net* net, const float* kpts2d_norm, int n_frames, int n_joints_in,
+                        int n_joints_out, int pad, float* out, int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSEPIPE_HIP_H */

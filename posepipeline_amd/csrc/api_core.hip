@@ -1,0 +1,424 @@
+// Context, memory helpers, layer-program executor (pp_net_*) and the single-conv entry point.
+#include <algorithm>
+#include <memory>
+
+#include "pp_internal.h"
+
+static thread_local std::string g_last_error;
+
+void pp_set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int pp_ctx::ensure_scratch(size_t bytes) {
+    if (bytes <= scratch_bytes) return PP_OK;
+    if (scratch) {
+        PP_HIP_CHECK(hipStreamSynchronize(stream));
+        PP_HIP_CHECK(hipFree(scratch));
+        scratch = nullptr;
+        scratch_bytes = 0;
+    }
+    size_t want = std::max(bytes, size_t(1) << 20);
+    PP_HIP_CHECK(hipMalloc(&scratch, want));
+    scratch_bytes = want;
+    return PP_OK;
+}
+
+extern "C" {
+
+int pp_abi_version(void) { return PP_ABI_VERSION; }
+
+const char* pp_last_error(void) { return g_last_error.c_str(); }
+
+int pp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int pp_ctx_create(int device, pp_ctx** out) {
+    PP_REQUIRE(out != nullptr, "pp_ctx_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        pp_set_error("pp_ctx_create: no HIP device visible (%s) -- this library has no CPU fallback",
+                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return PP_ERR_HIP;
+    }
+    PP_REQUIRE(device >= 0 && device < n, "pp_ctx_create: device %d out of range [0,%d)", device, n);
+    PP_HIP_CHECK(hipSetDevice(device));
+    std::unique_ptr<pp_ctx> c(new pp_ctx());
+    c->device = device;
+    PP_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    PP_HIP_CHECK(hipEventCreate(&c->ev_start));
+    PP_HIP_CHECK(hipEventCreate(&c->ev_stop));
+    *out = c.release();
+    return PP_OK;
+}
+
+void pp_ctx_destroy(pp_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int pp_ctx_set_stream(pp_ctx* ctx, void* hip_stream) {
+    PP_REQUIRE(ctx, "pp_ctx_set_stream: ctx is NULL");
+    PP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) PP_HIP_CHECK(hipStreamDestroy(ctx->stream));
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    ctx->own_stream = false;
+    return PP_OK;
+}
+
+int pp_ctx_synchronize(pp_ctx* ctx) {
+    PP_REQUIRE(ctx, "pp_ctx_synchronize: ctx is NULL");
+    PP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PP_OK;
+}
+
+int pp_timer_start(pp_ctx* ctx) {
+    PP_REQUIRE(ctx, "pp_timer_start: ctx is NULL");
+    PP_HIP_CHECK(hipEventRecord(ctx->ev_start, ctx->stream));
+    return PP_OK;
+}
+
+int pp_timer_stop(pp_ctx* ctx, float* elapsed_ms) {
+    PP_REQUIRE(ctx && elapsed_ms, "pp_timer_stop: NULL argument");
+    PP_HIP_CHECK(hipEventRecord(ctx->ev_stop, ctx->stream));
+    PP_HIP_CHECK(hipEventSynchronize(ctx->ev_stop));
+    PP_HIP_CHECK(hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+    return PP_OK;
+}
+
+int pp_malloc(pp_ctx* ctx, size_t bytes, void** dptr) {
+    PP_REQUIRE(ctx && dptr, "pp_malloc: NULL argument");
+    PP_HIP_CHECK(hipSetDevice(ctx->device));
+    PP_HIP_CHECK(hipMalloc(dptr, bytes ? bytes : 1));
+    return PP_OK;
+}
+
+int pp_free(pp_ctx* ctx, void* dptr) {
+    PP_REQUIRE(ctx, "pp_free: ctx is NULL");
+    if (!dptr) return PP_OK;
+    PP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    PP_HIP_CHECK(hipFree(dptr));
+    return PP_OK;
+}
+
+int pp_memcpy_h2d(pp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    PP_REQUIRE(ctx && (bytes == 0 || (dst && src)), "pp_memcpy_h2d: NULL argument");
+    PP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PP_OK;
+}
+
+int pp_memcpy_d2h(pp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    PP_REQUIRE(ctx && (bytes == 0 || (dst && src)), "pp_memcpy_d2h: NULL argument");
+    PP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PP_OK;
+}
+
+}  // extern "C"
+
+// ---- layer programs ----------------------------------------------------------------------------
+
+struct pp_net {
+    pp_ctx* ctx = nullptr;
+    std::vector<pp_op> ops;
+    std::vector<pp_buf> bufs;
+    std::vector<size_t> buf_off;    // float offset of buffer b (sized for max_batch)
+    std::vector<size_t> buf_elems;  // per-sample floats
+    float* weights = nullptr;
+    size_t n_weights = 0;
+    float* arena = nullptr;
+    size_t arena_floats = 0;
+    int max_batch = 0;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_batch = 0;
+
+    float* buf_ptr(int b) const { return arena + buf_off[b]; }
+};
+
+static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
+    const int nb = (int)net.bufs.size();
+    PP_REQUIRE(op.in >= 0 && op.in < nb && op.out >= 0 && op.out < nb, "op %d: buffer id out of range", idx);
+    PP_REQUIRE(op.res1 < nb && op.res2 < nb, "op %d: residual buffer id out of range", idx);
+    const pp_buf& bi = net.bufs[op.in];
+    const pp_buf& bo = net.bufs[op.out];
+    if (op.type == PP_OP_CONV) {
+        PP_REQUIRE(bi.c == op.cin, "op %d: in buffer has %d channels, op.cin=%d", idx, bi.c, op.cin);
+        PP_REQUIRE(bo.c == op.cout, "op %d: out buffer has %d channels, op.cout=%d", idx, bo.c, op.cout);
+        const int ho = pp_conv_out_dim(bi.h, op.kh, op.stride, op.pad_h, op.dil_h);
+        const int wo = pp_conv_out_dim(bi.w, op.kw, op.stride, op.pad_w, op.dil_w);
+        PP_REQUIRE((ho << op.up_log2) == bo.h && (wo << op.up_log2) == bo.w,
+                   "op %d: conv output %dx%d (<<%d) does not match out buffer %dx%d", idx, ho, wo, op.up_log2,
+                   bo.h, bo.w);
+        const size_t kpad = ((size_t)op.kh * op.kw * op.cin + 15) / 16 * 16;
+        const size_t cpad = ((size_t)op.cout + 15) / 16 * 16;
+        PP_REQUIRE(op.w_off >= 0 && (size_t)op.w_off + kpad * cpad <= net.n_weights, "op %d: weights out of blob", idx);
+        PP_REQUIRE(op.b_off >= 0 && (size_t)op.b_off + cpad <= net.n_weights, "op %d: bias out of blob", idx);
+        PP_REQUIRE((op.w_off % 4) == 0 && (op.b_off % 4) == 0, "op %d: blob offsets must be 16-byte aligned", idx);
+        if (op.res1 >= 0) PP_REQUIRE(net.bufs[op.res1].c == op.cout, "op %d: res1 channel mismatch", idx);
+        if (op.res2 >= 0)
+            PP_REQUIRE(net.bufs[op.res2].c == op.cout && net.bufs[op.res2].h == bo.h && net.bufs[op.res2].w == bo.w,
+                       "op %d: res2 shape mismatch", idx);
+    } else if (op.type == PP_OP_MAXPOOL) {
+        PP_REQUIRE(bi.c == bo.c, "op %d: maxpool channel mismatch", idx);
+        PP_REQUIRE(pp_conv_out_dim(bi.h, op.kh, op.stride, op.pad_h, 1) == bo.h &&
+                       pp_conv_out_dim(bi.w, op.kw, op.stride, op.pad_w, 1) == bo.w,
+                   "op %d: maxpool output dims mismatch", idx);
+    } else if (op.type == PP_OP_COPY) {
+        PP_REQUIRE(bi.c == bo.c && bi.h == bo.h && bi.w == bo.w, "op %d: copy shape mismatch", idx);
+    } else {
+        pp_set_error("op %d: unsupported op type %d", idx, op.type);
+        return PP_ERR_UNSUPPORTED;
+    }
+    return PP_OK;
+}
+
+static int net_launch_op(pp_net* net, const pp_op& op, int batch) {
+    hipStream_t s = net->ctx->stream;
+    const pp_buf& bi = net->bufs[op.in];
+    const pp_buf& bo = net->bufs[op.out];
+    if (op.type == PP_OP_CONV) {
+        ConvArgs a{};
+        a.x = net->buf_ptr(op.in);
+        a.y = net->buf_ptr(op.out);
+        a.w = net->weights + op.w_off;
+        a.bias = net->weights + op.b_off;
+        a.res1 = op.res1 >= 0 ? net->buf_ptr(op.res1) : nullptr;
+        a.res2 = op.res2 >= 0 ? net->buf_ptr(op.res2) : nullptr;
+        a.N = batch; a.Hin = bi.h; a.Win = bi.w; a.Cin = op.cin;
+        a.Hout = bo.h >> op.up_log2; a.Wout = bo.w >> op.up_log2;
+        a.Cout = op.cout; a.CoutPad = (op.cout + 15) / 16 * 16;
+        a.KH = op.kh; a.KW = op.kw; a.stride = op.stride; a.pad_h = op.pad_h; a.pad_w = op.pad_w;
+        a.dil_h = op.dil_h; a.dil_w = op.dil_w;
+        a.K = op.kh * op.kw * op.cin; a.Kpad = (a.K + 15) / 16 * 16;
+        a.HWout = a.Hout * a.Wout; a.M = batch * a.HWout;
+        a.relu = op.relu; a.up_log2 = op.up_log2; a.out_nchw = op.out_nchw;
+        a.res1_shift = op.res1_shift; a.res1_off_w = op.res1_off_w;
+        a.res1_H = op.res1 >= 0 ? net->bufs[op.res1].h : 0;
+        a.res1_W = op.res1 >= 0 ? net->bufs[op.res1].w : 0;
+        return pp_launch_conv(a, s);
+    } else if (op.type == PP_OP_MAXPOOL) {
+        PoolArgs p{};
+        p.x = net->buf_ptr(op.in); p.y = net->buf_ptr(op.out);
+        p.N = batch; p.Hin = bi.h; p.Win = bi.w; p.C = bi.c; p.Hout = bo.h; p.Wout = bo.w;
+        p.KH = op.kh; p.KW = op.kw; p.stride = op.stride; p.pad_h = op.pad_h; p.pad_w = op.pad_w;
+        return pp_launch_maxpool(p, s);
+    } else if (op.type == PP_OP_COPY) {
+        PP_HIP_CHECK(hipMemcpyAsync(net->buf_ptr(op.out), net->buf_ptr(op.in),
+                                    (size_t)batch * net->buf_elems[op.in] * sizeof(float),
+                                    hipMemcpyDeviceToDevice, s));
+        return PP_OK;
+    }
+    return PP_ERR_UNSUPPORTED;
+}
+
+extern "C" {
+
+int pp_net_create(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, int n_bufs,
+                  const float* weights, size_t n_weights, int max_batch, pp_net** out) {
+    PP_REQUIRE(ctx && ops && bufs && weights && out, "pp_net_create: NULL argument");
+    PP_REQUIRE(n_ops > 0 && n_bufs > 0 && max_batch > 0, "pp_net_create: empty program");
+    *out = nullptr;
+    std::unique_ptr<pp_net> net(new pp_net());
+    net->ctx = ctx;
+    net->ops.assign(ops, ops + n_ops);
+    net->bufs.assign(bufs, bufs + n_bufs);
+    net->max_batch = max_batch;
+    net->n_weights = n_weights;
+    size_t off = 0;
+    for (int b = 0; b < n_bufs; ++b) {
+        PP_REQUIRE(bufs[b].h > 0 && bufs[b].w > 0 && bufs[b].c > 0, "buffer %d has an empty dim", b);
+        const size_t e = (size_t)bufs[b].h * bufs[b].w * bufs[b].c;
+        net->buf_elems.push_back(e);
+        net->buf_off.push_back(off);
+        off += (e * max_batch + 63) / 64 * 64;   // 256-byte aligned
+    }
+    net->arena_floats = off;
+    for (int i = 0; i < n_ops; ++i) {
+        int rc = net_check_op(*net, net->ops[i], i);
+        if (rc != PP_OK) return rc;
+    }
+    PP_HIP_CHECK(hipSetDevice(ctx->device));
+    PP_HIP_CHECK(hipMalloc((void**)&net->weights, n_weights * sizeof(float)));
+    PP_HIP_CHECK(hipMemcpyAsync(net->weights, weights, n_weights * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PP_HIP_CHECK(hipMalloc((void**)&net->arena, net->arena_floats * sizeof(float)));
+    PP_HIP_CHECK(hipMemsetAsync(net->arena, 0, net->arena_floats * sizeof(float), ctx->stream));
+    PP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *out = net.release();
+    return PP_OK;
+}
+
+void pp_net_destroy(pp_net* net) {
+    if (!net) return;
+    if (net->ctx && net->ctx->stream) (void)hipStreamSynchronize(net->ctx->stream);
+    if (net->graph_exec) (void)hipGraphExecDestroy(net->graph_exec);
+    if (net->weights) (void)hipFree(net->weights);
+    if (net->arena) (void)hipFree(net->arena);
+    delete net;
+}
+
+int pp_net_buffer(pp_net* net, int buf, void** dptr, size_t* bytes_per_sample) {
+    PP_REQUIRE(net && buf >= 0 && buf < (int)net->bufs.size(), "pp_net_buffer: bad buffer id");
+    if (dptr) *dptr = net->buf_ptr(buf);
+    if (bytes_per_sample) *bytes_per_sample = net->buf_elems[buf] * sizeof(float);
+    return PP_OK;
+}
+
+int pp_net_run(pp_net* net, int batch, int first_op, int last_op) {
+    PP_REQUIRE(net, "pp_net_run: net is NULL");
+    PP_REQUIRE(batch > 0 && batch <= net->max_batch, "pp_net_run: batch %d not in (0,%d]", batch, net->max_batch);
+    PP_REQUIRE(first_op >= 0 && last_op <= (int)net->ops.size() && first_op <= last_op, "pp_net_run: bad op range");
+    if (net->graph_exec && batch == net->graph_batch && first_op == 0 && last_op == (int)net->ops.size()) {
+        PP_HIP_CHECK(hipGraphLaunch(net->graph_exec, net->ctx->stream));
+        return PP_OK;
+    }
+    for (int i = first_op; i < last_op; ++i) {
+        int rc = net_launch_op(net, net->ops[i], batch);
+        if (rc != PP_OK) return rc;
+    }
+    return PP_OK;
+}
+
+int pp_net_capture(pp_net* net, int batch) {
+    PP_REQUIRE(net, "pp_net_capture: net is NULL");
+    PP_REQUIRE(batch > 0 && batch <= net->max_batch, "pp_net_capture: bad batch");
+    if (net->graph_exec) {
+        PP_HIP_CHECK(hipGraphExecDestroy(net->graph_exec));
+        net->graph_exec = nullptr;
+    }
+    hipStream_t s = net->ctx->stream;
+    PP_HIP_CHECK(hipStreamSynchronize(s));
+    hipGraph_t graph = nullptr;
+    PP_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = PP_OK;
+    for (size_t i = 0; i < net->ops.size() && rc == PP_OK; ++i) rc = net_launch_op(net, net->ops[i], batch);
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc != PP_OK) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    PP_HIP_CHECK(e);
+    PP_HIP_CHECK(hipGraphInstantiate(&net->graph_exec, graph, nullptr, nullptr, 0));
+    PP_HIP_CHECK(hipGraphDestroy(graph));
+    net->graph_batch = batch;
+    return PP_OK;
+}
+
+int pp_net_forward(pp_net* net, int batch, int in_buf, const float* in, int out_buf, float* out, int mem) {
+    PP_REQUIRE(net && in && out, "pp_net_forward: NULL argument");
+    PP_REQUIRE(in_buf >= 0 && in_buf < (int)net->bufs.size() && out_buf >= 0 && out_buf < (int)net->bufs.size(),
+               "pp_net_forward: bad buffer id");
+    PP_REQUIRE(batch > 0 && batch <= net->max_batch, "pp_net_forward: batch %d not in (0,%d]", batch, net->max_batch);
+    hipStream_t s = net->ctx->stream;
+    const hipMemcpyKind kin = mem == PP_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    const hipMemcpyKind kout = mem == PP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    PP_HIP_CHECK(hipMemcpyAsync(net->buf_ptr(in_buf), in, (size_t)batch * net->buf_elems[in_buf] * sizeof(float), kin, s));
+    int rc = pp_net_run(net, batch, 0, (int)net->ops.size());
+    if (rc != PP_OK) return rc;
+    PP_HIP_CHECK(hipMemcpyAsync(out, net->buf_ptr(out_buf), (size_t)batch * net->buf_elems[out_buf] * sizeof(float), kout, s));
+    PP_HIP_CHECK(hipStreamSynchronize(s));
+    return PP_OK;
+}
+
+int pp_net_profile(pp_net* net, int batch, float* ms_per_op) {
+    PP_REQUIRE(net, "pp_net_profile: net is NULL");
+    PP_REQUIRE(batch > 0 && batch <= net->max_batch, "pp_net_profile: bad batch");
+    hipStream_t s = net->ctx->stream;
+    const size_t n = net->ops.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) PP_HIP_CHECK(hipEventCreate(&e));
+    int rc = PP_OK;
+    PP_HIP_CHECK(hipEventRecord(ev[0], s));
+    for (size_t i = 0; i < n && rc == PP_OK; ++i) {
+        rc = net_launch_op(net, net->ops[i], batch);
+        if (rc == PP_OK && hipEventRecord(ev[i + 1], s) != hipSuccess) rc = PP_ERR_HIP;
+    }
+    if (rc == PP_OK && hipStreamSynchronize(s) != hipSuccess) rc = PP_ERR_HIP;
+    if (rc == PP_OK && ms_per_op) {
+        for (size_t i = 0; i < n; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            ms_per_op[i] = ms;
+        }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+int pp_conv2d(pp_ctx* ctx, const pp_op* op, int n, int hin, int win, const float* x, const float* w,
+              const float* bias, const float* res1, const float* res2, float* y, int res1_h, int res1_w,
+              int mem) {
+    PP_REQUIRE(ctx && op && x && w && bias && y, "pp_conv2d: NULL argument");
+    PP_REQUIRE(op->type == PP_OP_CONV, "pp_conv2d: op is not a conv");
+    PP_REQUIRE(n > 0 && hin > 0 && win > 0, "pp_conv2d: empty input");
+    ConvArgs a{};
+    a.N = n; a.Hin = hin; a.Win = win; a.Cin = op->cin;
+    a.Hout = pp_conv_out_dim(hin, op->kh, op->stride, op->pad_h, op->dil_h);
+    a.Wout = pp_conv_out_dim(win, op->kw, op->stride, op->pad_w, op->dil_w);
+    PP_REQUIRE(a.Hout > 0 && a.Wout > 0, "pp_conv2d: empty output");
+    a.Cout = op->cout; a.CoutPad = (op->cout + 15) / 16 * 16;
+    a.KH = op->kh; a.KW = op->kw; a.stride = op->stride; a.pad_h = op->pad_h; a.pad_w = op->pad_w;
+    a.dil_h = op->dil_h; a.dil_w = op->dil_w;
+    a.K = op->kh * op->kw * op->cin; a.Kpad = (a.K + 15) / 16 * 16;
+    a.HWout = a.Hout * a.Wout; a.M = n * a.HWout;
+    a.relu = op->relu; a.up_log2 = op->up_log2; a.out_nchw = op->out_nchw;
+    a.res1_shift = op->res1_shift; a.res1_off_w = op->res1_off_w;
+    const int Ho2 = a.Hout << op->up_log2, Wo2 = a.Wout << op->up_log2;
+    a.res1_H = res1 ? (res1_h > 0 ? res1_h : Ho2) : 0;
+    a.res1_W = res1 ? (res1_w > 0 ? res1_w : Wo2) : 0;
+    const size_t x_e = (size_t)n * hin * win * op->cin;
+    const size_t w_e = (size_t)a.Kpad * a.CoutPad;
+    const size_t b_e = a.CoutPad;
+    const size_t y_e = (size_t)n * Ho2 * Wo2 * op->cout;
+    const size_t r1_e = res1 ? (size_t)n * a.res1_H * a.res1_W * op->cout : 0;
+    const size_t r2_e = res2 ? y_e : 0;
+    if (mem == PP_MEM_DEVICE) {
+        a.x = x; a.w = w; a.bias = bias; a.res1 = res1; a.res2 = res2; a.y = y;
+        return pp_launch_conv(a, ctx->stream);
+    }
+    size_t total = 0;
+    for (size_t e : {x_e, w_e, b_e, y_e, r1_e, r2_e}) total += ScratchCursor::align(e * sizeof(float));
+    int rc = ctx->ensure_scratch(total);
+    if (rc != PP_OK) return rc;
+    ScratchCursor cur(ctx);
+    float* dx = cur.take<float>(x_e);
+    float* dw = cur.take<float>(w_e);
+    float* db = cur.take<float>(b_e);
+    float* dy = cur.take<float>(y_e);
+    float* dr1 = cur.take<float>(r1_e);
+    float* dr2 = cur.take<float>(r2_e);
+    hipStream_t s = ctx->stream;
+    PP_HIP_CHECK(hipMemcpyAsync(dx, x, x_e * 4, hipMemcpyHostToDevice, s));
+    PP_HIP_CHECK(hipMemcpyAsync(dw, w, w_e * 4, hipMemcpyHostToDevice, s));
+    PP_HIP_CHECK(hipMemcpyAsync(db, bias, b_e * 4, hipMemcpyHostToDevice, s));
+    if (res1) PP_HIP_CHECK(hipMemcpyAsync(dr1, res1, r1_e * 4, hipMemcpyHostToDevice, s));
+    if (res2) PP_HIP_CHECK(hipMemcpyAsync(dr2, res2, r2_e * 4, hipMemcpyHostToDevice, s));
+    a.x = dx; a.w = dw; a.bias = db; a.res1 = res1 ? dr1 : nullptr; a.res2 = res2 ? dr2 : nullptr; a.y = dy;
+    rc = pp_launch_conv(a, s);
+    if (rc != PP_OK) return rc;
+    PP_HIP_CHECK(hipMemcpyAsync(y, dy, y_e * 4, hipMemcpyDeviceToHost, s));
+    PP_HIP_CHECK(hipStreamSynchronize(s));
+    return PP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+// Internal declarations shared by the translation units of libposepipe_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "posepipe_hip.h"
+
+void pp_set_error(const char* fmt, ...);
+
+#define PP_HIP_CHECK(expr)                                                              \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess) {                                                         \
+            pp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                         __LINE__);                                                     \
+            return PP_ERR_HIP;                                                          \
+        }                                                                               \
+    } while (0)
+
+#define PP_REQUIRE(cond, ...)            \
+    do {                                 \
+        if (!(cond)) {                   \
+            pp_set_error(__VA_ARGS__);   \
+            return PP_ERR_ARG;           \
+        }                                \
+    } while (0)
+
+struct pp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // grow-only device scratch used to stage PP_MEM_HOST arguments
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    int ensure_scratch(size_t bytes);
+};
+
+// Simple bump allocator over ctx scratch for one call.
+struct ScratchCursor {
+    pp_ctx* ctx;
+    size_t off = 0;
+    explicit ScratchCursor(pp_ctx* c) : ctx(c) {}
+    static size_t align(size_t b) { return (b + 255) & ~size_t(255); }
+    template <class T>
+    T* take(size_t count) {
+        T* p = reinterpret_cast<T*>(static_cast<char*>(ctx->scratch) + off);
+        off += align(count * sizeof(T));
+        return p;
+    }
+};
+
+// ---- convolution (conv_igemm.hip) ----------------------------------------------------------
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* res1;
+    const float* res2;
+    float* y;
+    int N, Hin, Win, Cin, Hout, Wout, Cout, CoutPad;
+    int KH, KW, stride, pad_h, pad_w, dil_h, dil_w;
+    int K, Kpad, M, HWout;
+    int relu, up_log2, out_nchw;
+    int res1_shift, res1_off_w, res1_H, res1_W;
+};
+int pp_conv_out_dim(int in, int k, int stride, int pad, int dil);
+int pp_launch_conv(const ConvArgs& a, hipStream_t stream);
+
+struct PoolArgs {
+    const float* x;
+    float* y;
+    int N, Hin, Win, C, Hout, Wout, KH, KW, stride, pad_h, pad_w;
+};
+int pp_launch_maxpool(const PoolArgs& a, hipStream_t stream);

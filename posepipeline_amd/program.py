@@ -1,0 +1,261 @@
+"""Layer programs: the host-side description that pp_net_create() compiles.
+
+A backbone is a straight-line list of pp_op records over NHWC fp32 activation buffers plus one flat
+weight blob.  ProgramBuilder is used by posepipeline_amd/models/*.py to turn an architecture spec +
+a state_dict (torch layouts, mmpose / VideoPose3D key names) into that form:
+  * BatchNorm is folded into (weight, bias) here -- float64 math, rounded once to float32;
+  * conv weights are re-laid out to W[K][cout_pad16], k = (kh*KW + kw)*cin_pad4 + cin, K padded to 16;
+  * virtual buffers get physical ids by a linear-scan over lifetimes (exact-shape pooling).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib as L
+
+
+def fold_bn(weight, conv_bias, gamma, beta, mean, var, eps=1e-5):
+    """Fold eval-mode BatchNorm into the preceding conv.  float64, one rounding to float32."""
+    scale = gamma.astype(np.float64) / np.sqrt(var.astype(np.float64) + eps)
+    w = weight.astype(np.float64) * scale.reshape((-1,) + (1,) * (weight.ndim - 1))
+    b0 = np.zeros_like(scale) if conv_bias is None else conv_bias.astype(np.float64)
+    b = beta.astype(np.float64) + (b0 - mean.astype(np.float64)) * scale
+    return w.astype(np.float32), b.astype(np.float32)
+
+
+def pack_conv(weight, bias, cin_pad=None):
+    """[cout][cin][kh][kw] (or [cout][cin][k] for Conv1d) -> (W[Kpad][cout_pad16], bias[cout_pad16])."""
+    w = np.asarray(weight, dtype=np.float32)
+    if w.ndim == 3:  # Conv1d: treat as kh = 1
+        w = w[:, :, None, :]
+    cout, cin, kh, kw = w.shape
+    cin_p = cin_pad if cin_pad is not None else (cin + 3) // 4 * 4
+    assert cin_p % 4 == 0 and cin_p >= cin
+    cout_p = (cout + 15) // 16 * 16
+    k = kh * kw * cin_p
+    k_p = (k + 15) // 16 * 16
+    wk = np.zeros((kh, kw, cin_p, cout_p), dtype=np.float32)
+    wk[:, :, :cin, :cout] = np.transpose(w, (2, 3, 1, 0))
+    out = np.zeros((k_p, cout_p), dtype=np.float32)
+    out[:k] = wk.reshape(k, cout_p)
+    b = np.zeros((cout_p,), dtype=np.float32)
+    if bias is not None:
+        b[:cout] = np.asarray(bias, dtype=np.float32)
+    return out, b
+
+
+@dataclass
+class VBuf:
+    h: int
+    w: int
+    c: int
+    pinned: bool = False  # inputs / outputs keep their own physical buffer
+
+
+@dataclass
+class Program:
+    ops: list
+    bufs: list                      # physical (h, w, c)
+    blob: np.ndarray
+    named: dict = field(default_factory=dict)   # name -> physical buffer id
+    flops: float = 0.0              # algorithmic FLOPs per sample (2 * MACs of the real, unpadded convs)
+    op_flops: list = field(default_factory=list)
+    op_names: list = field(default_factory=list)
+
+
+class ProgramBuilder:
+    def __init__(self):
+        self.vbufs: list[VBuf] = []
+        self.vops: list[dict] = []
+        self.blob_parts: list[np.ndarray] = []
+        self.blob_len = 0
+        self.named: dict[str, int] = {}
+
+    # ---- buffers -----------------------------------------------------------------------------
+    def buf(self, h, w, c, name=None, pinned=False) -> int:
+        self.vbufs.append(VBuf(int(h), int(w), int(c), pinned or name is not None))
+        vid = len(self.vbufs) - 1
+        if name is not None:
+            self.named[name] = vid
+        return vid
+
+    def dims(self, vid):
+        b = self.vbufs[vid]
+        return b.h, b.w, b.c
+
+    def _add_blob(self, arr) -> int:
+        arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
+        off = self.blob_len
+        pad = (-arr.size) % 4
+        self.blob_parts.append(arr)
+        if pad:
+            self.blob_parts.append(np.zeros(pad, np.float32))
+        self.blob_len += arr.size + pad
+        return off
+
+    # ---- ops ---------------------------------------------------------------------------------
+    def conv(self, x, weight, bias, *, stride=1, pad=(0, 0), dil=(1, 1), relu=L.PP_RELU_NONE, res1=-1, res2=-1,
+             up_log2=0, out=None, out_nchw=False, res1_shift=0, res1_off_w=0, name="conv") -> int:
+        """weight: torch layout, BN already folded.  Returns the (virtual) output buffer."""
+        if isinstance(pad, int):
+            pad = (pad, pad)
+        if isinstance(dil, int):
+            dil = (dil, dil)
+        h, w, cin_buf = self.dims(x)
+        wt = np.asarray(weight)
+        if wt.ndim == 3:
+            wt = wt[:, :, None, :]
+        cout, cin, kh, kw = wt.shape
+        assert cin <= cin_buf and cin_buf % 4 == 0, (cin, cin_buf)
+        W, b = pack_conv(wt, bias, cin_pad=cin_buf)
+        ho = (h + 2 * pad[0] - dil[0] * (kh - 1) - 1) // stride + 1
+        wo = (w + 2 * pad[1] - dil[1] * (kw - 1) - 1) // stride + 1
+        if out is None:
+            out = self.buf(ho << up_log2, wo << up_log2, cout)
+        else:
+            assert self.dims(out) == (ho << up_log2, wo << up_log2, cout), (self.dims(out), ho, wo, cout)
+        w_off = self._add_blob(W)
+        b_off = self._add_blob(b)
+        self.vops.append(dict(type=L.PP_OP_CONV, in_=x, out=out, res1=res1, res2=res2, cin=cin_buf, cout=cout, kh=kh,
+                              kw=kw, stride=stride, pad_h=pad[0], pad_w=pad[1], dil_h=dil[0], dil_w=dil[1], relu=relu,
+                              up_log2=up_log2, out_nchw=int(out_nchw), res1_shift=res1_shift, res1_off_w=res1_off_w,
+                              w_off=w_off, b_off=b_off, name=name,
+                              flops=2.0 * ho * wo * cout * cin * kh * kw))
+        return out
+
+    def maxpool(self, x, k, stride, pad, name="maxpool") -> int:
+        h, w, c = self.dims(x)
+        ho = (h + 2 * pad - (k - 1) - 1) // stride + 1
+        wo = (w + 2 * pad - (k - 1) - 1) // stride + 1
+        out = self.buf(ho, wo, c)
+        self.vops.append(dict(type=L.PP_OP_MAXPOOL, in_=x, out=out, res1=-1, res2=-1, cin=c, cout=c, kh=k, kw=k,
+                              stride=stride, pad_h=pad, pad_w=pad, dil_h=1, dil_w=1, relu=0, up_log2=0, out_nchw=0,
+                              res1_shift=0, res1_off_w=0, w_off=0, b_off=0, name=name, flops=0.0))
+        return out
+
+    # ---- finalize ----------------------------------------------------------------------------
+    def build(self) -> Program:
+        n_v = len(self.vbufs)
+        last_use = [-1] * n_v
+        first_def = [None] * n_v
+        for i, op in enumerate(self.vops):
+            for key in ("in_", "res1", "res2", "out"):
+                v = op[key]
+                if v >= 0:
+                    last_use[v] = i
+            if first_def[op["out"]] is None:
+                first_def[op["out"]] = i
+        phys_dims: list[tuple] = []
+        free: dict[tuple, list[int]] = {}
+        v2p = [-1] * n_v
+        # pinned buffers (inputs, named outputs) first, never recycled
+        for v, b in enumerate(self.vbufs):
+            if b.pinned:
+                phys_dims.append((b.h, b.w, b.c))
+                v2p[v] = len(phys_dims) - 1
+        for i, op in enumerate(self.vops):
+            v = op["out"]
+            if v2p[v] < 0:
+                key = self.dims(v)
+                pool = free.get(key, [])
+                # never alias an operand of this very op
+                busy = {v2p[op[k]] for k in ("in_", "res1", "res2") if op[k] >= 0}
+                pick = next((p for p in pool if p not in busy), None)
+                if pick is not None:
+                    pool.remove(pick)
+                    v2p[v] = pick
+                else:
+                    phys_dims.append(key)
+                    v2p[v] = len(phys_dims) - 1
+            # release operands whose last use is this op
+            for key in ("in_", "res1", "res2", "out"):
+                u = op[key]
+                if u >= 0 and last_use[u] == i and not self.vbufs[u].pinned and v2p[u] >= 0:
+                    lst = free.setdefault(self.dims(u), [])
+                    if v2p[u] not in lst:
+                        lst.append(v2p[u])
+        ops = []
+        for op in self.vops:
+            rec = L.pp_op()
+            for k, val in op.items():
+                if k in ("name", "flops"):
+                    continue
+                if k in ("in_", "out", "res1", "res2"):
+                    val = v2p[val] if val >= 0 else -1
+                setattr(rec, k, int(val))
+            ops.append(rec)
+        blob = np.concatenate(self.blob_parts) if self.blob_parts else np.zeros(4, np.float32)
+        named = {k: v2p[v] for k, v in self.named.items()}
+        return Program(ops=ops, bufs=phys_dims, blob=blob, named=named,
+                       flops=float(sum(op["flops"] for op in self.vops)),
+                       op_flops=[op["flops"] for op in self.vops], op_names=[op["name"] for op in self.vops])
+
+
+class Net:
+    """pp_net handle: resident weights + activation arena on one Context."""
+
+    def __init__(self, ctx: L.Context, prog: Program, max_batch: int):
+        self.ctx = ctx
+        self.prog = prog
+        self.max_batch = int(max_batch)
+        lib = ctx.lib
+        n_ops = len(prog.ops)
+        ops = (L.pp_op * n_ops)(*prog.ops)
+        bufs = (L.pp_buf * len(prog.bufs))(*[L.pp_buf(*d) for d in prog.bufs])
+        h = C.c_void_p()
+        blob = np.ascontiguousarray(prog.blob, dtype=np.float32)
+        L.check(lib.pp_net_create(ctx.handle, ops, n_ops, bufs, len(prog.bufs), L.ptr(blob), blob.size, self.max_batch,
+                                  C.byref(h)), "pp_net_create")
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.pp_net_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def buffer(self, name_or_id):
+        """(device pointer, bytes per sample, (h, w, c))"""
+        pid = self.prog.named[name_or_id] if isinstance(name_or_id, str) else int(name_or_id)
+        p = C.c_void_p()
+        nb = C.c_size_t()
+        L.check(self.ctx.lib.pp_net_buffer(self.handle, pid, C.byref(p), C.byref(nb)), "pp_net_buffer")
+        return int(p.value), int(nb.value), self.prog.bufs[pid]
+
+    def run(self, batch, first=0, last=None):
+        last = len(self.prog.ops) if last is None else last
+        L.check(self.ctx.lib.pp_net_run(self.handle, batch, first, last), "pp_net_run")
+
+    def capture(self, batch):
+        L.check(self.ctx.lib.pp_net_capture(self.handle, batch), "pp_net_capture")
+
+    def forward(self, x: np.ndarray, in_name="input", out_name="output") -> np.ndarray:
+        """Host convenience: x [n][h][w][c] fp32 NHWC -> named output buffer as numpy."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[0]
+        pin, pout = self.prog.named[in_name], self.prog.named[out_name]
+        assert tuple(x.shape[1:]) == tuple(self.prog.bufs[pin]), (x.shape, self.prog.bufs[pin])
+        oh, ow, oc = self.prog.bufs[pout]
+        out = np.empty((n, oh, ow, oc), dtype=np.float32)
+        L.check(self.ctx.lib.pp_net_forward(self.handle, n, pin, L.ptr(x), pout, L.ptr(out), L.PP_MEM_HOST),
+                "pp_net_forward")
+        return out
+
+    def read(self, name_or_id, batch) -> np.ndarray:
+        dptr, nb, (h, w, c) = self.buffer(name_or_id)
+        out = np.empty((batch, h, w, c), dtype=np.float32)
+        self.ctx.d2h(out, dptr)
+        return out
+
+    def profile(self, batch) -> np.ndarray:
+        ms = np.zeros(len(self.prog.ops), dtype=np.float32)
+        L.check(self.ctx.lib.pp_net_profile(self.handle, batch, L.ptr(ms)), "pp_net_profile")
+        return ms
