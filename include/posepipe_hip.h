@@ -46,6 +46,7 @@ typedef enum { PP_MEM_HOST = 0, PP_MEM_DEVICE = 1 } pp_mem_kind;
 typedef struct pp_ctx pp_ctx;   /* device + stream + scratch */
 typedef struct pp_net pp_net;   /* a compiled layer program + resident weights/activations */
 typedef struct pp_tracker pp_tracker; /* host-side multi-object tracker state */
+typedef struct pp_topdown pp_topdown; /* fused top-down 2D stage (crop -> backbone -> decode) */
 
 /* ---- library / context ------------------------------------------------------------------ */
 int pp_abi_version(void);
@@ -112,7 +113,7 @@ int pp_net_create(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, 
 void pp_net_destroy(pp_net* net);
 /* device address of activation buffer `buf` (batch-major, then the pp_buf layout) */
 int pp_net_buffer(pp_net* net, int buf, void** dptr, size_t* bytes_per_sample);
-/* run ops [first, last) for `batch` samples; inputs must already be in their buffers */
+/* run ops [first, last) for `batch` samples (last < 0: to the end); inputs must already be in their buffers */
 int pp_net_run(pp_net* net, int batch, int first_op, int last_op);
 /* convenience: copy `in` into buffer in_buf, run everything, copy buffer out_buf to `out` */
 int pp_net_forward(pp_net* net, int batch, int in_buf, const float* in, int out_buf, float* out,
@@ -162,6 +163,30 @@ int pp_flip_merge_decode(pp_ctx* ctx, const float* hm, const float* hm_flip, int
                          int w, const int32_t* flip_perm, int shift_heatmap, int post,
                          int blur_kernel, const float* center_scale, float* kpts, float* merged,
                          int mem);
+
+/* ---- fused top-down 2D stage -------------------------------------------------------------------
+ * The batched body of the per-frame loop at pose_pipeline/wrappers/mmpose.py:60-76: for every
+ * (frame, bbox) pair crop + normalise (+ mirrored copy), run the backbone program `net`, flip-merge
+ * and decode.  All parameters stay resident; one stream synchronisation per call.
+ * flip_perm == NULL disables flip_test.  Absent persons (NaN bbox) produce zero rows
+ * (wrappers/mmpose.py:67-69) and valid[i] = 0.
+ */
+int pp_topdown_create(pp_net* net, int in_buf, int out_buf, int num_joints, const int32_t* flip_perm,
+                      int shift_heatmap, int post, int blur_kernel, const float* lut,
+                      const int32_t* chan_map, pp_topdown** out);
+void pp_topdown_destroy(pp_topdown* t);
+/* frames [n_frames][h][w][3] u8 (host or device per frames_mem); kpts [n_person][K][3] fp32 */
+int pp_topdown_run(pp_topdown* t, const uint8_t* frames, int n_frames, int h, int w, int frames_mem,
+                   const int32_t* frame_idx, const double* bbox_tlwh, int n_person, float* kpts,
+                   int kpts_mem, int32_t* valid);
+/* BASELINE config 2: the person crops are already normalised tensors [n][in_h][in_w][4] fp32;
+ * center_scale [n][4] is a host array. */
+int pp_topdown_run_precropped(pp_topdown* t, const float* x_nhwc4, int x_mem, const float* center_scale,
+                              int n_person, float* kpts, int kpts_mem);
+
+/* HIP-event stage times of the last pp_topdown_run*: ms3 = {pre (copies, crop / mirror), backbone program,
+ * flip-merge + decode}, measured on the ctx stream. */
+int pp_topdown_timing(pp_topdown* t, float* ms3);
 
 /* ---- NMS -------------------------------------------------------------------------------------
  * Replaces mmcv-full `nms` / `batched_nms` reached from the Faster-RCNN RPN and RoI head

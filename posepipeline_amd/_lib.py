@@ -81,6 +81,11 @@ SIGNATURES = {
     "pp_net_profile": (_i, [_vp, _i, _vp]),
     "pp_conv2d": (_i, [_vp, C.POINTER(pp_op), _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     "pp_crop_affine_normalize": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
+    "pp_topdown_create": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, C.POINTER(_vp)]),
+    "pp_topdown_destroy": (None, [_vp]),
+    "pp_topdown_run": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "pp_topdown_run_precropped": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i]),
+    "pp_topdown_timing": (_i, [_vp, _vp]),
     "pp_flip_merge_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i]),
 }
 

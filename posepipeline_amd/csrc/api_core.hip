@@ -232,6 +232,14 @@ static int net_launch_op(pp_net* net, const pp_op& op, int batch) {
     return PP_ERR_UNSUPPORTED;
 }
 
+int pp_net_dims(pp_net* net, int buf, int* h, int* w, int* c) {
+    if (!net || buf < 0 || buf >= (int)net->bufs.size()) return PP_ERR_ARG;
+    *h = net->bufs[buf].h; *w = net->bufs[buf].w; *c = net->bufs[buf].c;
+    return PP_OK;
+}
+int pp_net_max_batch(pp_net* net) { return net ? net->max_batch : 0; }
+pp_ctx* pp_net_ctx(pp_net* net) { return net ? net->ctx : nullptr; }
+
 extern "C" {
 
 int pp_net_create(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, int n_bufs,
@@ -287,6 +295,7 @@ int pp_net_buffer(pp_net* net, int buf, void** dptr, size_t* bytes_per_sample) {
 int pp_net_run(pp_net* net, int batch, int first_op, int last_op) {
     PP_REQUIRE(net, "pp_net_run: net is NULL");
     PP_REQUIRE(batch > 0 && batch <= net->max_batch, "pp_net_run: batch %d not in (0,%d]", batch, net->max_batch);
+    if (last_op < 0) last_op = (int)net->ops.size();
     PP_REQUIRE(first_op >= 0 && last_op <= (int)net->ops.size() && first_op <= last_op, "pp_net_run: bad op range");
     if (net->graph_exec && batch == net->graph_batch && first_op == 0 && last_op == (int)net->ops.size()) {
         PP_HIP_CHECK(hipGraphLaunch(net->graph_exec, net->ctx->stream));

@@ -19,12 +19,6 @@
 
 namespace {
 
-struct PersonXform {
-    double a00, a01, b0, a10, a11, b1;  // inverse map dst -> src (OpenCV warpAffine, after inversion)
-    int frame;
-    int valid;
-};
-
 __device__ __forceinline__ int sat_round_i32(double v) {
     // cv::saturate_cast<int>(double) == cvRound: round-half-to-even, saturating
     double r = rint(v);
@@ -92,6 +86,16 @@ __global__ __launch_bounds__(256) void crop_affine_kernel(const uint8_t* __restr
     }
 }
 
+__global__ __launch_bounds__(256) void flip_w_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                     size_t rows, int w) {
+    const size_t total = rows * w;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / w;
+        const int x = (int)(i - r * w);
+        dst[r * w + (w - 1 - x)] = src[i];
+    }
+}
+
 // cv::solve(DECOMP_LU) restated for the 6x6 system of cv2.getAffineTransform: Gaussian elimination
 // with partial pivoting in double.
 bool solve6(double A[6][6], double b[6], double x[6]) {
@@ -123,7 +127,7 @@ bool solve6(double A[6][6], double b[6], double x[6]) {
 }  // namespace
 
 // mmpose `_box2cs` + `get_affine_transform(rot=0)` + OpenCV's inversion.  Returns false for NaN boxes.
-static bool person_transform(const double* bb, int out_w, int out_h, float cs[4], PersonXform* t) {
+bool pp_person_transform(const double* bb, int out_w, int out_h, float cs[4], PersonXform* t) {
     t->valid = 0;
     cs[0] = cs[1] = cs[2] = cs[3] = 0.f;
     if (std::isnan(bb[0]) || std::isnan(bb[1]) || std::isnan(bb[2]) || std::isnan(bb[3])) return false;
@@ -172,6 +176,28 @@ static bool person_transform(const double* bb, int out_w, int out_h, float cs[4]
     return true;
 }
 
+int pp_enqueue_crop(hipStream_t s, const uint8_t* frames, int h, int w, const PersonXform* xf, int n_person,
+                    int out_w, int out_h, const float* lut, const int32_t chan_map[3], int flip, float* out,
+                    uint8_t* crop_u8) {
+    if (n_person <= 0) return PP_OK;
+    const int npix = out_w * out_h;
+    dim3 grid(std::min((npix + 255) / 256, 64), n_person);
+    hipLaunchKernelGGL(crop_affine_kernel, grid, dim3(256), 0, s, frames, h, w, xf, n_person, out_w, out_h, lut,
+                       chan_map[0], chan_map[1], chan_map[2], flip, out, crop_u8);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}
+
+int pp_enqueue_flip_w(hipStream_t s, const float* src, float* dst, int n, int h, int w) {
+    const size_t rows = (size_t)n * h;
+    if (rows == 0) return PP_OK;
+    const int blocks = (int)std::min<size_t>((rows * w + 255) / 256, 2048);
+    hipLaunchKernelGGL(flip_w_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const float4*>(src),
+                       reinterpret_cast<float4*>(dst), rows, w);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}
+
 extern "C" int pp_crop_affine_normalize(pp_ctx* ctx, const uint8_t* frames, int n_frames, int h, int w,
                                         const int32_t* frame_idx, const double* bbox_tlwh, int n_person,
                                         int out_w, int out_h, const float* lut, const int32_t* chan_map,
@@ -185,7 +211,7 @@ extern "C" int pp_crop_affine_normalize(pp_ctx* ctx, const uint8_t* frames, int 
     for (int i = 0; i < n_person; ++i) {
         PP_REQUIRE(frame_idx[i] >= 0 && frame_idx[i] < n_frames, "frame_idx[%d]=%d out of range", i, frame_idx[i]);
         float cs[4];
-        person_transform(bbox_tlwh + 4 * i, out_w, out_h, cs, &xf[i]);
+        pp_person_transform(bbox_tlwh + 4 * i, out_w, out_h, cs, &xf[i]);
         xf[i].frame = frame_idx[i];
         if (center_scale) memcpy(center_scale + 4 * i, cs, sizeof(cs));
         if (valid) valid[i] = xf[i].valid;
@@ -215,11 +241,8 @@ extern "C" int pp_crop_affine_normalize(pp_ctx* ctx, const uint8_t* frames, int 
         dout = cur.take<float>(out_e);
         if (crop_u8) dcrop = cur.take<uint8_t>(crop_b);
     }
-    const int npix = out_w * out_h;
-    dim3 grid(std::min((npix + 255) / 256, 64), n_person);
-    hipLaunchKernelGGL(crop_affine_kernel, grid, dim3(256), 0, s, dframes, h, w, dxf, n_person, out_w, out_h, dlut,
-                       chan_map[0], chan_map[1], chan_map[2], flip, dout, dcrop);
-    PP_HIP_CHECK(hipGetLastError());
+    rc = pp_enqueue_crop(s, dframes, h, w, dxf, n_person, out_w, out_h, dlut, chan_map, flip, dout, dcrop);
+    if (rc != PP_OK) return rc;
     // the staged transforms / LUT live in ctx scratch: finish before another call can reuse it
     if (mem == PP_MEM_HOST) {
         PP_HIP_CHECK(hipMemcpyAsync(out, dout, out_e * 4, hipMemcpyDeviceToHost, s));

@@ -194,35 +194,56 @@ __global__ __launch_bounds__(256) void flip_merge_decode_kernel(DecodeArgs a) {
 
 }  // namespace
 
+static void fill_gaussian_taps(DecodeArgs& a) {
+    // cv::getGaussianKernel(ksize, sigma<=0): sigma = 0.3*((ksize-1)*0.5 - 1) + 0.8, taps in double,
+    // normalised to sum 1, stored as float32
+    const int ks = a.blur_kernel;
+    const double sigma = 0.3 * ((ks - 1) * 0.5 - 1) + 0.8;
+    const double scale2x = -0.5 / (sigma * sigma);
+    double tmp[MAX_BLUR], sum = 0;
+    for (int i = 0; i < ks; ++i) {
+        const double x = i - (ks - 1) * 0.5;
+        tmp[i] = std::exp(scale2x * x * x);
+        sum += tmp[i];
+    }
+    sum = 1.0 / sum;
+    for (int i = 0; i < ks; ++i) a.gk[i] = (float)(tmp[i] * sum);
+}
+
+int pp_enqueue_decode(hipStream_t s, const DecodeParams& p, const float* hm, const float* hm_flip,
+                      const int32_t* flip_perm, const float* center_scale, float* kpts, float* merged) {
+    PP_REQUIRE(p.n >= 0 && p.k > 0 && p.h > 0 && p.w > 0, "decode: bad dims");
+    PP_REQUIRE(!hm_flip || flip_perm, "decode: hm_flip given without flip_perm");
+    PP_REQUIRE(p.post == 0 || p.post == 1 || p.post == -1, "decode: post must be -1 (none), 0 (default) or 1 (unbiased)");
+    PP_REQUIRE(p.post != 1 || ((p.blur_kernel & 1) && p.blur_kernel >= 3 && p.blur_kernel <= MAX_BLUR),
+               "decode: blur_kernel must be odd in [3,%d]", MAX_BLUR);
+    const size_t lds = (size_t)2 * p.h * p.w * sizeof(float);
+    PP_REQUIRE(lds <= 160 * 1024 - 64, "decode: heatmap %dx%d does not fit LDS", p.h, p.w);
+    if (p.n == 0) return PP_OK;
+    DecodeArgs a{};
+    a.n = p.n; a.k = p.k; a.h = p.h; a.w = p.w;
+    a.shift_heatmap = p.shift_heatmap; a.post = p.post; a.blur_kernel = p.blur_kernel;
+    if (p.post == 1) fill_gaussian_taps(a);
+    a.hm = hm; a.hm_flip = hm_flip; a.flip_perm = flip_perm; a.center_scale = center_scale;
+    a.kpts = kpts; a.merged = merged;
+    static bool attr_set = false;
+    if (!attr_set && lds > 64 * 1024) {
+        PP_HIP_CHECK(hipFuncSetAttribute((const void*)flip_merge_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(flip_merge_decode_kernel, dim3(p.n * p.k), dim3(256), lds, s, a);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}
+
 extern "C" int pp_flip_merge_decode(pp_ctx* ctx, const float* hm, const float* hm_flip, int n, int k, int h, int w,
                                     const int32_t* flip_perm, int shift_heatmap, int post, int blur_kernel,
                                     const float* center_scale, float* kpts, float* merged, int mem) {
     PP_REQUIRE(ctx && hm && center_scale && kpts, "pp_flip_merge_decode: NULL argument");
     PP_REQUIRE(n >= 0 && k > 0 && h > 0 && w > 0, "pp_flip_merge_decode: bad dims");
     PP_REQUIRE(!hm_flip || flip_perm, "pp_flip_merge_decode: hm_flip given without flip_perm");
-    PP_REQUIRE(post == 0 || post == 1 || post == -1, "pp_flip_merge_decode: post must be -1 (none), 0 (default) or 1 (unbiased)");
-    PP_REQUIRE(post != 1 || ((blur_kernel & 1) && blur_kernel >= 3 && blur_kernel <= MAX_BLUR),
-               "pp_flip_merge_decode: blur_kernel must be odd in [3,%d]", MAX_BLUR);
-    const size_t lds = (size_t)2 * h * w * sizeof(float);
-    PP_REQUIRE(lds <= 160 * 1024 - 64, "pp_flip_merge_decode: heatmap %dx%d does not fit LDS", h, w);
     if (n == 0) return PP_OK;
-    DecodeArgs a{};
-    a.n = n; a.k = k; a.h = h; a.w = w;
-    a.shift_heatmap = shift_heatmap; a.post = post; a.blur_kernel = blur_kernel;
-    if (post == 1) {
-        // cv::getGaussianKernel(ksize, sigma<=0): sigma = 0.3*((ksize-1)*0.5 - 1) + 0.8, taps in double,
-        // normalised to sum 1, stored as float32
-        const double sigma = 0.3 * ((blur_kernel - 1) * 0.5 - 1) + 0.8;
-        const double scale2x = -0.5 / (sigma * sigma);
-        double tmp[MAX_BLUR], sum = 0;
-        for (int i = 0; i < blur_kernel; ++i) {
-            const double x = i - (blur_kernel - 1) * 0.5;
-            tmp[i] = std::exp(scale2x * x * x);
-            sum += tmp[i];
-        }
-        sum = 1.0 / sum;
-        for (int i = 0; i < blur_kernel; ++i) a.gk[i] = (float)(tmp[i] * sum);
-    }
+    const DecodeParams dp{n, k, h, w, shift_heatmap, post, blur_kernel};
     const size_t hm_e = (size_t)n * k * h * w;
     hipStream_t s = ctx->stream;
     size_t need = ScratchCursor::align(k * sizeof(int32_t));
@@ -234,10 +255,9 @@ extern "C" int pp_flip_merge_decode(pp_ctx* ctx, const float* hm, const float* h
     if (flip_perm) {
         for (int i = 0; i < k; ++i) PP_REQUIRE(flip_perm[i] >= 0 && flip_perm[i] < k, "flip_perm[%d] out of range", i);
         PP_HIP_CHECK(hipMemcpyAsync(dperm, flip_perm, k * sizeof(int32_t), hipMemcpyHostToDevice, s));
-        a.flip_perm = dperm;
     }
-    float* dk = kpts;
-    float* dm = merged;
+    const float *a_hm = hm, *a_hf = hm_flip, *a_cs = center_scale;
+    float *dk = kpts, *dm = merged;
     if (mem == PP_MEM_HOST) {
         float* dh = cur.take<float>(hm_e);
         float* dhf = cur.take<float>(hm_e);
@@ -247,19 +267,11 @@ extern "C" int pp_flip_merge_decode(pp_ctx* ctx, const float* hm, const float* h
         PP_HIP_CHECK(hipMemcpyAsync(dh, hm, hm_e * 4, hipMemcpyHostToDevice, s));
         if (hm_flip) PP_HIP_CHECK(hipMemcpyAsync(dhf, hm_flip, hm_e * 4, hipMemcpyHostToDevice, s));
         PP_HIP_CHECK(hipMemcpyAsync(dcs, center_scale, (size_t)n * 16, hipMemcpyHostToDevice, s));
-        a.hm = dh; a.hm_flip = hm_flip ? dhf : nullptr; a.center_scale = dcs;
-        a.merged = merged ? dm : nullptr;
-    } else {
-        a.hm = hm; a.hm_flip = hm_flip; a.center_scale = center_scale; a.merged = merged;
+        a_hm = dh; a_hf = hm_flip ? dhf : nullptr; a_cs = dcs;
+        if (!merged) dm = nullptr;
     }
-    a.kpts = dk;
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        PP_HIP_CHECK(hipFuncSetAttribute((const void*)flip_merge_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(flip_merge_decode_kernel, dim3(n * k), dim3(256), lds, s, a);
-    PP_HIP_CHECK(hipGetLastError());
+    rc = pp_enqueue_decode(s, dp, a_hm, a_hf, flip_perm ? dperm : nullptr, a_cs, dk, dm);
+    if (rc != PP_OK) return rc;
     if (mem == PP_MEM_HOST) {
         PP_HIP_CHECK(hipMemcpyAsync(kpts, dk, (size_t)n * k * 12, hipMemcpyDeviceToHost, s));
         if (merged) PP_HIP_CHECK(hipMemcpyAsync(merged, dm, hm_e * 4, hipMemcpyDeviceToHost, s));

@@ -77,3 +77,24 @@ struct PoolArgs {
     int N, Hin, Win, C, Hout, Wout, KH, KW, stride, pad_h, pad_w;
 };
 int pp_launch_maxpool(const PoolArgs& a, hipStream_t stream);
+
+// ---- top-down pre/post (crop_affine.hip, dark_decode.hip) ----------------------------------------
+struct PersonXform {
+    double a00, a01, b0, a10, a11, b1;  // inverse map dst -> src (OpenCV warpAffine, after inversion)
+    int frame;
+    int valid;
+};
+// mmpose `_box2cs` + `get_affine_transform(rot=0)` + OpenCV's inversion; false for NaN boxes
+bool pp_person_transform(const double* bbox_tlwh, int out_w, int out_h, float center_scale[4], PersonXform* t);
+// all pointers are device pointers; nothing is synchronised
+int pp_enqueue_crop(hipStream_t s, const uint8_t* frames, int h, int w, const PersonXform* xf, int n_person,
+                    int out_w, int out_h, const float* lut, const int32_t chan_map[3], int flip, float* out,
+                    uint8_t* crop_u8);
+int pp_enqueue_flip_w(hipStream_t s, const float* src, float* dst, int n, int h, int w);  // NHWC4 mirror
+
+struct DecodeParams {
+    int n, k, h, w;
+    int shift_heatmap, post, blur_kernel;
+};
+int pp_enqueue_decode(hipStream_t s, const DecodeParams& p, const float* hm, const float* hm_flip,
+                      const int32_t* flip_perm, const float* center_scale, float* kpts, float* merged);

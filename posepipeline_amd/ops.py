@@ -60,3 +60,73 @@ def flip_merge_decode(ctx: L.Context, hm: np.ndarray, hm_flip, center_scale, fli
                                          post_i, int(blur_kernel), L.ptr(cs), L.ptr(kp), L.ptr(merged), L.PP_MEM_HOST),
             "pp_flip_merge_decode")
     return kp, merged
+
+
+class TopDown:
+    """pp_topdown handle: crop/normalise -> backbone -> flip-merge + decode, parameters resident."""
+
+    def __init__(self, net, num_joints=17, flip_perm=None, shift_heatmap=True, post="unbiased", blur_kernel=17,
+                 lut=None, chan_map=(0, 1, 2), in_name="input", out_name="output"):
+        self.net = net
+        self.ctx = net.ctx
+        self.k = int(num_joints)
+        lut = normalize_lut() if lut is None else np.ascontiguousarray(lut, np.float32)
+        cm = np.asarray(chan_map, np.int32)
+        perm = None if flip_perm is None else np.ascontiguousarray(flip_perm, np.int32)
+        post_i = {"unbiased": 1, "default": 0, None: -1}[post]
+        h = C.c_void_p()
+        L.check(self.ctx.lib.pp_topdown_create(net.handle, net.prog.named[in_name], net.prog.named[out_name], self.k,
+                                               L.ptr(perm), int(shift_heatmap), post_i, int(blur_kernel), L.ptr(lut),
+                                               L.ptr(cm), C.byref(h)), "pp_topdown_create")
+        self.handle = h
+        self.flip = perm is not None
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.ctx.lib.pp_topdown_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, frames, frame_idx, bboxes, frames_dev_shape=None):
+        """frames: numpy [F][H][W][3] u8, or a device pointer (int) with frames_dev_shape=(F,H,W).
+        Returns (kpts [P][K][3] fp32, valid [P] int32)."""
+        bboxes = np.ascontiguousarray(bboxes, np.float64).reshape(-1, 4)
+        p = bboxes.shape[0]
+        frame_idx = np.ascontiguousarray(frame_idx, np.int32)
+        if isinstance(frames, np.ndarray):
+            frames = np.ascontiguousarray(frames, np.uint8)
+            f, h, w, _ = frames.shape
+            fmem = L.PP_MEM_HOST
+        else:
+            f, h, w = frames_dev_shape
+            fmem = L.PP_MEM_DEVICE
+        kp = np.empty((p, self.k, 3), np.float32)
+        valid = np.zeros((p,), np.int32)
+        L.check(self.ctx.lib.pp_topdown_run(self.handle, L.ptr(frames), f, h, w, fmem, L.ptr(frame_idx), L.ptr(bboxes), p,
+                                            L.ptr(kp), L.PP_MEM_HOST, L.ptr(valid)), "pp_topdown_run")
+        return kp, valid
+
+    def run_precropped(self, x, center_scale, n=None):
+        """x: numpy [N][H][W][4] fp32 or device pointer (int, with n given).  Returns kpts [N][K][3]."""
+        if isinstance(x, np.ndarray):
+            x = np.ascontiguousarray(x, np.float32)
+            n = x.shape[0]
+            xmem = L.PP_MEM_HOST
+        else:
+            xmem = L.PP_MEM_DEVICE
+        cs = np.ascontiguousarray(center_scale, np.float32).reshape(n, 4)
+        kp = np.empty((n, self.k, 3), np.float32)
+        L.check(self.ctx.lib.pp_topdown_run_precropped(self.handle, L.ptr(x), xmem, L.ptr(cs), n, L.ptr(kp),
+                                                       L.PP_MEM_HOST), "pp_topdown_run_precropped")
+        return kp
+
+    def timing(self):
+        """HIP-event stage times of the last run, ms: (pre, backbone, decode)."""
+        ms = np.zeros(3, np.float32)
+        L.check(self.ctx.lib.pp_topdown_timing(self.handle, L.ptr(ms)), "pp_topdown_timing")
+        return tuple(float(v) for v in ms)
