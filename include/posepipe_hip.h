@@ -190,14 +190,15 @@ int pp_topdown_timing(pp_topdown* t, float* ms3);
 
 /* ---- NMS -------------------------------------------------------------------------------------
  * Replaces mmcv-full `nms` / `batched_nms` reached from the Faster-RCNN RPN and RoI head
- * (faster_rcnn_r50_fpn.py:101-109): boxes [n][4] x1y1x2y2 fp32, scores [n]; suppress IoU > thr,
- * area = w*h; keep[] receives indices in descending score order, *n_keep their count.
+ * (faster_rcnn_r50_fpn.py:101-109) -- convention 0: boxes [n][4] x1y1x2y2 float32, scores [n]
+ * float32; suppress IoU > thr, area = w*h.
  * convention 1 = in-tree deep_sort preprocessing.non_max_suppression
- * (wrappers/deep_sort_yolov4/deep_sort/preprocessing.py:5-70: tlwh boxes, +1 areas,
- * overlap = inter / area_other).
+ * (wrappers/deep_sort_yolov4/deep_sort/preprocessing.py:5-70): boxes [n][4] (x, y, w, h) FLOAT64,
+ * scores [n] FLOAT64, +1 areas, overlap = inter / area_other.
+ * keep[n] receives the surviving indices in descending score order, *n_keep their count; n <= 8192.
  */
-int pp_nms(pp_ctx* ctx, const float* boxes, const float* scores, int n, float iou_thr,
-           int convention, int32_t* keep, int32_t* n_keep, int mem);
+int pp_nms(pp_ctx* ctx, const void* boxes, const void* scores, int n, double iou_thr, int convention,
+           int32_t* keep, int32_t* n_keep, int mem);
 
 /* ---- tracker (host) ---------------------------------------------------------------------------
  * Replaces the association stage of wrappers/mmtrack.py:45 (mmtrack SortTracker) with the one
@@ -207,16 +208,28 @@ int pp_nms(pp_ctx* ctx, const float* boxes, const float* scores, int n, float io
  * mode 0 = in-tree DeepSORT semantics without appearance features (IoU-only association);
  * mode 1 = mmtrack-style SORT (ids from 0, tentative handling as SURVEY.md A6; unpinned).
  */
-int pp_tracker_create(int mode, double max_iou_distance, int max_age, int n_init, pp_tracker** out);
+/* mode 0: (feat_dim >= 1, max_iou_distance .7, max_cosine_distance .3, max_age 30, n_init 3) are the
+ * defaults of tracker.py:40 / parser.py:35-47.  mode 1: max_iou_distance carries match_iou_thr (.5)
+ * and max_cosine_distance carries obj_score_thr (.5); feat_dim, max_age, n_init are ignored. */
+int pp_tracker_create(int mode, int feat_dim, double max_iou_distance, double max_cosine_distance,
+                      int max_age, int n_init, pp_tracker** out);
 void pp_tracker_destroy(pp_tracker* t);
-/* dets_tlwh: [n_det][4] float64, conf: [n_det].  Outputs (capacity cap): confirmed, just-updated
- * tracks as the reference's parser emits them: ids, tlwh (Kalman mean), and the matched
- * detection index.  Returns the number of tracks written through *n_out. */
-int pp_tracker_step(pp_tracker* t, const double* dets_tlwh, const double* conf, int n_det,
-                    int cap, int64_t* track_id, double* tlwh, int32_t* det_idx, int32_t* n_out);
+/* One frame.  dets_tlwh: [n_det][4] float64 (x, y, w, h), conf: [n_det], feats: [n_det][feat_dim]
+ * (mode 0 only, may be NULL in mode 1).  Outputs (capacity cap):
+ *   mode 0: every live track after the update, as parser.py:76-86 emits them: track_id, tlwh (from the
+ *           Kalman mean), info[4] = (state, hits, age, time_since_update);
+ *   mode 1: every kept detection (score > thr) with its id: tlwh = the detection, info[1] = its index. */
+int pp_tracker_step(pp_tracker* t, const double* dets_tlwh, const double* conf, const double* feats,
+                    int n_det, int cap, int64_t* track_id, double* tlwh, int32_t* info, int32_t* n_out);
 /* debugging / parity: dump all live tracks (id, state, hits, age, time_since_update, mean[8], cov[64]) */
 int pp_tracker_dump(pp_tracker* t, int cap, int64_t* ids, int32_t* state4, double* mean8,
                     double* cov64, int32_t* n_out);
+/* kalman_filter.py:31-217 entry points on their own (float64; mean[8], cov[8][8], z = (x, y, a, h)) */
+int pp_kalman_initiate(const double* z4, double* mean8, double* cov64);
+int pp_kalman_predict(double* mean8, double* cov64);
+int pp_kalman_update(double* mean8, double* cov64, const double* z4);
+int pp_kalman_gating_distance(const double* mean8, const double* cov64, const double* z4, int n,
+                              double* out);
 /* scipy.optimize.linear_sum_assignment restated (rectangular, float64); row4col/col4row sized
  * by n_rows / n_cols; returns assignment pairs sorted by row like scipy. */
 int pp_linear_sum_assignment(const double* cost, int n_rows, int n_cols, int32_t* rows,
@@ -226,11 +239,13 @@ int pp_linear_sum_assignment(const double* cost, int n_rows, int n_cols, int32_t
  * Replaces VideoPose3D TemporalModelOptimized1f + ChunkedGenerator windows reached from
  * wrappers/videopose3d.py:66-85, computed in the equivalent whole-clip dilated form.
  * net: a program built for the dilated form (posepipeline_amd.models.videopose3d).
- * kpts2d_norm: [n_frames][17][2] fp32 already screen-normalised (videopose3d.py:26-37);
- * out: [n_frames][17][3] fp32.  Edge replication by 121 frames is done on the device.
+ * in_buf is [1][T + 2*pad][>= in_features], out_buf [1][T][out_features]: the clip is processed in
+ * chunks of T frames with a pad-frame halo, clamped to the clip (= np.pad mode 'edge').
+ * kpts2d_norm: host [n_frames][in_features = 17*2] fp32 already screen-normalised
+ * (videopose3d.py:26-37); out: host [n_frames][out_features = 17*3] fp32.
  */
-int pp_videopose3d_lift(pp_net* net, const float* kpts2d_norm, int n_frames, int n_joints_in,
-                        int n_joints_out, int pad, float* out, int mem);
+int pp_videopose3d_lift(pp_net* net, int in_buf, int out_buf, const float* kpts2d_norm, int n_frames,
+                        int in_features, int out_features, int pad, float* out);
 
 #ifdef __cplusplus
 }

@@ -17,9 +17,33 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []), stdout=subprocess.DEVNULL)
 
 
+def usable_cores() -> int:
+    """min(scheduler affinity, cgroup CPU quota): what a process here can actually run in parallel."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 64))
+
+
+N_THREADS = None
+
+
 def lib():
-    global _lib
+    global _lib, N_THREADS
     if _lib is None:
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         build()
         try:
             _lib = C.CDLL(_SO)
@@ -31,6 +55,9 @@ def lib():
         _lib.oracle_conv2d_nhwc.restype = None
         _lib.oracle_maxpool2d_nhwc.argtypes = [fp] + [C.c_int] * 9 + [fp]
         _lib.oracle_maxpool2d_nhwc.restype = None
+        N_THREADS = usable_cores()
+        _lib.oracle_set_threads.argtypes = [C.c_int]
+        _lib.oracle_set_threads(N_THREADS)
     return _lib
 
 

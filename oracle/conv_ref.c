@@ -23,6 +23,20 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* number of OpenMP threads the oracle may use (callers pass the usable core count: a container's CPU
+ * quota can be far below the number of logical CPUs it sees) */
+void oracle_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 static int out_dim(int in, int k, int stride, int pad, int dil) {
     return (in + 2 * pad - dil * (k - 1) - 1) / stride + 1;
 }

@@ -86,6 +86,17 @@ SIGNATURES = {
     "pp_topdown_run": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "pp_topdown_run_precropped": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i]),
     "pp_topdown_timing": (_i, [_vp, _vp]),
+    "pp_nms": (_i, [_vp, _vp, _vp, _i, C.c_double, _i, _vp, C.POINTER(C.c_int32), _i]),
+    "pp_videopose3d_lift": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "pp_tracker_create": (_i, [_i, _i, C.c_double, C.c_double, _i, _i, C.POINTER(_vp)]),
+    "pp_tracker_destroy": (None, [_vp]),
+    "pp_tracker_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
+    "pp_tracker_dump": (_i, [_vp, _i, _vp, _vp, _vp, _vp, C.POINTER(C.c_int32)]),
+    "pp_kalman_initiate": (_i, [_vp, _vp, _vp]),
+    "pp_kalman_predict": (_i, [_vp, _vp]),
+    "pp_kalman_update": (_i, [_vp, _vp, _vp]),
+    "pp_kalman_gating_distance": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "pp_linear_sum_assignment": (_i, [_vp, _i, _i, _vp, _vp, C.POINTER(C.c_int32)]),
     "pp_flip_merge_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i]),
 }
 

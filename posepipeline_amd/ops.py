@@ -62,6 +62,19 @@ def flip_merge_decode(ctx: L.Context, hm: np.ndarray, hm_flip, center_scale, fli
     return kp, merged
 
 
+def nms(ctx: L.Context, boxes, scores, thr, convention=0):
+    """convention 0: float32 x1y1x2y2 (mmcv); 1: float64 tlwh (deep_sort).  Returns kept indices (int64)."""
+    dt = np.float32 if convention == 0 else np.float64
+    boxes = np.ascontiguousarray(boxes, dt).reshape(-1, 4)
+    scores = np.ascontiguousarray(scores, dt).reshape(-1)
+    n = boxes.shape[0]
+    keep = np.zeros(max(n, 1), np.int32)
+    k = C.c_int32()
+    L.check(ctx.lib.pp_nms(ctx.handle, L.ptr(boxes), L.ptr(scores), n, float(thr), convention, L.ptr(keep), C.byref(k),
+                           L.PP_MEM_HOST), "pp_nms")
+    return keep[: k.value].astype(np.int64)
+
+
 class TopDown:
     """pp_topdown handle: crop/normalise -> backbone -> flip-merge + decode, parameters resident."""
 

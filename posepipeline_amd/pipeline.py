@@ -1,0 +1,325 @@
+"""Hot-path tables of PosePipe with the reference's names, `definition` strings and `make()` dispatch.
+
+Mirrors pose_pipeline/pipeline.py for exactly the tables the detect/track -> 2D -> 3D cascade touches
+(file:line of each table next to its class).  The other 38 tables of the reference
+are sibling method branches / rendering and are out of scope.  Backed by posepipeline_amd.djshim unless
+POSEPIPE_USE_DATAJOINT=1 selects the real DataJoint package (then `definition` strings create the same
+MySQL schema as the reference).
+
+Videos: the reference stores an `attach@localattach` and re-decodes it with OpenCV in every stage
+(`Video.get_robust_reader`, pipeline.py:47-87).  Here `video` holds a path; posepipeline_amd.video
+reads it (OpenCV when importable, otherwise the raw `.npy`/`.ppvid` containers used by tests and bench).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+if os.environ.get("POSEPIPE_USE_DATAJOINT") == "1":  # pragma: no cover - needs MySQL
+    import datajoint as dj
+else:
+    from . import djshim as dj
+
+from . import video as _video
+
+if "custom" not in dj.config:
+    dj.config["custom"] = {}
+db_prefix = dj.config["custom"].get("database.prefix", "")
+schema = dj.schema(db_prefix + "pose_pipeline")
+
+
+@schema
+class Video(dj.Manual):  # pipeline.py:25-33
+    definition = """
+    # Table containing raw videos, grouped by project and filename, with their start time
+    video_project       : varchar(50)
+    filename            : varchar(100)
+    ---
+    video               : attach@localattach    # datajoint managed video file
+    start_time          : timestamp(3)          # time of beginning of video, as accurately as known
+    import_time  = CURRENT_TIMESTAMP : timestamp
+    """
+
+    @staticmethod
+    def get_robust_reader(key, return_cap=True):
+        """pipeline.py:47-87: hand back the video path (or an opened reader).  The reference validates
+        by decoding every frame once and transcodes with ffmpeg on failure; the frame sources here are
+        validated when opened."""
+        path = (Video & key).fetch1("video")
+        if return_cap:
+            return _video.open_video(path)
+        return path
+
+
+@schema
+class VideoInfo(dj.Computed):  # pipeline.py:92-102
+    definition = """
+    # Video info including timestamps, delta times, num frames, height and width
+    -> Video
+    ---
+    timestamps      : longblob
+    delta_time      : longblob
+    fps             : float
+    height          : int
+    width           : int
+    num_frames      : int
+    """
+
+    def make(self, key, override=False):
+        from datetime import timedelta
+        key = key.copy()
+        path, start_time = (Video & key).fetch1("video", "start_time")
+        src = _video.open_video(path)
+        fps = float(src.fps)
+        if fps < 1:
+            raise Exception("FPS is less than 1")
+        key["fps"] = fps
+        key["num_frames"] = frames = int(src.num_frames)
+        key["width"], key["height"] = int(src.width), int(src.height)
+        key["timestamps"] = [start_time + timedelta(0, i / fps) for i in range(frames)]
+        key["delta_time"] = [timedelta(0, i / fps).total_seconds() for i in range(frames)]
+        src.release()
+        self.insert1(key)
+
+
+@schema
+class TrackingBboxMethodLookup(dj.Lookup):  # pipeline.py:480-494
+    definition = """
+    tracking_method      : int
+    ---
+    tracking_method_name : varchar(50)
+    """
+    contents = [
+        {"tracking_method": 0, "tracking_method_name": "DeepSortYOLOv4"},
+        {"tracking_method": 1, "tracking_method_name": "MMTrack_tracktor"},
+        {"tracking_method": 2, "tracking_method_name": "FairMOT"},
+        {"tracking_method": 3, "tracking_method_name": "TransTrack"},
+        {"tracking_method": 4, "tracking_method_name": "TraDeS"},
+        {"tracking_method": 5, "tracking_method_name": "MMTrack_deepsort"},
+        {"tracking_method": 6, "tracking_method_name": "MMTrack_bytetrack"},
+        {"tracking_method": 7, "tracking_method_name": "MMTrack_qdtrack"},
+    ]
+
+
+@schema
+class TrackingBboxMethod(dj.Manual):  # pipeline.py:499-503
+    definition = """
+    -> Video
+    tracking_method   : int
+    ---
+    """
+
+
+@schema
+class TrackingBbox(dj.Computed):  # pipeline.py:508-513
+    definition = """
+    -> TrackingBboxMethod
+    ---
+    tracks            : longblob
+    num_tracks        : int
+    """
+
+    def make(self, key):  # pipeline.py:515-578
+        video = Video.get_robust_reader(key, return_cap=False)
+        name = (TrackingBboxMethodLookup & key).fetch1("tracking_method_name")
+        if name in "MMTrack_tracktor":     # sic: substring test, pipeline.py:525
+            from .wrappers.mmtrack import mmtrack_bounding_boxes
+            tracks = mmtrack_bounding_boxes(video, "tracktor")
+        elif name == "MMTrack_deepsort":
+            from .wrappers.mmtrack import mmtrack_bounding_boxes
+            tracks = mmtrack_bounding_boxes(video, "deepsort")
+        elif name == "MMTrack_bytetrack":
+            from .wrappers.mmtrack import mmtrack_bounding_boxes
+            tracks = mmtrack_bounding_boxes(video, "bytetrack")
+        elif name == "MMTrack_qdtrack":
+            from .wrappers.mmtrack import mmtrack_bounding_boxes
+            tracks = mmtrack_bounding_boxes(video, "qdtrack")
+        else:
+            raise Exception(f"Unsupported tracking method: {key['tracking_method']}")
+        key["tracks"] = tracks
+        track_ids = np.unique([t["track_id"] for track in tracks for t in track])
+        key["num_tracks"] = len(track_ids)
+        self.insert1(key)
+
+
+@schema
+class PersonBboxValid(dj.Manual):  # pipeline.py:639-644
+    definition = """
+    -> TrackingBbox
+    video_subject_id        : int
+    ---
+    keep_tracks             : longblob
+    """
+
+
+@schema
+class PersonBbox(dj.Computed):  # pipeline.py:649-654
+    definition = """
+    -> PersonBboxValid
+    ---
+    bbox               : longblob
+    present            : longblob
+    """
+
+    def make(self, key):  # pipeline.py:656-687
+        from .tracking import person_bbox
+        tracks = (TrackingBbox & key).fetch1("tracks")
+        keep_tracks = (PersonBboxValid & key).fetch1("keep_tracks")
+        key["bbox"], key["present"] = person_bbox(tracks, keep_tracks)
+        self.insert1(key)
+
+    @property
+    def key_source(self):  # pipeline.py:705-707
+        return PersonBboxValid & "video_subject_id >= 0"
+
+
+@schema
+class DetectedFrames(dj.Computed):  # pipeline.py:712-722
+    definition = """
+    -> PersonBboxValid
+    -> VideoInfo
+    ---
+    frames_detected        : int
+    frames_missed          : int
+    fraction_found         : float
+    mean_other_people      : float
+    median_confidence      : float
+    frame_data             : longblob
+    """
+
+    def make(self, key):  # pipeline.py:724-762
+        tracks = (TrackingBbox & key).fetch1("tracks")
+        keep_tracks = (PersonBboxValid & key).fetch1("keep_tracks")
+        stats = []
+        for fr in tracks:
+            valid = [t for t in fr if t["track_id"] in keep_tracks]
+            if len(valid) == 1:
+                stats.append({"present": True, "confidence": valid[0].get("confidence", 1.0), "others": len(fr) - 1})
+            else:
+                stats.append({"present": False, "confidence": 0, "others": len(fr)})
+        present = np.array([s["present"] for s in stats])
+        key["frames_detected"] = np.sum(present)
+        key["frames_missed"] = np.sum(~present)
+        key["fraction_found"] = key["frames_detected"] / (key["frames_missed"] + key["frames_detected"])
+        key["median_confidence"] = (np.median([s["confidence"] for s in stats if s["present"]])
+                                    if key["frames_detected"] > 0 else 0.0)
+        key["mean_other_people"] = np.nanmean([s["others"] for s in stats])
+        key["frame_data"] = stats
+        self.insert1(key)
+
+    @property
+    def key_source(self):
+        return PersonBboxValid & "video_subject_id >= 0"
+
+
+@schema
+class TopDownMethodLookup(dj.Lookup):  # pipeline.py:979-998
+    definition = """
+    top_down_method      : int
+    ---
+    top_down_method_name : varchar(50)
+    """
+    contents = [
+        {"top_down_method": 0, "top_down_method_name": "MMPose"},
+        {"top_down_method": 1, "top_down_method_name": "MMPoseWholebody"},
+        {"top_down_method": 2, "top_down_method_name": "MMPoseHalpe"},
+        {"top_down_method": 3, "top_down_method_name": "MMPoseHrformerCoco"},
+        {"top_down_method": 4, "top_down_method_name": "OpenPose"},
+        {"top_down_method": 6, "top_down_method_name": "OpenPose_BODY25B"},
+        {"top_down_method": 7, "top_down_method_name": "MMPoseTCFormerWholebody"},
+        {"top_down_method": 8, "top_down_method_name": "OpenPose_HR"},
+        {"top_down_method": 9, "top_down_method_name": "OpenPose_LR"},
+        {"top_down_method": 11, "top_down_method_name": "Bridging_COCO_25"},
+        {"top_down_method": 12, "top_down_method_name": "Bridging_bml_movi_87"},
+        {"top_down_method": 13, "top_down_method_name": "Bridging_smpl+head_30"},
+        {"top_down_method": 14, "top_down_method_name": "Bridging_smplx_42"},
+    ]
+
+
+@schema
+class TopDownMethod(dj.Manual):  # pipeline.py:1003-1006
+    definition = """
+    -> PersonBbox
+    top_down_method    : int
+    """
+
+
+@schema
+class TopDownPerson(dj.Computed):  # pipeline.py:1011-1015
+    definition = """
+    -> TopDownMethod
+    ---
+    keypoints          : longblob
+    """
+
+    def make(self, key):  # pipeline.py:1017-1095
+        method_name = (TopDownMethodLookup & key).fetch1("top_down_method_name")
+        from .wrappers.mmpose import mmpose_top_down_person
+        if method_name == "MMPose":
+            key["keypoints"] = mmpose_top_down_person(key, "HRNet_W48_COCO")
+        elif method_name == "MMPoseWholebody":
+            key["keypoints"] = mmpose_top_down_person(key, "HRNet_W48_COCOWholeBody")
+        elif method_name == "MMPoseHalpe":
+            key["keypoints"] = mmpose_top_down_person(key, "HRNet_W48_HALPE")
+        else:
+            raise Exception("Method not implemented")
+        self.insert1(key)
+
+    @staticmethod
+    def joint_names(method="MMPose"):
+        from .wrappers.mmpose import mmpose_joint_dictionary
+        return mmpose_joint_dictionary[method]
+
+
+@schema
+class LiftingMethodLookup(dj.Lookup):  # pipeline.py:1226-1239
+    definition = """
+    lifting_method      : int
+    ---
+    lifting_method_name : varchar(50)
+    """
+    contents = [
+        {"lifting_method": 0, "lifting_method_name": "GastNet"},
+        {"lifting_method": 1, "lifting_method_name": "VideoPose3D"},
+        {"lifting_method": 2, "lifting_method_name": "PoseAug"},
+        {"lifting_method": 11, "lifting_method_name": "Bridging_COCO_25"},
+        {"lifting_method": 12, "lifting_method_name": "Bridging_bml_movi_87"},
+        {"lifting_method": 13, "lifting_method_name": "Bridging_smpl+head_30"},
+        {"lifting_method": 14, "lifting_method_name": "Bridging_smplx_42"},
+    ]
+
+
+@schema
+class LiftingMethod(dj.Manual):  # pipeline.py:1244-1247
+    definition = """
+    -> TopDownPerson
+    -> LiftingMethodLookup
+    """
+
+
+@schema
+class LiftingPerson(dj.Computed):  # pipeline.py:1252-1257
+    definition = """
+    -> LiftingMethod
+    ---
+    keypoints_3d       : longblob
+    keypoints_valid    : longblob
+    """
+
+    def make(self, key):  # pipeline.py:1259-1416
+        name = (LiftingMethodLookup & key).fetch1("lifting_method_name")
+        if name == "VideoPose3D":
+            from .wrappers.videopose3d import process_videopose3d
+            results = process_videopose3d(key)
+        else:
+            raise Exception(f"Method not implemented {key}")
+        key.update(results)
+        self.insert1(key)
+
+    @staticmethod
+    def joint_names():
+        """Lifting layers use Human3.6 ordering (pipeline.py:1418-1438)"""
+        return ["Hip (root)", "Right hip", "Right knee", "Right foot", "Left hip", "Left knee", "Left foot", "Spine",
+                "Thorax", "Nose", "Head", "Left shoulder", "Left elbow", "Left wrist", "Right shoulder", "Right elbow",
+                "Right wrist"]

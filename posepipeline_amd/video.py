@@ -1,0 +1,112 @@
+"""Frame sources for the wrappers.
+
+The reference opens every video with `cv2.VideoCapture` (wrappers/mmtrack.py:32, wrappers/mmpose.py:55)
+and reads BGR frames one at a time.  OpenCV is used here when it is importable; the raw containers
+below exist because neither OpenCV nor ffmpeg is installed in the build / GPU images:
+  *.npy    numpy array [N][H][W][3] uint8, BGR (what cv2 would have decoded)
+  *.ppvid  32-byte header (magic 'PPVID001', N, H, W, fps*1000 as little-endian int32) + raw BGR frames
+Every source yields frames in BGR order, like `cap.read()`.
+"""
+from __future__ import annotations
+
+import os
+import struct
+
+import numpy as np
+
+MAGIC = b"PPVID001"
+
+
+class ArrayVideo:
+    def __init__(self, frames: np.ndarray, fps: float = 30.0):
+        assert frames.ndim == 4 and frames.shape[3] == 3 and frames.dtype == np.uint8
+        self.frames = frames
+        self.fps = float(fps)
+        self.pos = 0
+
+    @property
+    def num_frames(self):
+        return int(self.frames.shape[0])
+
+    @property
+    def height(self):
+        return int(self.frames.shape[1])
+
+    @property
+    def width(self):
+        return int(self.frames.shape[2])
+
+    def read(self):
+        if self.pos >= self.num_frames:
+            return False, None
+        f = self.frames[self.pos]
+        self.pos += 1
+        return True, f
+
+    def read_batch(self, n):
+        """up to n consecutive frames as one [k][H][W][3] array (a view for in-memory sources)"""
+        a = self.frames[self.pos: self.pos + n]
+        self.pos += a.shape[0]
+        return a
+
+    def release(self):
+        self.frames = None
+
+
+class _Cv2Video:  # pragma: no cover - OpenCV is not installed in the build image
+    def __init__(self, path):
+        import cv2
+        self.cv2 = cv2
+        self.cap = cv2.VideoCapture(path)
+        self.fps = self.cap.get(cv2.CAP_PROP_FPS)
+        self.num_frames = int(self.cap.get(cv2.CAP_PROP_FRAME_COUNT))
+        self.width = int(self.cap.get(cv2.CAP_PROP_FRAME_WIDTH))
+        self.height = int(self.cap.get(cv2.CAP_PROP_FRAME_HEIGHT))
+
+    def read(self):
+        return self.cap.read()
+
+    def read_batch(self, n):
+        out = []
+        for _ in range(n):
+            ret, f = self.cap.read()
+            if not ret or f is None:
+                break
+            out.append(f)
+        if not out:
+            return np.zeros((0, self.height, self.width, 3), np.uint8)
+        return np.stack(out)
+
+    def release(self):
+        self.cap.release()
+
+
+def write_ppvid(path, frames: np.ndarray, fps: float = 30.0):
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, h, w, c = frames.shape
+    assert c == 3
+    with open(path, "wb") as f:
+        f.write(MAGIC + struct.pack("<iiii", n, h, w, int(round(fps * 1000))) + b"\0" * 8)
+        f.write(frames.tobytes())
+
+
+def open_video(path):
+    """-> object with fps / num_frames / height / width / read() / read_batch(n) / release()."""
+    if isinstance(path, np.ndarray):
+        return ArrayVideo(path)
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".npy":
+        return ArrayVideo(np.load(path, mmap_mode="r"))
+    if ext == ".ppvid":
+        with open(path, "rb") as f:
+            head = f.read(32)
+        if head[:8] != MAGIC:
+            raise ValueError(f"{path}: not a PPVID001 file")
+        n, h, w, fps1000 = struct.unpack("<iiii", head[8:24])
+        frames = np.memmap(path, dtype=np.uint8, mode="r", offset=32, shape=(n, h, w, 3))
+        return ArrayVideo(frames, fps1000 / 1000.0)
+    try:
+        import cv2  # noqa: F401
+    except ImportError as e:
+        raise RuntimeError(f"cannot decode {path}: OpenCV is not installed and the file is not .npy/.ppvid") from e
+    return _Cv2Video(path)  # pragma: no cover

@@ -1,0 +1,143 @@
+"""Pin the network oracle (C fmaf-chain convs + numpy glue) against an independent torch-CPU statement of
+the same architectures: nn.functional.conv2d / conv1d + UNFOLDED eval-mode batch_norm, torch's own
+summation order.  Agreement is to float32 round-off, not bit-exact (different order, BN not folded)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import clib
+from oracle import nets as onets
+from posepipeline_amd.models import hrnet, synth
+from posepipeline_amd.models import videopose3d as vp3d
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize("cfg", [(3, 8, 3, 1, 1, 1), (16, 24, 3, 2, 1, 1), (8, 12, 1, 1, 0, 1), (4, 6, 7, 2, 3, 1),
+                                 (12, 20, 3, 1, 2, 2)])
+def test_conv_oracle_vs_torch(cfg):
+    cin, cout, k, s, p, d = cfg
+    rng = np.random.default_rng(cin * 100 + cout)
+    x = rng.standard_normal((2, cin, 19, 23)).astype(np.float32)
+    w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = F.conv2d(T(x), T(w), T(b), stride=s, padding=p, dilation=d).numpy()
+    got = clib.conv2d_nhwc(np.transpose(x, (0, 2, 3, 1)), w, b, stride=s, pad=p, dil=d)
+    np.testing.assert_allclose(np.transpose(got, (0, 3, 1, 2)), ref, rtol=1e-4, atol=2e-5)
+
+
+def test_maxpool_oracle_vs_torch():
+    x = np.random.default_rng(0).standard_normal((2, 8, 17, 21)).astype(np.float32)
+    ref = F.max_pool2d(T(x), 3, 2, 1).numpy()
+    got = clib.maxpool2d_nhwc(np.transpose(x, (0, 2, 3, 1)), 3, 2, 1)
+    assert np.array_equal(np.transpose(got, (0, 3, 1, 2)), ref)
+
+
+class TorchHRNet:
+    """mmpose HRNet wiring written against torch ops only (independent of oracle/nets.py's helpers)."""
+
+    def __init__(self, sd, width):
+        self.sd = {k: T(v) for k, v in sd.items()}
+        self.ch = [width * 2 ** i for i in range(4)]
+
+    def cb(self, x, conv, bn, stride=1, pad=1):
+        sd = self.sd
+        y = F.conv2d(x, sd[conv + ".weight"], None, stride, pad)
+        return F.batch_norm(y, sd[bn + ".running_mean"], sd[bn + ".running_var"], sd[bn + ".weight"], sd[bn + ".bias"],
+                            False, 0.1, 1e-5)
+
+    def forward(self, x):
+        B = "backbone."
+        x = F.relu(self.cb(x, B + "conv1", B + "bn1", 2))
+        x = F.relu(self.cb(x, B + "conv2", B + "bn2", 2))
+        for i in range(4):
+            p = f"{B}layer1.{i}."
+            idn = self.cb(x, p + "downsample.0", p + "downsample.1", 1, 0) if i == 0 else x
+            y = F.relu(self.cb(x, p + "conv1", p + "bn1", 1, 0))
+            y = F.relu(self.cb(y, p + "conv2", p + "bn2", 1, 1))
+            x = F.relu(self.cb(y, p + "conv3", p + "bn3", 1, 0) + idn)
+        ys, pre = [x], [256]
+        for si, (n_mod, n_br) in enumerate(((1, 2), (4, 3), (3, 4))):
+            cur = self.ch[:n_br]
+            t = f"{B}transition{si + 1}."
+            xs = []
+            for i in range(n_br):
+                if i < len(pre):
+                    xs.append(F.relu(self.cb(ys[i], f"{t}{i}.0", f"{t}{i}.1")) if pre[i] != cur[i] else ys[i])
+                else:
+                    y = ys[-1]
+                    for j in range(i + 1 - len(pre)):
+                        y = F.relu(self.cb(y, f"{t}{i}.{j}.0", f"{t}{i}.{j}.1", 2))
+                    xs.append(y)
+            for m in range(n_mod):
+                mp = f"{B}stage{si + 2}.{m}."
+                for b in range(n_br):
+                    for k in range(4):
+                        p = f"{mp}branches.{b}.{k}."
+                        y = F.relu(self.cb(xs[b], p + "conv1", p + "bn1"))
+                        xs[b] = F.relu(self.cb(y, p + "conv2", p + "bn2") + xs[b])
+                n_out = 1 if (si == 2 and m == n_mod - 1) else n_br
+                outs = []
+                for i in range(n_out):
+                    y = 0
+                    for j in range(n_br):
+                        f = f"{mp}fuse_layers.{i}.{j}."
+                        if i == j:
+                            y = y + xs[j]
+                        elif j > i:
+                            y = y + F.interpolate(self.cb(xs[j], f + "0", f + "1", 1, 0), scale_factor=2 ** (j - i), mode="nearest")
+                        else:
+                            z = xs[j]
+                            for k in range(i - j):
+                                z = self.cb(z, f"{f}{k}.0", f"{f}{k}.1", 2)
+                                if k != i - j - 1:
+                                    z = F.relu(z)
+                            y = y + z
+                    outs.append(F.relu(y))
+                xs = outs
+            ys, pre = xs, cur
+        return F.conv2d(ys[0], self.sd["keypoint_head.final_layer.weight"], self.sd["keypoint_head.final_layer.bias"])
+
+
+def test_hrnet_oracle_vs_torch():
+    spec = hrnet.HRNetSpec(32, 17, 64, 64)
+    sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(spec), seed=4)
+    x = np.random.default_rng(1).standard_normal((2, 3, 64, 64)).astype(np.float32)
+    with torch.no_grad():
+        ref = TorchHRNet(sd, 32).forward(T(x)).numpy()
+    got = onets.HRNetRef(sd, 32).forward(x)
+    scale = np.abs(ref).max()
+    assert scale > 1e-3
+    assert np.abs(got - ref).max() <= 2e-4 * scale, np.abs(got - ref).max() / scale
+
+
+def test_videopose3d_oracle_vs_torch_and_window_semantics():
+    spec = vp3d.VideoPose3DSpec(channels=64)           # same topology, narrow, so the test takes seconds
+    sd = synth.synth_state_dict(vp3d.videopose3d_param_shapes(spec), seed=5)
+    rng = np.random.default_rng(6)
+    kp = rng.uniform(-1, 1, (9, 17, 2)).astype(np.float32)
+    win = onets.videopose3d_windows(kp, spec.pad)
+    assert win.shape == (9, 243, 17, 2)
+    # ChunkedGenerator pads with np.pad(..., 'edge')
+    padded = np.pad(kp, ((121, 121), (0, 0), (0, 0)), "edge")
+    assert np.array_equal(win[4], padded[4:4 + 243])
+    got = onets.VideoPose3DRef(sd).forward(win)
+    # torch: TemporalModelOptimized1f forward (strided convs), unfolded BN
+    t = {k: T(v) for k, v in sd.items()}
+
+    def bn(x, name):
+        return F.batch_norm(x, t[name + ".running_mean"], t[name + ".running_var"], t[name + ".weight"], t[name + ".bias"],
+                            False, 0.1, 1e-5)
+
+    with torch.no_grad():
+        x = T(win).reshape(9, 243, 34).permute(0, 2, 1)
+        x = F.relu(bn(F.conv1d(x, t["expand_conv.weight"], stride=3), "expand_bn"))
+        for i in range(4):
+            res = x[:, :, 1::3]
+            x = F.relu(bn(F.conv1d(x, t[f"layers_conv.{2 * i}.weight"], stride=3), f"layers_bn.{2 * i}"))
+            x = res + F.relu(bn(F.conv1d(x, t[f"layers_conv.{2 * i + 1}.weight"]), f"layers_bn.{2 * i + 1}"))
+        ref = F.conv1d(x, t["shrink.weight"], t["shrink.bias"]).permute(0, 2, 1).reshape(9, 17, 3).numpy()
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
