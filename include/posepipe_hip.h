@@ -235,6 +235,32 @@ int pp_kalman_gating_distance(const double* mean8, const double* cov64, const do
 int pp_linear_sum_assignment(const double* cost, int n_rows, int n_cols, int32_t* rows,
                              int32_t* cols, int32_t* n_pairs);
 
+/* ---- detector ------------------------------------------------------------------------------------
+ * Faster-RCNN R50-FPN person detector = the detection half of `mmtrack.apis.inference_mot`
+ * (wrappers/mmtrack.py:45), batched over frames.  net_a: image program (input [Hp][Wp][4]; outputs:
+ * 5 RPN objectness maps [H][W][3], 5 RPN delta maps [H][W][12], FPN P2..P5 [H][W][256]); net_b: RoI-head
+ * program (input [7][7][256] per RoI; outputs cls [1][1][2], reg [1][1][4]; max_batch >= 1000 per frame).
+ * bufs_a = {input, cls0..4, reg0..4, p2..p5} (15 ids), bufs_b = {roi_in, cls, reg}.
+ * lut: [3][256] fp32 = (v - mean[c]) * (1/std[c]) (mmcv imnormalize); channel c of the decoded BGR frame
+ * feeds tensor channel c (the reference's double BGR<->RGB swap, wrappers/mmtrack.py:43 + to_rgb=True).
+ * base_anchors: [5][3][4] fp32 (AnchorGenerator scales [8], ratios [.5,1,2], strides 4..64).
+ * Test-time constants are those of faster_rcnn_r50_fpn.py:101-109.
+ */
+typedef struct pp_detector pp_detector;
+/* mmcv rescale_size for img_scale (1088,1088) + Pad(size_divisor=32): resized and padded input dims */
+int pp_detector_input_size(int src_h, int src_w, int32_t* nh, int32_t* nw, int32_t* hp, int32_t* wp);
+int pp_detector_create(pp_net* net_a, pp_net* net_b, const int32_t* bufs_a, const int32_t* bufs_b, int src_h,
+                       int src_w, const float* lut, const float* base_anchors, pp_detector** out);
+void pp_detector_destroy(pp_detector* d);
+/* frames: [n_frames][src_h][src_w][3] u8 BGR (host or device per frames_mem; NULL = the program input
+ * buffer was filled by the caller).  dets: host [n_frames][100][5] = (x1, y1, x2, y2, score) in source
+ * pixels, n_dets: host [n_frames].  proposals / n_proposals (optional, host): [n_frames][1000][4], [n_frames]. */
+int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int frames_mem, float* dets,
+                    int32_t* n_dets, float* proposals, int32_t* n_proposals);
+/* HIP-event stage times of the last run, ms6 = {preprocess, image program, RPN proposals + NMS, RoIAlign,
+ * RoI-head program, final decode + NMS} */
+int pp_detector_timing(pp_detector* d, float* ms6);
+
 /* ---- 3D lifting -----------------------------------------------------------------------------
  * Replaces VideoPose3D TemporalModelOptimized1f + ChunkedGenerator windows reached from
  * wrappers/videopose3d.py:66-85, computed in the equivalent whole-clip dilated form.

@@ -43,22 +43,22 @@ def nms_mmcv(boxes_xyxy, scores, iou_thr):
     b = np.asarray(boxes_xyxy, np.float32).reshape(-1, 4)
     s = np.asarray(scores, np.float32).reshape(-1)
     order = np.argsort(-s, kind="stable")
+    b = b[order]
     area = ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])).astype(np.float32)
+    thr = np.float32(iou_thr)
+    zero = np.float32(0)
     suppressed = np.zeros(len(b), bool)
     keep = []
-    for oi, i in enumerate(order):
+    for i in range(len(b)):
         if suppressed[i]:
             continue
-        keep.append(int(i))
-        for j in order[oi + 1:]:
-            if suppressed[j]:
-                continue
-            w = np.float32(max(np.float32(0), min(b[i, 2], b[j, 2]) - max(b[i, 0], b[j, 0])))
-            h = np.float32(max(np.float32(0), min(b[i, 3], b[j, 3]) - max(b[i, 1], b[j, 1])))
-            inter = np.float32(w * h)
-            iou = inter / np.float32(np.float32(area[i] + area[j]) - inter)
-            if iou > np.float32(iou_thr):
-                suppressed[j] = True
+        keep.append(int(order[i]))
+        r = slice(i + 1, len(b))
+        w = np.maximum(np.minimum(b[i, 2], b[r, 2]) - np.maximum(b[i, 0], b[r, 0]), zero)
+        h = np.maximum(np.minimum(b[i, 3], b[r, 3]) - np.maximum(b[i, 1], b[r, 1]), zero)
+        inter = (w * h).astype(np.float32)
+        # mmcv's devIoU compares without dividing: interS > threshold * (Sa + Sb - interS)
+        suppressed[r] |= inter > (thr * ((area[i] + area[r]).astype(np.float32) - inter).astype(np.float32)).astype(np.float32)
     return keep
 
 

@@ -86,6 +86,11 @@ SIGNATURES = {
     "pp_topdown_run": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "pp_topdown_run_precropped": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i]),
     "pp_topdown_timing": (_i, [_vp, _vp]),
+    "pp_detector_input_size": (_i, [_i, _i] + [C.POINTER(C.c_int32)] * 4),
+    "pp_detector_create": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(_vp)]),
+    "pp_detector_destroy": (None, [_vp]),
+    "pp_detector_run": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "pp_detector_timing": (_i, [_vp, _vp]),
     "pp_nms": (_i, [_vp, _vp, _vp, _i, C.c_double, _i, _vp, C.POINTER(C.c_int32), _i]),
     "pp_videopose3d_lift": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
     "pp_tracker_create": (_i, [_i, _i, C.c_double, C.c_double, _i, _i, C.POINTER(_vp)]),

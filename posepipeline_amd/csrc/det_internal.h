@@ -1,0 +1,47 @@
+// Internal interfaces of the detector post-processing (det_post.hip <-> detector.hip <-> nms.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+struct DetRpnArgs {
+    const float* cls[5];   // RPN objectness logits per level [frame][H][W][3]
+    const float* reg[5];   // RPN deltas per level [frame][H][W][12]
+    int h[5], w[5], stride[5];
+    float base[5][3][4];   // AnchorGenerator base anchors (float32, computed by the host like mmdet)
+    int nms_pre;           // 1000
+    int max_n;             // 5 * nms_pre rounded up: row stride of boxes / scores
+    float* score_scratch;  // [frame][scratch_stride] sigmoid scores
+    int scratch_stride;
+    float* cand_box;       // [frame][5][nms_pre][4]
+    float* cand_score;     // [frame][5][nms_pre]
+    int32_t* cand_cnt;     // [frame][5]
+    float* boxes;          // [frame][max_n][4]
+    float* boxes_nms;      // [frame][max_n][4]  (+ level offsets)
+    float* scores;         // [frame][max_n]
+    int32_t* n_boxes;      // [frame]
+};
+
+struct DetFpnArgs {
+    const float* feat[4];  // P2..P5 [frame][H][W][C]
+    int h[4], w[4], stride[4];
+    int c;
+};
+
+int det_enqueue_preprocess(hipStream_t s, const uint8_t* frames, int n_frames, int H, int W, int nh, int nw, int Hp,
+                           int Wp, const int32_t* xtab, const int32_t* ytab, const float* lut, float* out);
+int det_enqueue_rpn(hipStream_t s, const DetRpnArgs& a, int n_frames);
+int det_enqueue_gather(hipStream_t s, const float* boxes, const float* scores, int max_n, const int32_t* keep,
+                       const int32_t* n_keep, int limit, float* out_box, float* out_score, int32_t* n_out, int out5,
+                       int n_frames);
+int det_enqueue_roi_align(hipStream_t s, const DetFpnArgs& a, const float* rois, const int32_t* n_rois, int max_rois,
+                          float* out, int n_frames);
+int det_enqueue_final_decode(hipStream_t s, const float* rois, const int32_t* n_rois, int max_rois, const float* cls,
+                             const float* reg, float sfx, float sfy, float score_thr, float* boxes, float* scores,
+                             int32_t* n_out, int n_frames);
+
+// nms.hip: batched float32 NMS (mmcv convention).  boxes [frame][max_n][4] (used for the IoU test), scores
+// [frame][max_n], n [frame] on the device.  keep [frame][max_n] receives indices in descending score order.
+// scratch: pp_nms_batched_scratch_bytes(max_n, n_frames).
+size_t pp_nms_batched_scratch_bytes(int max_n, int n_frames);
+int pp_enqueue_nms_batched(hipStream_t s, const float* boxes, const float* scores, const int32_t* n, int max_n,
+                           int n_frames, float thr, void* scratch, int32_t* keep, int32_t* n_keep);

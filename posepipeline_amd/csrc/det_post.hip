@@ -1,0 +1,472 @@
+// Device-side pre/post-processing of the Faster-RCNN detector, batched over frames, no host round trips.
+//
+// Replaces, for the detection stage reached from pose_pipeline/wrappers/mmtrack.py:45
+// (mmtrack `inference_mot` -> mmdet FasterRCNN.simple_test; model spec
+// 3rdparty/mmtracking/_base_/models/faster_rcnn_r50_fpn.py:1-112, test pipeline
+// 3rdparty/mmtracking/_base_/datasets/mot_challenge.py:3-4,33-47):
+//   det_preprocess   mmcv imrescale (cv2.resize INTER_LINEAR, 8-bit fixed point) + imnormalize(to_rgb) + Pad(/32)
+//   rpn_select       per level: sigmoid, top-1000 by score, AnchorGenerator grid anchor + delta2bbox
+//   rpn_compact      concat levels, drop empty boxes, batched_nms coordinate offsets
+//   (nms.hip)        NMS 0.7 -> top 1000 proposals;  NMS 0.5 -> top 100 detections
+//   roi_align        SingleRoIExtractor.map_roi_levels + mmcv RoIAlign(7x7, aligned, adaptive sampling, avg)
+//   final_decode     softmax, delta2bbox(.1,.1,.2,.2), /scale_factor, score > .05
+// Every step follows oracle/detector.py line by line (same float32 operation order; sigmoid / exp /
+// softmax evaluated in double and rounded once; sort ties break towards the lower index), so the
+// integer outputs (selected indices, kept boxes) are bit-exact and the float boxes equal.
+#include "pp_internal.h"
+#include "det_internal.h"
+
+namespace {
+
+// ---- block-wide helpers (1024 threads = 16 waves) ---------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// exclusive prefix of a 0/1 flag over the block, in thread order; *total = sum.  s_w: >= 17 ints of LDS.
+__device__ int block_rank(bool flag, int* s_w, int* total) {
+    const unsigned long long b = __ballot(flag);
+    const int r = __popcll(b & ((1ull << lane_id()) - 1ull));
+    __syncthreads();
+    if (lane_id() == 0) s_w[wave_id()] = __popcll(b);
+    __syncthreads();
+    int base = 0, tot = 0;
+    const int nw = blockDim.x >> 6;
+    for (int w = 0; w < nw; ++w) {
+        const int c = s_w[w];
+        if (w < wave_id()) base += c;
+        tot += c;
+    }
+    *total = tot;
+    return base + r;
+}
+
+__device__ __forceinline__ float sigmoid_f32(float x) { return (float)(1.0 / (1.0 + exp(-(double)x))); }
+__device__ __forceinline__ float exp_f32(float x) { return (float)exp((double)x); }
+
+// DeltaXYWHBBoxCoder.decode, means 0, clip_border False
+__device__ __forceinline__ void delta2bbox(const float roi[4], const float d_in[4], const float stds[4], float out[4]) {
+    const float dx = d_in[0] * stds[0], dy = d_in[1] * stds[1];
+    float dw = d_in[2] * stds[2], dh = d_in[3] * stds[3];
+    const float px = (roi[0] + roi[2]) * 0.5f, py = (roi[1] + roi[3]) * 0.5f;
+    const float pw = roi[2] - roi[0], ph = roi[3] - roi[1];
+    const float max_ratio = (float)4.135166556742356;     // |log(16/1000)|
+    dw = fminf(fmaxf(dw, -max_ratio), max_ratio);
+    dh = fminf(fmaxf(dh, -max_ratio), max_ratio);
+    const float gx = px + pw * dx, gy = py + ph * dy;
+    const float gw = pw * exp_f32(dw), gh = ph * exp_f32(dh);
+    const float hw = gw * 0.5f, hh = gh * 0.5f;
+    out[0] = gx - hw; out[1] = gy - hh; out[2] = gx + hw; out[3] = gy + hh;
+}
+
+// ---- det_preprocess -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __restrict__ frames, int H, int W, int nh,
+                                                             int nw, int Hp, int Wp, const int32_t* __restrict__ xtab,
+                                                             const int32_t* __restrict__ ytab, const float* __restrict__ lut,
+                                                             float* __restrict__ out) {
+    // xtab: [nw][3] = (sx, a0, a1);  ytab: [nh][3] = (sy, b0, b1)   (cv::resize 8-bit linear tables, *2048)
+    __shared__ float s_lut[768];
+    for (int i = threadIdx.x; i < 768; i += blockDim.x) s_lut[i] = lut[i];
+    __syncthreads();
+    const int f = blockIdx.y;
+    const uint8_t* img = frames + (size_t)f * H * W * 3;
+    float* o = out + (size_t)f * Hp * Wp * 4;
+    const int total = Hp * Wp;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
+        const int y = p / Wp, x = p - y * Wp;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (y < nh && x < nw) {
+            const int sx = xtab[3 * x], a0 = xtab[3 * x + 1], a1 = xtab[3 * x + 2];
+            const int sy = ytab[3 * y], b0 = ytab[3 * y + 1], b1 = ytab[3 * y + 2];
+            const int sx1 = min(sx + 1, W - 1), sy1 = min(sy + 1, H - 1);
+            const uint8_t* r0 = img + (size_t)sy * W * 3;
+            const uint8_t* r1 = img + (size_t)sy1 * W * 3;
+            uint8_t c3[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int h0 = r0[sx * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
+                const int h1 = r1[sx * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+                int val = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+                c3[c] = (uint8_t)min(max(val, 0), 255);
+            }
+            // to_rgb swap of the (already swapped by the wrapper) frame: tensor channel c <- frame channel 2-c
+            // of the wrapper's RGB array == channel c of the decoded BGR frame; `frames` here IS the BGR frame.
+            v.x = s_lut[0 * 256 + c3[0]];
+            v.y = s_lut[1 * 256 + c3[1]];
+            v.z = s_lut[2 * 256 + c3[2]];
+        }
+        *reinterpret_cast<float4*>(o + (size_t)p * 4) = v;
+    }
+}
+
+// ---- rpn_select: one block per (level, frame) --------------------------------------------------------------
+struct RpnLevels {
+    const float* cls[5];      // [frame][H][W][3]
+    const float* reg[5];      // [frame][H][W][12]
+    int h[5], w[5], stride[5];
+    float base[5][3][4];      // base anchors
+};
+
+__global__ __launch_bounds__(1024) void rpn_select_kernel(RpnLevels L, int nms_pre, float* __restrict__ score_scratch,
+                                                          int scratch_stride, float* __restrict__ cand_box,
+                                                          float* __restrict__ cand_score, int32_t* __restrict__ cand_cnt) {
+    // outputs per frame: cand_box [5*nms_pre][4], cand_score [5*nms_pre], cand_cnt [5]
+    const int lvl = blockIdx.x, f = blockIdx.y;
+    const int N = L.h[lvl] * L.w[lvl] * 3;
+    const float* cls = L.cls[lvl] + (size_t)f * N;
+    const float* reg = L.reg[lvl] + (size_t)f * N * 4;
+    int lvl_off = 0;
+    for (int l = 0; l < lvl; ++l) lvl_off += L.h[l] * L.w[l] * 3;
+    float* sc = score_scratch + (size_t)f * scratch_stride + lvl_off;
+    __shared__ int s_hist[2048];
+    __shared__ int s_w[17];
+    __shared__ float s_key[1024];
+    __shared__ int s_idx[1024];
+    __shared__ int s_sel_cnt;
+    __shared__ unsigned s_prefix;
+    __shared__ int s_need;
+
+    for (int i = threadIdx.x; i < N; i += blockDim.x) sc[i] = sigmoid_f32(cls[i]);
+    __syncthreads();
+    const int k = min(nms_pre, N);
+    int n_sel;
+    if (N <= nms_pre) {
+        // no top-k: natural index order (RPNHead only sorts when nms_pre < N)
+        for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+            s_key[i] = i < N ? sc[i] : -1.f;
+            s_idx[i] = i < N ? i : 0x7fffffff;
+        }
+        n_sel = N;
+        __syncthreads();
+    } else {
+        // radix select of the k-th largest score (scores >= 0: uint order == float order)
+        unsigned prefix = 0;
+        int need = k;            // how many still to take from the current prefix bucket
+        const int shifts[3] = {21, 10, 0};
+        const int bits[3] = {11, 11, 10};
+        for (int pass = 0; pass < 3; ++pass) {
+            for (int i = threadIdx.x; i < 2048; i += blockDim.x) s_hist[i] = 0;
+            __syncthreads();
+            const int sh = shifts[pass], nb = 1 << bits[pass];
+            const unsigned hi_mask = pass == 0 ? 0u : (0xffffffffu << (sh + bits[pass]));
+            for (int i = threadIdx.x; i < N; i += blockDim.x) {
+                const unsigned u = __float_as_uint(sc[i]);
+                if ((u & hi_mask) == (prefix & hi_mask)) atomicAdd(&s_hist[(u >> sh) & (nb - 1)], 1);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int acc = 0, b = nb - 1;
+                for (; b >= 0; --b) {
+                    if (acc + s_hist[b] >= need) break;
+                    acc += s_hist[b];
+                }
+                s_prefix = prefix | ((unsigned)b << sh);
+                s_need = need - acc;
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            need = s_need;
+            __syncthreads();
+        }
+        const float T = __uint_as_float(prefix);     // k-th largest value; `need` ties (lowest indices) are taken
+        if (threadIdx.x == 0) s_sel_cnt = 0;
+        __syncthreads();
+        int eq_seen = 0;
+        for (int base = 0; base < N; base += blockDim.x) {
+            const int i = base + threadIdx.x;
+            const float v = i < N ? sc[i] : -1.f;
+            const bool gt = v > T;
+            const bool eq = (i < N) && (v == T);
+            int tot;
+            const int r = block_rank(eq, s_w, &tot);
+            const bool take = gt || (eq && (eq_seen + r) < need);
+            if (take) {
+                const int pos = atomicAdd(&s_sel_cnt, 1);
+                s_key[pos] = v;
+                s_idx[pos] = i;
+            }
+            eq_seen += tot;
+        }
+        __syncthreads();
+        n_sel = s_sel_cnt;          // == k
+        for (int i = n_sel + threadIdx.x; i < 1024; i += blockDim.x) {
+            s_key[i] = -1.f;
+            s_idx[i] = 0x7fffffff;
+        }
+        __syncthreads();
+        // bitonic sort by (score desc, index asc)
+        for (int kk = 2; kk <= 1024; kk <<= 1) {
+            for (int j = kk >> 1; j > 0; j >>= 1) {
+                const int i = threadIdx.x, l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & kk) == 0;
+                    const float ka = s_key[i], kb = s_key[l];
+                    const int ia = s_idx[i], ib = s_idx[l];
+                    const bool a_first = ka > kb || (ka == kb && ia < ib);
+                    if (a_first != up) {
+                        s_key[i] = kb; s_key[l] = ka;
+                        s_idx[i] = ib; s_idx[l] = ia;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // decode the selected anchors
+    float* ob = cand_box + ((size_t)f * 5 + lvl) * nms_pre * 4;
+    float* os = cand_score + ((size_t)f * 5 + lvl) * nms_pre;
+    const int Wl = L.w[lvl];
+    const float stride = (float)L.stride[lvl];
+    const float ones[4] = {1.f, 1.f, 1.f, 1.f};
+    for (int r = threadIdx.x; r < n_sel; r += blockDim.x) {
+        const int idx = s_idx[r];
+        const int a = idx % 3, pos = idx / 3;
+        const int x = pos % Wl, y = pos / Wl;
+        const float sx = (float)x * stride, sy = (float)y * stride;
+        float anchor[4] = {L.base[lvl][a][0] + sx, L.base[lvl][a][1] + sy, L.base[lvl][a][2] + sx, L.base[lvl][a][3] + sy};
+        const float* d = reg + (size_t)idx * 4;
+        float dd[4] = {d[0], d[1], d[2], d[3]};
+        float box[4];
+        delta2bbox(anchor, dd, ones, box);
+        ob[4 * r] = box[0]; ob[4 * r + 1] = box[1]; ob[4 * r + 2] = box[2]; ob[4 * r + 3] = box[3];
+        os[r] = s_key[r];
+    }
+    if (threadIdx.x == 0) cand_cnt[f * 5 + lvl] = n_sel;
+}
+
+// ---- rpn_compact: concat levels, drop empty boxes, add batched_nms offsets --------------------------------
+__global__ __launch_bounds__(1024) void rpn_compact_kernel(const float* __restrict__ cand_box, const float* __restrict__ cand_score,
+                                                           const int32_t* __restrict__ cand_cnt, int nms_pre, int max_n,
+                                                           float* __restrict__ boxes, float* __restrict__ boxes_nms,
+                                                           float* __restrict__ scores, int32_t* __restrict__ n_out) {
+    const int f = blockIdx.x;
+    __shared__ int s_w[17];
+    __shared__ float s_max[16];
+    const float* cb = cand_box + (size_t)f * 5 * nms_pre * 4;
+    const float* cs = cand_score + (size_t)f * 5 * nms_pre;
+    float* ob = boxes + (size_t)f * max_n * 4;
+    float* obn = boxes_nms + (size_t)f * max_n * 4;
+    float* os = scores + (size_t)f * max_n;
+    // pass 1: max coordinate over valid boxes
+    float mx = -INFINITY;
+    for (int l = 0; l < 5; ++l) {
+        const int c = cand_cnt[f * 5 + l];
+        for (int r = threadIdx.x; r < c; r += blockDim.x) {
+            const float* b = cb + ((size_t)l * nms_pre + r) * 4;
+            if ((b[2] - b[0]) > 0.f && (b[3] - b[1]) > 0.f) mx = fmaxf(fmaxf(fmaxf(mx, b[0]), fmaxf(b[1], b[2])), b[3]);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    if (lane_id() == 0) s_max[wave_id()] = mx;
+    __syncthreads();
+    mx = s_max[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) mx = fmaxf(mx, s_max[w]);
+    const float step = mx + 1.0f;
+    // pass 2: ordered compaction
+    int written = 0;
+    for (int l = 0; l < 5; ++l) {
+        const int c = cand_cnt[f * 5 + l];
+        const float offset = (float)l * step;
+        for (int base = 0; base < c; base += blockDim.x) {
+            const int r = base + threadIdx.x;
+            bool ok = false;
+            float b[4] = {0, 0, 0, 0};
+            if (r < c) {
+                const float* p = cb + ((size_t)l * nms_pre + r) * 4;
+                b[0] = p[0]; b[1] = p[1]; b[2] = p[2]; b[3] = p[3];
+                ok = (b[2] - b[0]) > 0.f && (b[3] - b[1]) > 0.f;
+            }
+            int tot;
+            const int pos = written + block_rank(ok, s_w, &tot);
+            if (ok) {
+                ob[4 * pos] = b[0]; ob[4 * pos + 1] = b[1]; ob[4 * pos + 2] = b[2]; ob[4 * pos + 3] = b[3];
+                obn[4 * pos] = b[0] + offset; obn[4 * pos + 1] = b[1] + offset;
+                obn[4 * pos + 2] = b[2] + offset; obn[4 * pos + 3] = b[3] + offset;
+                os[pos] = cs[(size_t)l * nms_pre + r];
+            }
+            written += tot;
+        }
+    }
+    if (threadIdx.x == 0) n_out[f] = written;
+}
+
+// ---- gather the first `limit` kept boxes ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_kept_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                          int max_n, const int32_t* __restrict__ keep,
+                                                          const int32_t* __restrict__ n_keep, int limit,
+                                                          float* __restrict__ out_box, float* __restrict__ out_score,
+                                                          int32_t* __restrict__ n_out, int out5) {
+    // out5 == 0: out_box [f][limit][4] + out_score [f][limit];  out5 == 1: out_box [f][limit][5] (score in col 4)
+    const int f = blockIdx.x;
+    const int n = min(n_keep[f], limit);
+    for (int r = threadIdx.x; r < limit; r += blockDim.x) {
+        float b[4] = {0, 0, 0, 0}, s = 0.f;
+        if (r < n) {
+            const int i = keep[(size_t)f * max_n + r];
+            const float* p = boxes + ((size_t)f * max_n + i) * 4;
+            b[0] = p[0]; b[1] = p[1]; b[2] = p[2]; b[3] = p[3];
+            s = scores[(size_t)f * max_n + i];
+        }
+        if (out5) {
+            float* o = out_box + ((size_t)f * limit + r) * 5;
+            o[0] = b[0]; o[1] = b[1]; o[2] = b[2]; o[3] = b[3]; o[4] = s;
+        } else {
+            float* o = out_box + ((size_t)f * limit + r) * 4;
+            o[0] = b[0]; o[1] = b[1]; o[2] = b[2]; o[3] = b[3];
+            out_score[(size_t)f * limit + r] = s;
+        }
+    }
+    if (threadIdx.x == 0) n_out[f] = n;
+}
+
+// ---- RoIAlign ---------------------------------------------------------------------------------------------------
+struct FpnLevels {
+    const float* feat[4];   // [frame][H][W][C]
+    int h[4], w[4], stride[4];
+};
+
+__device__ __forceinline__ float bilinear(const float* feat, int H, int W, int C, int c, float y, float x) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return 0.f;
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+    if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+    const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    const float v1 = feat[((size_t)y_low * W + x_low) * C + c], v2 = feat[((size_t)y_low * W + x_high) * C + c];
+    const float v3 = feat[((size_t)y_high * W + x_low) * C + c], v4 = feat[((size_t)y_high * W + x_high) * C + c];
+    return ((w1 * v1 + w2 * v2) + w3 * v3) + w4 * v4;
+}
+
+__global__ __launch_bounds__(256) void roi_align_kernel(FpnLevels L, int C, const float* __restrict__ rois,
+                                                        const int32_t* __restrict__ n_rois, int max_rois,
+                                                        float* __restrict__ out) {
+    // grid (max_rois, frames), block C threads; out [frame*max_rois + r][7][7][C]
+    const int r = blockIdx.x, f = blockIdx.y, c = threadIdx.x;
+    float* o = out + ((size_t)f * max_rois + r) * 49 * C;
+    if (r >= n_rois[f]) {
+        for (int b = 0; b < 49; ++b) o[b * C + c] = 0.f;
+        return;
+    }
+    const float* roi = rois + ((size_t)f * max_rois + r) * 4;
+    const float rx1 = roi[0], ry1 = roi[1], rx2 = roi[2], ry2 = roi[3];
+    // SingleRoIExtractor.map_roi_levels (finest_scale 56)
+    const float scale = sqrtf((rx2 - rx1) * (ry2 - ry1));
+    int lvl = (int)floor(log2((double)(scale / 56.f + 1e-6f)));
+    lvl = min(max(lvl, 0), 3);
+    const float ss = 1.0f / (float)L.stride[lvl];
+    const int H = L.h[lvl], W = L.w[lvl];
+    const float* feat = L.feat[lvl] + (size_t)f * H * W * C;
+    const float x1 = rx1 * ss - 0.5f, y1 = ry1 * ss - 0.5f, x2 = rx2 * ss - 0.5f, y2 = ry2 * ss - 0.5f;
+    const float rw = x2 - x1, rh = y2 - y1;
+    const float bw = rw / 7.f, bh = rh / 7.f;
+    const int gh = (int)ceilf(rh / 7.f), gw = (int)ceilf(rw / 7.f);
+    const float count = (float)max(gh * gw, 1);
+    for (int ph = 0; ph < 7; ++ph) {
+        for (int pw = 0; pw < 7; ++pw) {
+            float acc = 0.f;
+            for (int iy = 0; iy < gh; ++iy) {
+                const float y = (y1 + (float)ph * bh) + (((float)iy + 0.5f) * bh) / (float)gh;
+                for (int ix = 0; ix < gw; ++ix) {
+                    const float x = (x1 + (float)pw * bw) + (((float)ix + 0.5f) * bw) / (float)gw;
+                    acc += bilinear(feat, H, W, C, c, y, x);
+                }
+            }
+            o[(ph * 7 + pw) * C + c] = acc / count;
+        }
+    }
+}
+
+// ---- final_decode: softmax, delta2bbox, rescale, score threshold, ordered compaction ---------------------------
+__global__ __launch_bounds__(1024) void final_decode_kernel(const float* __restrict__ rois, const int32_t* __restrict__ n_rois,
+                                                            int max_rois, const float* __restrict__ cls,
+                                                            const float* __restrict__ reg, float sfx, float sfy,
+                                                            float score_thr, float* __restrict__ boxes,
+                                                            float* __restrict__ scores, int32_t* __restrict__ n_out) {
+    const int f = blockIdx.x;
+    __shared__ int s_w[17];
+    const int n = n_rois[f];
+    const float stds[4] = {0.1f, 0.1f, 0.2f, 0.2f};
+    int written = 0;
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int r = base + threadIdx.x;
+        bool ok = false;
+        float b[4] = {0, 0, 0, 0}, s = 0.f;
+        if (r < n) {
+            const size_t g = (size_t)f * max_rois + r;
+            const double z0 = cls[2 * g], z1 = cls[2 * g + 1];
+            const double m = fmax(z0, z1);
+            const double e0 = exp(z0 - m), e1 = exp(z1 - m);
+            s = (float)(e0 / (e0 + e1));
+            const float roi[4] = {rois[4 * g], rois[4 * g + 1], rois[4 * g + 2], rois[4 * g + 3]};
+            const float d[4] = {reg[4 * g], reg[4 * g + 1], reg[4 * g + 2], reg[4 * g + 3]};
+            delta2bbox(roi, d, stds, b);
+            b[0] = b[0] / sfx; b[1] = b[1] / sfy; b[2] = b[2] / sfx; b[3] = b[3] / sfy;
+            ok = s > score_thr;
+        }
+        int tot;
+        const int pos = written + block_rank(ok, s_w, &tot);
+        if (ok) {
+            float* ob = boxes + ((size_t)f * max_rois + pos) * 4;
+            ob[0] = b[0]; ob[1] = b[1]; ob[2] = b[2]; ob[3] = b[3];
+            scores[(size_t)f * max_rois + pos] = s;
+        }
+        written += tot;
+    }
+    if (threadIdx.x == 0) n_out[f] = written;
+}
+
+}  // namespace
+
+// ---- launchers ------------------------------------------------------------------------------------------------------
+int det_enqueue_preprocess(hipStream_t s, const uint8_t* frames, int n_frames, int H, int W, int nh, int nw, int Hp,
+                           int Wp, const int32_t* xtab, const int32_t* ytab, const float* lut, float* out) {
+    dim3 grid(std::min((Hp * Wp + 255) / 256, 512), n_frames);
+    hipLaunchKernelGGL(det_preprocess_kernel, grid, dim3(256), 0, s, frames, H, W, nh, nw, Hp, Wp, xtab, ytab, lut, out);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}
+
+int det_enqueue_rpn(hipStream_t s, const DetRpnArgs& a, int n_frames) {
+    RpnLevels L;
+    for (int l = 0; l < 5; ++l) {
+        L.cls[l] = a.cls[l]; L.reg[l] = a.reg[l]; L.h[l] = a.h[l]; L.w[l] = a.w[l]; L.stride[l] = a.stride[l];
+        memcpy(L.base[l], a.base[l], sizeof(L.base[l]));
+    }
+    hipLaunchKernelGGL(rpn_select_kernel, dim3(5, n_frames), dim3(1024), 0, s, L, a.nms_pre, a.score_scratch,
+                       a.scratch_stride, a.cand_box, a.cand_score, a.cand_cnt);
+    hipLaunchKernelGGL(rpn_compact_kernel, dim3(n_frames), dim3(1024), 0, s, a.cand_box, a.cand_score, a.cand_cnt, a.nms_pre,
+                       a.max_n, a.boxes, a.boxes_nms, a.scores, a.n_boxes);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}
+
+int det_enqueue_gather(hipStream_t s, const float* boxes, const float* scores, int max_n, const int32_t* keep,
+                       const int32_t* n_keep, int limit, float* out_box, float* out_score, int32_t* n_out, int out5,
+                       int n_frames) {
+    hipLaunchKernelGGL(gather_kept_kernel, dim3(n_frames), dim3(256), 0, s, boxes, scores, max_n, keep, n_keep, limit,
+                       out_box, out_score, n_out, out5);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}
+
+int det_enqueue_roi_align(hipStream_t s, const DetFpnArgs& a, const float* rois, const int32_t* n_rois, int max_rois,
+                          float* out, int n_frames) {
+    PP_REQUIRE(a.c == 256, "roi_align: C=%d (kernel launches one thread per channel, C must be 256)", a.c);
+    FpnLevels L;
+    for (int l = 0; l < 4; ++l) {
+        L.feat[l] = a.feat[l]; L.h[l] = a.h[l]; L.w[l] = a.w[l]; L.stride[l] = a.stride[l];
+    }
+    hipLaunchKernelGGL(roi_align_kernel, dim3(max_rois, n_frames), dim3(a.c), 0, s, L, a.c, rois, n_rois, max_rois, out);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}
+
+int det_enqueue_final_decode(hipStream_t s, const float* rois, const int32_t* n_rois, int max_rois, const float* cls,
+                             const float* reg, float sfx, float sfy, float score_thr, float* boxes, float* scores,
+                             int32_t* n_out, int n_frames) {
+    hipLaunchKernelGGL(final_decode_kernel, dim3(n_frames), dim3(1024), 0, s, rois, n_rois, max_rois, cls, reg, sfx, sfy,
+                       score_thr, boxes, scores, n_out);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}

@@ -71,7 +71,7 @@ def synth_clip(rng, n, h, w):
     frames = rng.integers(0, 256, (n, h, w, 3)).astype(np.uint8)
     boxes = []
     for t in range(n):
-        x0, y0, bw, bh = 100 + 3 * t, 90, 120, 300
+        x0, y0, bw, bh = w // 6 + 3 * t, h // 5, 3 * w // 16, 5 * h // 8      # 120x300 at 640x480
         frames[t, y0:y0 + bh, x0:x0 + bw] = np.clip(rng.normal(180, 30, (bh, bw, 3)), 0, 255).astype(np.uint8)
         boxes.append([x0, y0, bw, bh])
     return frames, np.array(boxes, np.float64)
