@@ -1,13 +1,17 @@
 #!/usr/bin/env python
 """bench.py -- throughput of the MI355X hot path, one JSON line on rank 0.
 
-Workloads (config.workload):
-  c2  BASELINE.json configs[1]: HRNet-W32 256x192 top-down 2D keypoints on 64 pre-cropped persons per
-      step (flip_test: 128 backbone samples), flip-merge + decode, keypoints back on the host.
-      Inputs (normalised crops) are resident in HBM when the timed region starts.
-One process per GPU (torchrun); ranks work on independent frame batches (weak scaling, no data-path
-collective); weights are generated on rank 0 and broadcast over RCCL.  `value` = frames of all ranks /
-max-over-ranks wall time of exactly K steps bracketed by barrier + synchronize.
+Workloads (--workload, named in config.workload):
+  cascade (default)  BASELINE.json configs[2]/[3] on one GPU: synthetic 1080p frames -> Faster-RCNN R50-FPN
+          detect -> SORT association (host) -> HRNet-W48 384x288 top-down 2D with flip_test + DARK decode ->
+          VideoPose3D 243-frame lifting.  A step = one chunk of --chunk frames resident in HBM (u8 BGR).
+          The detector runs on every frame; because its weights are seeded-random its boxes are meaningless,
+          so the boxes fed to the tracker / 2D stage are replayed synthetic ground truth (+jitter), as
+          SURVEY.md 8(d) prescribes.
+  c2      BASELINE.json configs[1]: HRNet-W32 256x192 on 64 pre-cropped persons per step (flip_test, decode).
+One process per GPU (torchrun); ranks work on independent frame shards (weak scaling, no data-path
+collective); weights are broadcast from rank 0 over RCCL.  `value` = frames of all ranks / max-over-ranks
+wall time of exactly K steps bracketed by barrier + synchronize.
 """
 import argparse
 import json
@@ -22,125 +26,268 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+METRIC = "frames/sec (whole node), detect->2D->3D cascade on 1080p; MPJPE vs reference"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2")
-    ap.add_argument("--batch", type=int, default=64, help="person-frames per step per GPU")
-    ap.add_argument("--cpu-frames", type=int, default=6, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cascade", choices=["cascade", "c2"])
+    ap.add_argument("--chunk", type=int, default=8, help="cascade: frames per step per GPU")
+    ap.add_argument("--persons", type=int, default=1, help="cascade: tracked persons per frame")
+    ap.add_argument("--batch", type=int, default=64, help="c2: person-frames per step per GPU")
+    ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+class Dist:
+    def __init__(self):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            self.dist = dist
 
+    def barrier(self, ctx):
+        if self.dist is not None:
+            self.dist.barrier()
+        ctx.synchronize()
+
+    def bcast_blob(self, blob: np.ndarray) -> np.ndarray:
+        """weights: one RCCL broadcast from rank 0; every rank then owns the same resident blob"""
+        if self.dist is None:
+            return blob
+        import torch
+        t = torch.from_numpy(blob).cuda() if self.rank == 0 else torch.empty(blob.size, dtype=torch.float32, device="cuda")
+        self.dist.broadcast(t, src=0)
+        return t.cpu().numpy()
+
+    def max_time(self, dt):
+        if self.dist is None:
+            return dt
+        import torch
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+# ---- synthetic 1080p clip (SURVEY.md 8d, C3) ---------------------------------------------------------
+def synth_1080p(rng, n_frames, persons, h=1080, w=1920):
+    """low-frequency background + textured rectangles on linear trajectories; returns frames (BGR u8) and
+    per-frame ground-truth boxes [P][5] (x1, y1, x2, y2, score)."""
+    bg = rng.integers(40, 200, (h // 40 + 1, w // 40 + 1, 3)).astype(np.uint8)
+    bg = np.repeat(np.repeat(bg, 40, axis=0), 40, axis=1)[:h, :w]
+    frames = np.empty((n_frames, h, w, 3), np.uint8)
+    people = []
+    for p in range(persons):
+        bw = int(rng.integers(80, 200))
+        bh = int(rng.integers(250, 600))
+        people.append(dict(w=bw, h=bh, x=float(rng.uniform(0, w - bw - 60)), y=float(rng.uniform(0, h - bh)),
+                           vx=float(rng.uniform(1, 4)), tex=rng.integers(0, 256, (bh, bw, 3)).astype(np.uint8)))
+    boxes = []
+    for t in range(n_frames):
+        f = bg.copy()
+        row = []
+        for q in people:
+            x0, y0 = int(q["x"] + q["vx"] * t), int(q["y"])
+            f[y0:y0 + q["h"], x0:x0 + q["w"]] = q["tex"]
+            row.append([x0, y0, x0 + q["w"], y0 + q["h"], 0.9])
+        frames[t] = f
+        boxes.append(np.array(row, np.float32))
+    return frames, boxes
+
+
+def run_cascade(args, D):
+    from posepipeline_amd import _lib
+    from posepipeline_amd.cascade import Cascade
+    from posepipeline_amd.models import faster_rcnn as fr, hrnet, synth
+    from posepipeline_amd.models import videopose3d as vp3d
+
+    ctx = _lib.Context(D.local_rank)
+    det_sd = synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2)
+    pose_spec = hrnet.hrnet_w48_384x288()
+    pose_sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(pose_spec), seed=1)
+    lift_sd = synth.synth_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3)
+    B, P = args.chunk, args.persons
+    cas = Cascade(ctx, det_sd, pose_sd, lift_sd, 1080, 1920, chunk=B, max_persons=P)
+    if D.world > 1:
+        # the resident blobs were uploaded from locally generated (identical, seeded) weights; exercise the
+        # RCCL weight broadcast the multi-GPU deployment uses and check that it delivers the same bytes
+        for prog in (cas.detector.prog_a, cas.detector.prog_b, cas.pose_net.prog, cas.lift_net.prog):
+            got = D.bcast_blob(prog.blob)
+            assert np.array_equal(got, prog.blob)
+    rng = np.random.default_rng(3000 + D.rank)                     # config index 3, per-rank shard
+    frames, gt = synth_1080p(rng, B, P)
+    dptr = ctx.malloc(frames.nbytes)
+    ctx.h2d(dptr, frames)                                          # the chunk is resident in HBM before timing
+    jitter = np.random.default_rng(77 + D.rank)
+
+    def replay_boxes():
+        out = []
+        for g in gt:
+            b = g.copy()
+            b[:, :4] += jitter.uniform(-2, 2, (len(b), 4)).astype(np.float32)
+            b[:, 4] = jitter.uniform(0.5, 1.0, len(b)).astype(np.float32)
+            out.append(b)
+        return out
+
+    stage = dict(det_pre=0.0, det_image=0.0, det_rpn=0.0, det_roialign=0.0, det_roihead=0.0, det_final=0.0,
+                 pose_pre=0.0, pose_backbone=0.0, pose_decode=0.0)
+
+    def step(accumulate=False):
+        res = cas.step(None, frames_dev=(dptr, B), replay=replay_boxes())
+        if accumulate:
+            t = cas.detector.timing()
+            for k_, v in zip(("det_pre", "det_image", "det_rpn", "det_roialign", "det_roihead", "det_final"), t.values()):
+                stage[k_] += v
+            a, b_, c = cas.topdown.timing()
+            stage["pose_pre"] += a
+            stage["pose_backbone"] += b_
+            stage["pose_decode"] += c
+        return res
+
+    for _ in range(args.warmup):
+        res = step()
+    D.barrier(ctx)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step(True)
+    D.barrier(ctx)
+    dt = D.max_time(time.perf_counter() - t0)
+    if D.rank != 0:
+        return
+    K = args.steps
+    stage = {k: v / K for k, v in stage.items()}
+    conv_ms = stage["det_image"] + stage["det_roihead"] + stage["pose_backbone"]
+    n_launch = len(cas.detector.prog_a.ops) + len(cas.detector.prog_b.ops) + len(cas.pose_net.prog.ops)
+    flops_step = B * (cas.detector.flops_per_frame + 2 * P * cas.pose_net.prog.flops)
+    achieved = flops_step / (conv_ms * 1e-3) / 1e12
+    out = {
+        "metric": METRIC, "value": D.world * B * K / dt, "unit": "frames/s", "n_gpus": D.world, "steps": K,
+        "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[3] on one GPU per rank: 1080p detect (Faster-RCNN R50-FPN) -> SORT -> HRNet-W48 "
+                               "384x288 flip_test + DARK decode -> VideoPose3D 243-frame lifting",
+                   "frames_per_step_per_gpu": B, "persons_per_frame": P,
+                   "gflop_per_frame": flops_step / B / 1e9,
+                   "detector_boxes": "detector runs on every frame; downstream boxes are replayed synthetic GT (random-weight detector)"},
+        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (%d launches per step: detector image + RoI-head programs, HRNet-W48)" % n_launch,
+                     "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "flops_per_launch": flops_step / n_launch, "avg_launch_ms": conv_ms / n_launch, "stage_ms": stage},
+    }
+    n_cpu = 1 if args.cpu_frames is None else args.cpu_frames
+    if n_cpu > 0:
+        out["cpu_baseline"] = cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames[0], gt[0][0], cas, ctx)
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frame_bgr, gt_box, cas, ctx):
+    """CPU restatement of the reference wrapper path (oracle/) for ONE 1080p frame: detector, then the
+    top-down stage on the frame's (replayed) person box, then one 243-frame lifting window -- the per-frame bodies of
+    wrappers/mmtrack.py:37-60, wrappers/mmpose.py:60-76 and wrappers/videopose3d.py:77-85."""
+    from oracle import clib
+    from oracle import decode as odec
+    from oracle import detector as odet
+    from oracle import nets as onets
+    from oracle import preprocess as opre
+    from posepipeline_amd.models import hrnet
+    from posepipeline_amd.wrappers.videopose3d import normalize_screen_coordinates
+    clib.lib()
+    t0 = time.perf_counter()
+    dets = odet.detect(odet.FasterRCNNRef(det_sd), frame_bgr[:, :, ::-1])
+    t_det = time.perf_counter() - t0
+    bb = np.array([gt_box[0], gt_box[1], gt_box[2] - gt_box[0], gt_box[3] - gt_box[1]], np.float64)
+    t, c, s, _ = opre.top_down_input(frame_bgr[:, :, ::-1], bb, (288, 384))
+    model = onets.HRNetRef(pose_sd, 48)
+    hm = model.forward(t[None])
+    hmf = model.forward(np.ascontiguousarray(t[None, :, :, ::-1]))
+    kp, _ = odec.decode_topdown(hm, hmf, hrnet.COCO_FLIP_PAIRS, c[None], s[None], post_process="unbiased", kernel=17)
+    kn = normalize_screen_coordinates(kp[:, :, :2].astype(np.float64), 1920, 1080).astype(np.float32)
+    k3 = onets.VideoPose3DRef(lift_sd).forward(onets.videopose3d_windows(kn, 121))
+    dt = time.perf_counter() - t0
+    # the same frame through the GPU path (detector boxes NOT replayed) for a parity readout
+    g = cas.detector.run(frame_bgr[None])[0]
+    kg, _ = cas.topdown.run(frame_bgr[None], np.zeros(1, np.int32), bb[None])
+    from posepipeline_amd.wrappers.videopose3d import lift
+    k3g = lift(cas.lift_net, cas.lift_spec, normalize_screen_coordinates(kg[:, :, :2].astype(np.float64), 1920, 1080))
+    return {"value": 1.0 / dt, "unit": "frames/s", "cores": clib.N_THREADS, "kind": "port",
+            "sample": "1 synthetic 1080p frame through the CPU restatement of detect + top-down 2D (W48, flip) + one lifting window "
+                      "(%.1f s, detector %.1f s)" % (dt, t_det),
+            "parity_vs_gpu": {"detections_equal": bool(g.shape == dets.shape and np.array_equal(g, dets)),
+                              "max_abs_diff_2d_px": float(np.abs(kg[0, :, :2] - kp[0, :, :2]).max()),
+                              "max_abs_diff_3d": float(np.abs(k3g - k3).max())}}
+
+
+def run_c2(args, D):
     from posepipeline_amd import _lib, ops
     from posepipeline_amd.models import hrnet, synth
     from posepipeline_amd.program import Net
 
-    ctx = _lib.Context(local_rank)
+    ctx = _lib.Context(D.local_rank)
     spec = hrnet.hrnet_w32_256x192()
-    shapes = hrnet.hrnet_param_shapes(spec)
-    sd = synth.synth_state_dict(shapes, seed=1)
+    sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(spec), seed=1)
     prog = hrnet.build_hrnet_program(spec, sd)
-    if world > 1:
-        # weights: one RCCL broadcast from rank 0 (every rank then owns the same resident blob)
-        import torch
-        blob = torch.from_numpy(prog.blob).cuda() if rank == 0 else torch.empty(prog.blob.size, dtype=torch.float32, device="cuda")
-        dist.broadcast(blob, src=0)
-        prog.blob = blob.cpu().numpy()
-        del blob
+    prog.blob = D.bcast_blob(prog.blob)
     n = args.batch
     net = Net(ctx, prog, max_batch=2 * n)
+    # mmpose's W32 256x192 configs decode with post_process='default' (SURVEY.md 8a a10)
     td = ops.TopDown(net, num_joints=17, flip_perm=hrnet.flip_perm(17), post="default")
-    # BASELINE configs[1] names W32 256x192 -> mmpose's W32 configs decode with post_process='default' 
-
-    rng = np.random.default_rng(1000 + rank)                      # config index 1, per-rank shard
+    rng = np.random.default_rng(1000 + D.rank)                    # config index 1, per-rank shard
     x = np.zeros((n, spec.in_h, spec.in_w, 4), np.float32)
     x[..., :3] = rng.standard_normal((n, spec.in_h, spec.in_w, 3)).astype(np.float32)
     cs = np.tile(np.array([[96.0, 128.0, 192 / 200 * 1.25, 256 / 200 * 1.25]], np.float32), (n, 1))
-    dptr, nbytes, _ = net.buffer("input")
+    dptr, _, _ = net.buffer("input")
     ctx.h2d(dptr, x)                                              # inputs resident in HBM before timing
-
-    def step():
-        return td.run_precropped(dptr, cs, n=n)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        ctx.synchronize()
-
     for _ in range(args.warmup):
-        kp = step()
-    barrier()
+        kp = td.run_precropped(dptr, cs, n=n)
+    D.barrier(ctx)
     t0 = time.perf_counter()
     t_net = t_pre = t_dec = 0.0
     for _ in range(args.steps):
-        kp = step()
+        kp = td.run_precropped(dptr, cs, n=n)
         a, b, c = td.timing()
-        t_pre += a
-        t_net += b
-        t_dec += c
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    if rank == 0:
-        n_launch = len(prog.ops)
-        flops_step = prog.flops * 2 * n                          # algorithmic conv FLOPs: flip doubles the samples
-        net_ms = t_net / args.steps
-        achieved = flops_step / (net_ms * 1e-3) / 1e12
-        out = {
-            "metric": "frames/sec (whole node), detect->2D->3D cascade on 1080p; MPJPE vs reference",
-            "value": world * n * args.steps / dt,
-            "unit": "frames/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "configs[1]: HRNet-W32 256x192 top-down 2D, pre-cropped persons, flip_test, decode 'default'",
-                       "frames_per_step_per_gpu": n, "backbone_samples_per_step": 2 * n,
-                       "stages_timed": "mirror copy + backbone (fp32 MFMA) + flip-merge/decode + keypoints D2H",
-                       "not_in_this_line": "detector, tracker, 3D lifting (cascade bench lands when those stages do)"},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (all %d conv launches of the backbone program)" % n_launch,
-                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "flops_per_launch": flops_step / n_launch, "avg_launch_ms": net_ms / n_launch,
-                         "stage_ms": {"pre": t_pre / args.steps, "backbone": net_ms, "decode": t_dec / args.steps}},
-        }
-        if args.cpu_frames > 0:
-            out["cpu_baseline"] = cpu_baseline(sd, x[: args.cpu_frames], cs[: args.cpu_frames], kp[: args.cpu_frames])
-        print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        t_pre, t_net, t_dec = t_pre + a, t_net + b, t_dec + c
+    D.barrier(ctx)
+    dt = D.max_time(time.perf_counter() - t0)
+    if D.rank != 0:
+        return
+    n_launch = len(prog.ops)
+    flops_step = prog.flops * 2 * n
+    net_ms = t_net / args.steps
+    achieved = flops_step / (net_ms * 1e-3) / 1e12
+    out = {
+        "metric": METRIC, "value": D.world * n * args.steps / dt, "unit": "frames/s", "n_gpus": D.world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: HRNet-W32 256x192 top-down 2D, pre-cropped persons, flip_test, decode 'default'",
+                   "frames_per_step_per_gpu": n, "backbone_samples_per_step": 2 * n,
+                   "not_in_this_line": "detector, tracker, 3D lifting (see --workload cascade)"},
+        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (all %d conv launches of the backbone program)" % n_launch,
+                     "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                     "traffic": None, "flops_per_launch": flops_step / n_launch, "avg_launch_ms": net_ms / n_launch,
+                     "stage_ms": {"pre": t_pre / args.steps, "backbone": net_ms, "decode": t_dec / args.steps}},
+    }
+    n_cpu = 6 if args.cpu_frames is None else args.cpu_frames
+    if n_cpu > 0:
+        out["cpu_baseline"] = cpu_baseline_c2(sd, x[:n_cpu], cs[:n_cpu], kp[:n_cpu])
+    print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(sd, x, cs, kp_gpu):
-    """CPU restatement of the reference wrapper path (oracle/), per-frame batch-1 loop like
-    pose_pipeline/wrappers/mmpose.py:60-76, OpenMP over all host cores."""
+def cpu_baseline_c2(sd, x, cs, kp_gpu):
+    """per-frame batch-1 loop like pose_pipeline/wrappers/mmpose.py:60-76 on the CPU oracle"""
     from oracle import clib
     from oracle import decode as odec
     from oracle import nets as onets
@@ -159,10 +306,18 @@ def cpu_baseline(sd, x, cs, kp_gpu):
             break
     dt = time.perf_counter() - t0
     m = len(kps)
-    err = float(np.abs(np.array(kps) - kp_gpu[:m]).max())
     return {"value": m / dt, "unit": "frames/s", "cores": clib.N_THREADS, "kind": "port",
             "sample": "%d of the same pre-cropped frames, batch-1 loop, C/OpenMP fmaf-chain convs + numpy decode (%.1f s)" % (m, dt),
-            "max_abs_diff_px_vs_gpu": err}
+            "max_abs_diff_px_vs_gpu": float(np.abs(np.array(kps) - kp_gpu[:m]).max())}
+
+
+def main():
+    args = parse()
+    D = Dist()
+    try:
+        (run_cascade if args.workload == "cascade" else run_c2)(args, D)
+    finally:
+        D.close()
 
 
 if __name__ == "__main__":

@@ -218,7 +218,8 @@ void pp_tracker_destroy(pp_tracker* t);
  * (mode 0 only, may be NULL in mode 1).  Outputs (capacity cap):
  *   mode 0: every live track after the update, as parser.py:76-86 emits them: track_id, tlwh (from the
  *           Kalman mean), info[4] = (state, hits, age, time_since_update);
- *   mode 1: every kept detection (score > thr) with its id: tlwh = the detection, info[1] = its index. */
+ *   mode 1: boxes are the detector's (x1, y1, x2, y2) rows (float32 values widened to double); every kept
+ *           detection (score > thr) comes back with its id: tlwh = the input row, info[1] = its index. */
 int pp_tracker_step(pp_tracker* t, const double* dets_tlwh, const double* conf, const double* feats,
                     int n_det, int cap, int64_t* track_id, double* tlwh, int32_t* info, int32_t* n_out);
 /* debugging / parity: dump all live tracks (id, state, hits, age, time_since_update, mean[8], cov[64]) */

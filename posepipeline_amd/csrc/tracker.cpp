@@ -585,8 +585,8 @@ int pp_tracker_step(pp_tracker* t, const double* dets_tlwh, const double* conf, 
         const double* b = dets_tlwh + 4 * keep[k];
         boxes[4 * k + 0] = (float)b[0];
         boxes[4 * k + 1] = (float)b[1];
-        boxes[4 * k + 2] = (float)(b[0] + b[2]);
-        boxes[4 * k + 3] = (float)(b[1] + b[3]);
+        boxes[4 * k + 2] = (float)b[2];   // mode 1 takes the detector's x1 y1 x2 y2 rows as they are
+        boxes[4 * k + 3] = (float)b[3];
     }
     if (!t->sort_tracks.empty() && nk > 0) {
         std::vector<int> active;

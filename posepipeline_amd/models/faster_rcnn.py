@@ -170,8 +170,9 @@ class Detector:
         nb = self.prog_b.named
         bufs_b = np.array([nb["roi_in"], nb["cls"], nb["reg"]], np.int32)
         h = C.c_void_p()
+        lut, anchors = normalize_lut(), base_anchors()      # keep the arrays alive across the call
         L.check(ctx.lib.pp_detector_create(self.net_a.handle, self.net_b.handle, L.ptr(bufs_a), L.ptr(bufs_b), src_h, src_w,
-                                           L.ptr(normalize_lut()), L.ptr(base_anchors()), C.byref(h)), "pp_detector_create")
+                                           L.ptr(lut), L.ptr(anchors), C.byref(h)), "pp_detector_create")
         self.handle = h
         self.max_frames = max_frames
 
