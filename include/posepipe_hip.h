@@ -99,7 +99,7 @@ typedef struct pp_op {
     int32_t out_nchw;         /* 1: write `out` as [n][cout][H][W] planes (heatmaps) */
     int32_t res1_shift;       /* read res1 at (h >> s, w >> s)  (FPN top-down add) */
     int32_t res1_off_w;       /* read res1 at w + off (VideoPose3D centre-cropped residual) */
-    int64_t w_off, b_off;     /* float offsets into the weight blob: W[K][cout_pad16], bias[cout_pad16] */
+    int64_t w_off, b_off;     /* float offsets into the weight blob: W (layout below), bias[cout_pad16] */
 } pp_op;
 
 typedef struct pp_buf {
@@ -124,7 +124,9 @@ int pp_net_capture(pp_net* net, int batch);
 int pp_net_profile(pp_net* net, int batch, float* ms_per_op);
 
 /* single convolution on caller-provided device/host buffers (tests, VideoPose3D, FC layers).
- * x: [n][hin][win][cin]; w: [kh*kw*cin][cout_pad16]; bias: [cout_pad16]; y per op flags. */
+ * x: [n][hin][win][cin]; bias: [cout_pad16]; y per op flags.
+ * w: [ceil(K/32)][cout_pad16][32], K = kh*kw*cin, k = (kh_i*kw + kw_i)*cin + c; within a chunk of 32 k's the
+ * element 8*g + s of an output channel holds k = 32*chunk + 4*s + g (MFMA operand order; zero padded). */
 int pp_conv2d(pp_ctx* ctx, const pp_op* op, int n, int hin, int win, const float* x,
               const float* w, const float* bias, const float* res1, const float* res2, float* y,
               int res1_h, int res1_w, int mem);

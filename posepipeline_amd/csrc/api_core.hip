@@ -152,9 +152,63 @@ struct pp_net {
     int max_batch = 0;
     hipGraphExec_t graph_exec = nullptr;
     int graph_batch = 0;
+    // multi-lane execution: independent ops (HRNet branches, FPN / RPN levels) run on separate HIP streams so
+    // that the tail of one launch overlaps the head of another; dependencies (RAW on inputs / residuals, WAR
+    // and WAW on recycled buffers) become event waits.
+    std::vector<hipStream_t> lanes;
+    std::vector<int> op_lane;
+    std::vector<std::vector<int>> op_waits;   // ops on OTHER lanes this op must wait for
+    std::vector<char> op_needs_event;
+    std::vector<hipEvent_t> op_done;
+    hipEvent_t fork_ev = nullptr;
+    std::vector<hipEvent_t> join_ev;
 
     float* buf_ptr(int b) const { return arena + buf_off[b]; }
 };
+
+static void net_plan_lanes(pp_net* net, int n_lanes) {
+    const int n = (int)net->ops.size(), nb = (int)net->bufs.size();
+    net->op_lane.assign(n, 0);
+    net->op_waits.assign(n, {});
+    net->op_needs_event.assign(n, 0);
+    std::vector<int> last_writer(nb, -1);
+    std::vector<std::vector<int>> readers(nb);
+    std::vector<int> lane_tail(n_lanes, -1);
+    for (int i = 0; i < n; ++i) {
+        const pp_op& op = net->ops[i];
+        std::vector<int> deps;
+        auto add = [&](int d) {
+            if (d >= 0 && std::find(deps.begin(), deps.end(), d) == deps.end()) deps.push_back(d);
+        };
+        for (int b : {op.in, op.res1, op.res2})
+            if (b >= 0) add(last_writer[b]);
+        add(last_writer[op.out]);                       // WAW
+        for (int r : readers[op.out]) add(r);           // WAR
+        // lane: continue the lane whose tail is one of the dependencies (largest index), else the stalest lane
+        int lane = -1, best = -1;
+        for (int l = 0; l < n_lanes; ++l)
+            if (lane_tail[l] >= 0 && lane_tail[l] > best && std::find(deps.begin(), deps.end(), lane_tail[l]) != deps.end()) {
+                best = lane_tail[l];
+                lane = l;
+            }
+        if (lane < 0) {
+            lane = 0;
+            for (int l = 1; l < n_lanes; ++l)
+                if (lane_tail[l] < lane_tail[lane]) lane = l;
+        }
+        net->op_lane[i] = lane;
+        for (int d : deps)
+            if (net->op_lane[d] != lane) {
+                net->op_waits[i].push_back(d);
+                net->op_needs_event[d] = 1;
+            }
+        lane_tail[lane] = i;
+        for (int b : {op.in, op.res1, op.res2})
+            if (b >= 0 && b != op.out) readers[b].push_back(i);
+        last_writer[op.out] = i;
+        readers[op.out].clear();
+    }
+}
 
 static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
     const int nb = (int)net.bufs.size();
@@ -170,7 +224,7 @@ static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
         PP_REQUIRE((ho << op.up_log2) == bo.h && (wo << op.up_log2) == bo.w,
                    "op %d: conv output %dx%d (<<%d) does not match out buffer %dx%d", idx, ho, wo, op.up_log2,
                    bo.h, bo.w);
-        const size_t kpad = ((size_t)op.kh * op.kw * op.cin + 15) / 16 * 16;
+        const size_t kpad = ((size_t)op.kh * op.kw * op.cin + 31) / 32 * 32;
         const size_t cpad = ((size_t)op.cout + 15) / 16 * 16;
         PP_REQUIRE(op.w_off >= 0 && (size_t)op.w_off + kpad * cpad <= net.n_weights, "op %d: weights out of blob", idx);
         PP_REQUIRE(op.b_off >= 0 && (size_t)op.b_off + cpad <= net.n_weights, "op %d: bias out of blob", idx);
@@ -193,8 +247,7 @@ static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
     return PP_OK;
 }
 
-static int net_launch_op(pp_net* net, const pp_op& op, int batch) {
-    hipStream_t s = net->ctx->stream;
+static int net_launch_op(pp_net* net, const pp_op& op, int batch, hipStream_t s) {
     const pp_buf& bi = net->bufs[op.in];
     const pp_buf& bo = net->bufs[op.out];
     if (op.type == PP_OP_CONV) {
@@ -210,7 +263,7 @@ static int net_launch_op(pp_net* net, const pp_op& op, int batch) {
         a.Cout = op.cout; a.CoutPad = (op.cout + 15) / 16 * 16;
         a.KH = op.kh; a.KW = op.kw; a.stride = op.stride; a.pad_h = op.pad_h; a.pad_w = op.pad_w;
         a.dil_h = op.dil_h; a.dil_w = op.dil_w;
-        a.K = op.kh * op.kw * op.cin; a.Kpad = (a.K + 15) / 16 * 16;
+        a.K = op.kh * op.kw * op.cin; a.Kpad = (a.K + 31) / 32 * 32;
         a.HWout = a.Hout * a.Wout; a.M = batch * a.HWout;
         a.relu = op.relu; a.up_log2 = op.up_log2; a.out_nchw = op.out_nchw;
         a.res1_shift = op.res1_shift; a.res1_off_w = op.res1_off_w;
@@ -272,6 +325,19 @@ int pp_net_create(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, 
     PP_HIP_CHECK(hipMalloc((void**)&net->arena, net->arena_floats * sizeof(float)));
     PP_HIP_CHECK(hipMemsetAsync(net->arena, 0, net->arena_floats * sizeof(float), ctx->stream));
     PP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const char* env_lanes = getenv("POSEPIPE_NET_LANES");
+    const int n_lanes = env_lanes ? atoi(env_lanes) : 4;
+    if (n_lanes > 1 && n_ops >= 8) {
+        net_plan_lanes(net.get(), n_lanes);
+        net->lanes.resize(n_lanes);
+        for (auto& l : net->lanes) PP_HIP_CHECK(hipStreamCreateWithFlags(&l, hipStreamNonBlocking));
+        net->op_done.assign(n_ops, nullptr);
+        for (int i = 0; i < n_ops; ++i)
+            if (net->op_needs_event[i]) PP_HIP_CHECK(hipEventCreateWithFlags(&net->op_done[i], hipEventDisableTiming));
+        PP_HIP_CHECK(hipEventCreateWithFlags(&net->fork_ev, hipEventDisableTiming));
+        net->join_ev.resize(n_lanes);
+        for (auto& e : net->join_ev) PP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     *out = net.release();
     return PP_OK;
 }
@@ -279,6 +345,15 @@ int pp_net_create(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, 
 void pp_net_destroy(pp_net* net) {
     if (!net) return;
     if (net->ctx && net->ctx->stream) (void)hipStreamSynchronize(net->ctx->stream);
+    for (auto l : net->lanes) {
+        (void)hipStreamSynchronize(l);
+        (void)hipStreamDestroy(l);
+    }
+    for (auto e : net->op_done)
+        if (e) (void)hipEventDestroy(e);
+    for (auto e : net->join_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (net->fork_ev) (void)hipEventDestroy(net->fork_ev);
     if (net->graph_exec) (void)hipGraphExecDestroy(net->graph_exec);
     if (net->weights) (void)hipFree(net->weights);
     if (net->arena) (void)hipFree(net->arena);
@@ -301,9 +376,29 @@ int pp_net_run(pp_net* net, int batch, int first_op, int last_op) {
         PP_HIP_CHECK(hipGraphLaunch(net->graph_exec, net->ctx->stream));
         return PP_OK;
     }
+    hipStream_t main = net->ctx->stream;
+    if (net->lanes.empty() || last_op - first_op < 8) {
+        for (int i = first_op; i < last_op; ++i) {
+            int rc = net_launch_op(net, net->ops[i], batch, main);
+            if (rc != PP_OK) return rc;
+        }
+        return PP_OK;
+    }
+    // fork: every lane starts after whatever is already queued on the ctx stream
+    PP_HIP_CHECK(hipEventRecord(net->fork_ev, main));
+    for (hipStream_t l : net->lanes) PP_HIP_CHECK(hipStreamWaitEvent(l, net->fork_ev, 0));
     for (int i = first_op; i < last_op; ++i) {
-        int rc = net_launch_op(net, net->ops[i], batch);
+        hipStream_t s = net->lanes[net->op_lane[i]];
+        for (int d : net->op_waits[i])
+            if (d >= first_op) PP_HIP_CHECK(hipStreamWaitEvent(s, net->op_done[d], 0));
+        int rc = net_launch_op(net, net->ops[i], batch, s);
         if (rc != PP_OK) return rc;
+        if (net->op_needs_event[i]) PP_HIP_CHECK(hipEventRecord(net->op_done[i], s));
+    }
+    // join: the ctx stream continues after every lane
+    for (size_t l = 0; l < net->lanes.size(); ++l) {
+        PP_HIP_CHECK(hipEventRecord(net->join_ev[l], net->lanes[l]));
+        PP_HIP_CHECK(hipStreamWaitEvent(main, net->join_ev[l], 0));
     }
     return PP_OK;
 }
@@ -320,7 +415,7 @@ int pp_net_capture(pp_net* net, int batch) {
     hipGraph_t graph = nullptr;
     PP_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     int rc = PP_OK;
-    for (size_t i = 0; i < net->ops.size() && rc == PP_OK; ++i) rc = net_launch_op(net, net->ops[i], batch);
+    for (size_t i = 0; i < net->ops.size() && rc == PP_OK; ++i) rc = net_launch_op(net, net->ops[i], batch, s);
     hipError_t e = hipStreamEndCapture(s, &graph);
     if (rc != PP_OK) {
         if (graph) (void)hipGraphDestroy(graph);
@@ -359,7 +454,7 @@ int pp_net_profile(pp_net* net, int batch, float* ms_per_op) {
     int rc = PP_OK;
     PP_HIP_CHECK(hipEventRecord(ev[0], s));
     for (size_t i = 0; i < n && rc == PP_OK; ++i) {
-        rc = net_launch_op(net, net->ops[i], batch);
+        rc = net_launch_op(net, net->ops[i], batch, s);
         if (rc == PP_OK && hipEventRecord(ev[i + 1], s) != hipSuccess) rc = PP_ERR_HIP;
     }
     if (rc == PP_OK && hipStreamSynchronize(s) != hipSuccess) rc = PP_ERR_HIP;
@@ -388,7 +483,7 @@ int pp_conv2d(pp_ctx* ctx, const pp_op* op, int n, int hin, int win, const float
     a.Cout = op->cout; a.CoutPad = (op->cout + 15) / 16 * 16;
     a.KH = op->kh; a.KW = op->kw; a.stride = op->stride; a.pad_h = op->pad_h; a.pad_w = op->pad_w;
     a.dil_h = op->dil_h; a.dil_w = op->dil_w;
-    a.K = op->kh * op->kw * op->cin; a.Kpad = (a.K + 15) / 16 * 16;
+    a.K = op->kh * op->kw * op->cin; a.Kpad = (a.K + 31) / 32 * 32;
     a.HWout = a.Hout * a.Wout; a.M = n * a.HWout;
     a.relu = op->relu; a.up_log2 = op->up_log2; a.out_nchw = op->out_nchw;
     a.res1_shift = op->res1_shift; a.res1_off_w = op->res1_off_w;

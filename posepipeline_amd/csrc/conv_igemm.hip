@@ -13,34 +13,41 @@
 // natural order, so every output equals  fmaf(x_{K-1}, w_{K-1}, ... fmaf(x_0, w_0, 0))  exactly,
 // which is what oracle/conv_ref.c computes.  Zero padding contributes fmaf(0, w, acc) == acc.
 //
-// Layout: activations NHWC fp32 (Cin % 4 == 0), weights [Kpad][CoutPad] (both padded to 16 with
-// zeros), bias [CoutPad].  LDS tiles are k-major ([k][cout], [k][pixel]) with a row stride that
-// shifts consecutive k rows by 16 banks, so the ds_read_b32 operand fetches (lanes 0-15: k,
-// lanes 16-31: k+1, ...) are conflict-free.
+// Layout: activations NHWC fp32 (Cin % 4 == 0); bias [CoutPad16].  K is cut into chunks of 32.
+// Weight blob: [Kpad32/32][CoutPad16][32] with the 32 k's of a chunk stored per output channel in
+// "operand order": element 8*g + s holds k = 4*s + g.  Lane (row, g = lane>>4) of an MFMA consumes
+// k = 4*s + g at step s, so its 8 operands of a chunk are 8 contiguous floats = two ds_read_b128.
+//
+// LDS: both tiles are [row][32] (row = output channel / pixel, 128-byte rows, no padding) in operand
+// order, with the 16-byte slot index XOR-swizzled by a function of (row & 15) chosen (exhaustive
+// search over GF(2)-linear maps) so that every ds_read_b128 lane group AND the transposing
+// ds_write_b32 pattern of the pixel loader are bank-conflict free.
+// Pixel loader: lanes run along k first (8 lanes x 16 B = one 128-byte line of a pixel's channels), so a
+// wave-load touches 8 cache lines instead of 64.
+#include <cstdlib>
+
 #include "pp_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK = 32;
 
-template <int CT, int PT>
-struct Tile {
-    static constexpr int BC = 16 * CT;           // output channels per block
-    static constexpr int BP = 64 * PT;           // pixels per block (4 waves x PT x 16)
-    static constexpr int WS = BC + ((BC % 32 == 16) ? 0 : 16);
-    static constexpr int XS = BP + 16;
-    static constexpr int LDS_FLOATS = BK * WS + BK * XS;
-};
+__device__ __forceinline__ int swz(int j) {
+    // GF(2)-linear map of the row index (bit masks 2, 1, 6): conflict-free for the b128 lane groups
+    return ((j >> 1) & 1) | ((j & 1) << 1) | ((((j >> 1) ^ (j >> 2)) & 1) << 2);
+}
 
 template <int CT, int PT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
-    using T = Tile<CT, PT>;
-    constexpr int BC = T::BC, BP = T::BP, WS = T::WS, XS = T::XS;
-    __shared__ __attribute__((aligned(16))) float smem[T::LDS_FLOATS];
+    constexpr int BC = 16 * CT;          // output channels per block
+    constexpr int BP = 64 * PT;          // pixels per block (4 waves x PT x 16)
+    constexpr int NQ = 2 * PT;           // pixel quads per thread and chunk
+    constexpr int NW = (BC * 8 + 255) / 256;   // weight float4s per thread and chunk
+    __shared__ __attribute__((aligned(16))) float smem[(BC + BP) * BK];
     float* Ws = smem;
-    float* Xs = smem + BK * WS;
+    float* Xs = smem + BC * BK;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -48,82 +55,94 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int m0 = blockIdx.x * BP;
     const int c0 = blockIdx.y * BC;
 
-    // ---- X loader role: one pixel, PT k-quads per thread ---------------------------------
-    const int lp = tid % BP;
-    const int kq0 = (tid / BP) * PT;
-    const int lm = m0 + lp;
-    const bool lvalid = lm < a.M;
-    int ln = 0, lho = 0, lwo = 0;
-    if (lvalid) {
-        ln = lm / a.HWout;
-        const int rem = lm - ln * a.HWout;
-        lho = rem / a.Wout;
-        lwo = rem - lho * a.Wout;
-    }
-    const int hi0 = lho * a.stride - a.pad_h;
-    const int wi0 = lwo * a.stride - a.pad_w;
-    const float* xn = a.x + (size_t)ln * a.Hin * a.Win * a.Cin;
-
-    // (kh, kw, c) of each of this thread's k-quads for the current chunk
-    int qkh[PT], qkw[PT], qc[PT];
+    // ---- pixel loader role: k-quad kq of rows prow0 + 32*i ------------------------------------------
+    const int kq = tid & 7;
+    const int prow0 = tid >> 3;
+    const int wsw = swz(prow0 & 15);     // rows prow0 + 32*i share (row & 15)
+    unsigned pbase[NQ];                  // element offset of the pixel's image
+    int phw[NQ];                         // (hi0 << 16) | (wi0 & 0xffff), or INT_MIN for rows past M
 #pragma unroll
-    for (int i = 0; i < PT; ++i) {
-        int k4 = 4 * (kq0 + i);
-        int tap = k4 / a.Cin;
-        qc[i] = k4 - tap * a.Cin;
-        qkh[i] = tap / a.KW;
-        qkw[i] = tap - qkh[i] * a.KW;
+    for (int i = 0; i < NQ; ++i) {
+        const int m = m0 + prow0 + 32 * i;
+        if (m < a.M) {
+            const int n = m / a.HWout;
+            const int rem = m - n * a.HWout;
+            const int ho = rem / a.Wout;
+            const int wo = rem - ho * a.Wout;
+            pbase[i] = (unsigned)n * (unsigned)(a.Hin * a.Win * a.Cin);
+            phw[i] = ((ho * a.stride - a.pad_h) << 16) | ((wo * a.stride - a.pad_w) & 0xffff);
+        } else {
+            pbase[i] = 0;
+            phw[i] = (int)0x80000000;
+        }
     }
+    // (kh, kw, c) of this thread's quad in the current chunk
+    int qkh, qkw, qc;
+    {
+        const int k4 = 4 * kq;
+        const int tap = k4 / a.Cin;
+        qc = k4 - tap * a.Cin;
+        qkh = tap / a.KW;
+        qkw = tap - qkh * a.KW;
+    }
+    const float* wblob = a.w + (size_t)c0 * BK;
 
-    // ---- W loader role: one float4 per thread (threads < 4*BC active) ----------------------
-    const int wk = tid / (BC / 4);
-    const int wc4 = tid % (BC / 4);
-    const bool wactive = (wk < BK) && (c0 + 4 * wc4 < a.CoutPad);
-    const float* wsrc = a.w + (size_t)wk * a.CoutPad + c0 + 4 * wc4;
-
-    float4 xr[PT];
-    float4 wr;
+    float4 xr[NQ];
+    float4 wr[NW];
 
     auto load_chunk = [&](int k0) {
+        const bool kok = k0 + 4 * kq < a.K;
+        const int dh = qkh * a.dil_h, dw = qkw * a.dil_w;
 #pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            const int hi = hi0 + qkh[i] * a.dil_h;
-            const int wi = wi0 + qkw[i] * a.dil_w;
-            const bool ok = lvalid && (k0 + 4 * (kq0 + i) < a.K) && (unsigned)hi < (unsigned)a.Hin &&
-                            (unsigned)wi < (unsigned)a.Win;
+        for (int i = 0; i < NQ; ++i) {
+            const int hi = (phw[i] >> 16) + dh;
+            const int wi = (int)(short)(phw[i] & 0xffff) + dw;
+            const bool ok = kok && phw[i] != (int)0x80000000 && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
             if (ok) {
-                xr[i] = *reinterpret_cast<const float4*>(xn + ((size_t)hi * a.Win + wi) * a.Cin + qc[i]);
+                xr[i] = *reinterpret_cast<const float4*>(a.x + (size_t)pbase[i] + (size_t)((hi * a.Win + wi) * a.Cin + qc));
             } else {
                 xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            // advance this quad by BK for the next chunk
-            qc[i] += BK;
-            while (qc[i] >= a.Cin) {
-                qc[i] -= a.Cin;
-                if (++qkw[i] == a.KW) {
-                    qkw[i] = 0;
-                    ++qkh[i];
-                }
+        }
+        qc += BK;
+        while (qc >= a.Cin) {
+            qc -= a.Cin;
+            if (++qkw == a.KW) {
+                qkw = 0;
+                ++qkh;
             }
         }
-        if (wactive) {
-            wr = *reinterpret_cast<const float4*>(wsrc + (size_t)k0 * a.CoutPad);
-        } else {
-            wr = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* wsrc = wblob + (size_t)(k0 / BK) * a.CoutPad * BK;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int q = tid + 256 * j;
+            const int row = q >> 3;
+            if (q < BC * 8 && c0 + row < a.CoutPad) {
+                wr[j] = *reinterpret_cast<const float4*>(wsrc + (size_t)q * 4);
+            } else {
+                wr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
 
     auto store_chunk = [&]() {
+        // transpose: element r of the quad is k = 4*kq + r  ->  operand position 8*r + kq
+        const int within = kq & 3, hi_slot = kq >> 2;
 #pragma unroll
-        for (int i = 0; i < PT; ++i) {
-            float* dst = Xs + (4 * (kq0 + i)) * XS + lp;
-            dst[0] = xr[i].x;
-            dst[XS] = xr[i].y;
-            dst[2 * XS] = xr[i].z;
-            dst[3 * XS] = xr[i].w;
+        for (int i = 0; i < NQ; ++i) {
+            float* row = Xs + (prow0 + 32 * i) * BK + within;
+            row[((0 + hi_slot) ^ wsw) * 4] = xr[i].x;
+            row[((2 + hi_slot) ^ wsw) * 4] = xr[i].y;
+            row[((4 + hi_slot) ^ wsw) * 4] = xr[i].z;
+            row[((6 + hi_slot) ^ wsw) * 4] = xr[i].w;
         }
-        if (wk < BK) {
-            *reinterpret_cast<float4*>(Ws + wk * WS + 4 * wc4) = wr;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int q = tid + 256 * j;
+            if (q < BC * 8) {
+                const int row = q >> 3, sl = q & 7;
+                *reinterpret_cast<float4*>(Ws + row * BK + ((sl ^ wsw) * 4)) = wr[j];
+            }
         }
     };
 
@@ -133,10 +152,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) acc[ct][pt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int lrow = lane >> 4;   // k within the MFMA step
+    const int lrow = lane >> 4;   // g: k offset within an MFMA step
     const int lcol = lane & 15;   // cout (A) / pixel (B) within the 16-tile
-    const float* wrd = Ws + lrow * WS + lcol;
-    const float* xrd = Xs + lrow * XS + wave * (16 * PT) + lcol;
+    const int rsw = swz(lcol);
+    const float* wrd = Ws + lcol * BK;
+    const float* xrd = Xs + (wave * (16 * PT) + lcol) * BK;
 
     load_chunk(0);
     for (int k0 = 0; k0 < a.Kpad; k0 += BK) {
@@ -145,17 +165,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         __syncthreads();
         if (k0 + BK < a.Kpad) load_chunk(k0 + BK);
 #pragma unroll
-        for (int s = 0; s < BK / 4; ++s) {
-            float av[CT], bv[PT];
+        for (int h = 0; h < 2; ++h) {
+            const int so = ((2 * lrow + h) ^ rsw) * 4;
+            f32x4 av[CT], bv[PT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) av[ct] = wrd[(4 * s) * WS + ct * 16];
+            for (int ct = 0; ct < CT; ++ct) av[ct] = *reinterpret_cast<const f32x4*>(wrd + ct * 16 * BK + so);
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) bv[pt] = xrd[(4 * s) * XS + pt * 16];
+            for (int pt = 0; pt < PT; ++pt) bv[pt] = *reinterpret_cast<const f32x4*>(xrd + pt * 16 * BK + so);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt)
-                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct], bv[pt], acc[ct][pt], 0, 0, 0);
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt)
+                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct][s], bv[pt][s], acc[ct][pt], 0, 0, 0);
         }
     }
 
@@ -242,8 +265,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
 template <int CT, int PT>
 int launch_t(const ConvArgs& a, hipStream_t stream) {
-    using T = Tile<CT, PT>;
-    dim3 grid((a.M + T::BP - 1) / T::BP, (a.CoutPad + T::BC - 1) / T::BC);
+    dim3 grid((a.M + 64 * PT - 1) / (64 * PT), (a.CoutPad + 16 * CT - 1) / (16 * CT));
     hipLaunchKernelGGL((conv_igemm_kernel<CT, PT>), grid, dim3(256), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -289,6 +311,11 @@ __global__ __launch_bounds__(256) void maxpool_kernel(PoolArgs a) {
     }
 }
 
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 }  // namespace
 
 int pp_conv_out_dim(int in, int k, int stride, int pad, int dil) {
@@ -300,7 +327,17 @@ int pp_launch_conv(const ConvArgs& a, hipStream_t stream) {
         pp_set_error("conv: Cin=%d must be a multiple of 4 (pad the input channels)", a.Cin);
         return PP_ERR_ARG;
     }
+    if ((size_t)a.N * a.Hin * a.Win * a.Cin >= (size_t)1 << 32) {
+        pp_set_error("conv: input of %zu elements exceeds the 32-bit offset range", (size_t)a.N * a.Hin * a.Win * a.Cin);
+        return PP_ERR_ARG;
+    }
+    if (a.Hin >= 32768 || a.Win >= 32768) {
+        pp_set_error("conv: spatial dims must be < 32768");
+        return PP_ERR_ARG;
+    }
     if (a.M <= 0) return PP_OK;
+    static const int force_ct = env_int("POSEPIPE_CONV_CT", 0), force_pt = env_int("POSEPIPE_CONV_PT", 0),
+                     min_blocks = env_int("POSEPIPE_CONV_MIN_BLOCKS", 512);
     const int tiles = a.CoutPad / 16;
     // pick the channel tile that wastes the fewest 16-wide tiles; ties go to the larger tile
     int best_ct = 1, best_waste = 1 << 30;
@@ -311,10 +348,13 @@ int pp_launch_conv(const ConvArgs& a, hipStream_t stream) {
             best_ct = ct;
         }
     }
+    if (force_ct) best_ct = force_ct;
     const int cblocks = (tiles + best_ct - 1) / best_ct;
-    // pixel tile: keep >= ~2 blocks per CU in flight when the problem allows it
-    int pt = 4;
-    while (pt > 1 && (long)((a.M + 64 * pt - 1) / (64 * pt)) * cblocks < 512) pt >>= 1;
+    // pixel tile: 128 pixels (PT=2: 4 waves/SIMD by registers) when that still gives >= ~2 blocks per CU,
+    // else 64.  PT=4 halves the occupancy and measured 20 % slower on HRNet-W48, so it is never chosen.
+    int pt = 2;
+    while (pt > 1 && (long)((a.M + 64 * pt - 1) / (64 * pt)) * cblocks < min_blocks) pt >>= 1;
+    if (force_pt) pt = force_pt;
     switch (best_ct) {
         case 4: return launch_ct<4>(a, pt, stream);
         case 3: return launch_ct<3>(a, pt, stream);

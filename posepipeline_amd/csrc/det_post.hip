@@ -338,10 +338,77 @@ __device__ __forceinline__ float bilinear(const float* feat, int H, int W, int C
     return ((w1 * v1 + w2 * v2) + w3 * v3) + w4 * v4;
 }
 
+// 4 channels per lane (16-byte loads), one wave per bin: a 256-thread block walks the 49 bins of one RoI four
+// at a time.  Same (iy, ix) accumulation order per output as the scalar statement -> identical results.
+__device__ __forceinline__ float4 bilinear4(const float* feat, int H, int W, int C, int c, float y, float x) {
+    if (y < -1.0f || y > (float)H || x < -1.0f || x > (float)W) return make_float4(0.f, 0.f, 0.f, 0.f);
+    if (y <= 0.f) y = 0.f;
+    if (x <= 0.f) x = 0.f;
+    int y_low = (int)y, x_low = (int)x, y_high, x_high;
+    if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
+    if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
+    const float ly = y - (float)y_low, lx = x - (float)x_low, hy = 1.f - ly, hx = 1.f - lx;
+    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    const float4 v1 = *reinterpret_cast<const float4*>(feat + ((size_t)y_low * W + x_low) * C + c);
+    const float4 v2 = *reinterpret_cast<const float4*>(feat + ((size_t)y_low * W + x_high) * C + c);
+    const float4 v3 = *reinterpret_cast<const float4*>(feat + ((size_t)y_high * W + x_low) * C + c);
+    const float4 v4 = *reinterpret_cast<const float4*>(feat + ((size_t)y_high * W + x_high) * C + c);
+    float4 o;
+    o.x = ((w1 * v1.x + w2 * v2.x) + w3 * v3.x) + w4 * v4.x;
+    o.y = ((w1 * v1.y + w2 * v2.y) + w3 * v3.y) + w4 * v4.y;
+    o.z = ((w1 * v1.z + w2 * v2.z) + w3 * v3.z) + w4 * v4.z;
+    o.w = ((w1 * v1.w + w2 * v2.w) + w3 * v3.w) + w4 * v4.w;
+    return o;
+}
+
 __global__ __launch_bounds__(256) void roi_align_kernel(FpnLevels L, int C, const float* __restrict__ rois,
                                                         const int32_t* __restrict__ n_rois, int max_rois,
                                                         float* __restrict__ out) {
-    // grid (max_rois, frames), block C threads; out [frame*max_rois + r][7][7][C]
+    // grid (max_rois, frames), block 256 = 4 waves x (C/4 = 64 lanes); out [frame*max_rois + r][7][7][C]
+    const int r = blockIdx.x, f = blockIdx.y;
+    float* o = out + ((size_t)f * max_rois + r) * 49 * C;
+    if (r >= n_rois[f]) {
+        for (int i = threadIdx.x; i < 49 * C / 4; i += blockDim.x)
+            reinterpret_cast<float4*>(o)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    {
+        const int c = (threadIdx.x & 63) * 4;
+        const int wv = threadIdx.x >> 6;
+        const float* roi = rois + ((size_t)f * max_rois + r) * 4;
+        const float rx1 = roi[0], ry1 = roi[1], rx2 = roi[2], ry2 = roi[3];
+        const float scale = sqrtf((rx2 - rx1) * (ry2 - ry1));
+        int lvl = (int)floor(log2((double)(scale / 56.f + 1e-6f)));
+        lvl = min(max(lvl, 0), 3);
+        const float ss = 1.0f / (float)L.stride[lvl];
+        const int H = L.h[lvl], W = L.w[lvl];
+        const float* feat = L.feat[lvl] + (size_t)f * H * W * C;
+        const float x1 = rx1 * ss - 0.5f, y1 = ry1 * ss - 0.5f, x2 = rx2 * ss - 0.5f, y2 = ry2 * ss - 0.5f;
+        const float rw = x2 - x1, rh = y2 - y1;
+        const float bw = rw / 7.f, bh = rh / 7.f;
+        const int gh = (int)ceilf(rh / 7.f), gw = (int)ceilf(rw / 7.f);
+        const float count = (float)max(gh * gw, 1);
+        for (int bin = wv; bin < 49; bin += 4) {
+            const int ph = bin / 7, pw = bin - ph * 7;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int iy = 0; iy < gh; ++iy) {
+                const float y = (y1 + (float)ph * bh) + (((float)iy + 0.5f) * bh) / (float)gh;
+                for (int ix = 0; ix < gw; ++ix) {
+                    const float x = (x1 + (float)pw * bw) + (((float)ix + 0.5f) * bw) / (float)gw;
+                    const float4 v = bilinear4(feat, H, W, C, c, y, x);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            }
+            *reinterpret_cast<float4*>(o + bin * C + c) = make_float4(acc.x / count, acc.y / count, acc.z / count, acc.w / count);
+        }
+        return;
+    }
+}
+
+// scalar statement of the same kernel (one thread per channel), kept as the readable reference of the arithmetic
+__global__ __launch_bounds__(256) void roi_align_kernel_scalar(FpnLevels L, int C, const float* __restrict__ rois,
+                                                               const int32_t* __restrict__ n_rois, int max_rois,
+                                                               float* __restrict__ out) {
     const int r = blockIdx.x, f = blockIdx.y, c = threadIdx.x;
     float* o = out + ((size_t)f * max_rois + r) * 49 * C;
     if (r >= n_rois[f]) {

@@ -121,22 +121,52 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long*
     for (int k = 0; k < WPL; ++k) removed[k] = 0;
     const int lane = threadIdx.x;
     int cnt = 0;
-    for (int i = 0; i < n; ++i) {
-        const int w = i >> 6;
-        unsigned long long word = 0;
+    // 64 boxes (= one mask word) at a time: resolve the chunk against itself with the diagonal words held in
+    // registers (no memory on the sequential path), then OR the surviving rows into the later words with
+    // independent, batched loads.
+    const int nchunks = (n + 63) >> 6;
+    for (int c = 0; c < nchunks; ++c) {
+        unsigned long long cur = 0;
 #pragma unroll
         for (int k = 0; k < WPL; ++k)
-            if ((w >> 6) == k) word = removed[k];
-        word = __shfl(word, w & 63, 64);
-        if (!((word >> (i & 63)) & 1ull)) {
-            if (lane == 0) kp[cnt] = ord[i];
-            cnt++;
-            const unsigned long long* row = mask + ((size_t)f * max_n + i) * words;
-#pragma unroll
-            for (int k = 0; k < WPL; ++k) {
-                const int ww = lane + 64 * k;
-                if (ww >= w && ww < words) removed[k] |= row[ww];
+            if ((c >> 6) == k) cur = removed[k];
+        cur = __shfl(cur, c & 63, 64);                         // removed bits of this chunk (uniform)
+        const int i = (c << 6) + lane;
+        const unsigned long long diag = i < n ? mask[((size_t)f * max_n + i) * words + c] : 0ull;
+        const int nb = min(64, n - (c << 6));
+        unsigned long long keepmask = 0;
+        for (int b = 0; b < nb; ++b) {
+            const unsigned long long d = __shfl(diag, b, 64);
+            if (!((cur >> b) & 1ull)) {
+                keepmask |= 1ull << b;
+                cur |= d;
             }
+        }
+        if ((keepmask >> lane) & 1ull) kp[cnt + __popcll(keepmask & ((1ull << lane) - 1ull))] = ord[i];
+        cnt += __popcll(keepmask);
+        // later words: lane owns words lane and lane + 64
+        unsigned long long km = keepmask;
+        while (km) {
+            unsigned long long v[4][WPL];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int k = 0; k < WPL; ++k) v[u][k] = 0;
+                if (km) {
+                    const int b = __ffsll((long long)km) - 1;
+                    km &= km - 1;
+                    const unsigned long long* row = mask + ((size_t)f * max_n + (c << 6) + b) * words;
+#pragma unroll
+                    for (int k = 0; k < WPL; ++k) {
+                        const int ww = lane + 64 * k;
+                        if (ww > c && ww < words) v[u][k] = row[ww];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < WPL; ++k) removed[k] |= v[u][k];
         }
     }
     if (lane == 0) n_keep[f] = cnt;

@@ -4,7 +4,8 @@ A backbone is a straight-line list of pp_op records over NHWC fp32 activation bu
 weight blob.  ProgramBuilder is used by posepipeline_amd/models/*.py to turn an architecture spec +
 a state_dict (torch layouts, mmpose / VideoPose3D key names) into that form:
   * BatchNorm is folded into (weight, bias) here -- float64 math, rounded once to float32;
-  * conv weights are re-laid out to W[K][cout_pad16], k = (kh*KW + kw)*cin_pad4 + cin, K padded to 16;
+  * conv weights are re-laid out to W[K/32][cout_pad16][32] (k = (kh*KW + kw)*cin_pad4 + cin, chunks of 32 k's in
+    MFMA operand order, see pack_conv);
   * virtual buffers get physical ids by a linear-scan over lifetimes (exact-shape pooling).
 """
 from __future__ import annotations
@@ -27,7 +28,7 @@ def fold_bn(weight, conv_bias, gamma, beta, mean, var, eps=1e-5):
 
 
 def pack_conv(weight, bias, cin_pad=None):
-    """[cout][cin][kh][kw] (or [cout][cin][k] for Conv1d) -> (W[Kpad][cout_pad16], bias[cout_pad16])."""
+    """[cout][cin][kh][kw] (or [cout][cin][k] for Conv1d) -> (W[Kpad32/32][cout_pad16][32], bias[cout_pad16])."""
     w = np.asarray(weight, dtype=np.float32)
     if w.ndim == 3:  # Conv1d: treat as kh = 1
         w = w[:, :, None, :]
@@ -36,11 +37,14 @@ def pack_conv(weight, bias, cin_pad=None):
     assert cin_p % 4 == 0 and cin_p >= cin
     cout_p = (cout + 15) // 16 * 16
     k = kh * kw * cin_p
-    k_p = (k + 15) // 16 * 16
+    k_p = (k + 31) // 32 * 32
     wk = np.zeros((kh, kw, cin_p, cout_p), dtype=np.float32)
     wk[:, :, :cin, :cout] = np.transpose(w, (2, 3, 1, 0))
-    out = np.zeros((k_p, cout_p), dtype=np.float32)
-    out[:k] = wk.reshape(k, cout_p)
+    flat = np.zeros((k_p, cout_p), dtype=np.float32)            # [k][cout], k = (kh*KW + kw)*cin_pad + cin
+    flat[:k] = wk.reshape(k, cout_p)
+    # chunks of 32 k's, per output channel in MFMA operand order: position 8*g + s holds k = 4*s + g
+    chunks = flat.reshape(k_p // 32, 8, 4, cout_p)              # [chunk][s][g][cout]
+    out = np.ascontiguousarray(np.transpose(chunks, (0, 3, 2, 1))).reshape(k_p // 32, cout_p, 32)
     b = np.zeros((cout_p,), dtype=np.float32)
     if bias is not None:
         b[:cout] = np.asarray(bias, dtype=np.float32)

@@ -16,9 +16,14 @@ from posepipeline_amd.program import Net  # noqa: E402
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "w32"
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-    spec = hrnet.hrnet_w32_256x192() if which == "w32" else hrnet.hrnet_w48_384x288()
-    sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(spec), seed=1)
-    prog = hrnet.build_hrnet_program(spec, sd)
+    if which in ("det", "roi"):
+        from posepipeline_amd.models import faster_rcnn as fr
+        sd = synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2)
+        prog = fr.build_image_program(sd, 640, 1088) if which == "det" else fr.build_roi_program(sd)
+    else:
+        spec = hrnet.hrnet_w32_256x192() if which == "w32" else hrnet.hrnet_w48_384x288()
+        sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(spec), seed=1)
+        prog = hrnet.build_hrnet_program(spec, sd)
     ctx = _lib.Context(0)
     net = Net(ctx, prog, max_batch=batch)
     net.profile(batch)
