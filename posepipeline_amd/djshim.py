@@ -74,6 +74,11 @@ class _Relation:
                 if common and any(all(row[a] == k[a] for a in common) for k in keys):
                     return False
             elif kind == "sql":
+                ms = re.match(r"""\s*(\w+)\s*=\s*(["'])(.*)\2\s*$""", r)     # attr="text"
+                if ms:
+                    if row[ms.group(1)] != ms.group(3):
+                        return False
+                    continue
                 m = re.match(r"\s*(\w+)\s*(>=|<=|=|>|<)\s*(-?\d+(?:\.\d+)?)\s*$", r)
                 if not m:
                     raise NotImplementedError(f"restriction string {r!r}")
@@ -157,6 +162,19 @@ class _TableMeta(type):
         return len(cls._store)
 
 
+class _hybrid:
+    """method usable on the table class as well as on an instance (DataJoint code calls both
+    `TopDownPerson.populate(key)` and `TopDownPerson().populate(key)`)"""
+
+    def __init__(self, f):
+        self.f = f
+        self.__doc__ = f.__doc__
+
+    def __get__(self, obj, cls):
+        import functools
+        return functools.partial(self.f, obj if obj is not None else cls())
+
+
 class Table(metaclass=_TableMeta):
     definition = ""
     primary_key: list = []
@@ -174,9 +192,11 @@ class Table(metaclass=_TableMeta):
     def __len__(self):
         return len(type(self)._store)
 
+    @_hybrid
     def fetch1(self, *attrs):
         return _Relation(type(self)).fetch1(*attrs)
 
+    @_hybrid
     def fetch(self, *attrs, **kw):
         return _Relation(type(self)).fetch(*attrs, **kw)
 
@@ -194,13 +214,16 @@ class Table(metaclass=_TableMeta):
                 raise DuplicateError(f"duplicate entry in {cls.__name__}: { {a: row[a] for a in cls.primary_key} }")
         cls._store.append(row)
 
+    @_hybrid
     def insert1(self, row, skip_duplicates=False, **kw):
         type(self)._insert_row(row, skip_duplicates)
 
+    @_hybrid
     def insert(self, rows, skip_duplicates=False, **kw):
         for r in rows:
             type(self)._insert_row(r, skip_duplicates)
 
+    @_hybrid
     def delete(self):
         type(self)._store.clear()
 
@@ -221,6 +244,7 @@ class Computed(Table):
     def make(self, key):
         raise NotImplementedError
 
+    @_hybrid
     def populate(self, *restrictions, reserve_jobs=False, suppress_errors=False, display_progress=False, **kw):
         cls = type(self)
         src = self.key_source

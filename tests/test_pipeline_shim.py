@@ -111,3 +111,38 @@ def test_populate_chain_with_stub_wrappers(monkeypatch, tmp_path):
     pl.LiftingPerson().populate(lkey)
     assert calls[-1][0] == "3d" and (pl.LiftingPerson & lkey).fetch1("keypoints_3d").shape == (12, 17, 3)
     assert pl.LiftingPerson.joint_names()[0] == "Hip (root)" and len(pl.TopDownPerson.joint_names()) == 17
+
+
+def test_lifting_pipeline_recipe_with_stub_wrappers(monkeypatch, tmp_path):
+    """utils/standard_pipelines.py:110-164 on the shim: one call takes a video to LiftingPerson."""
+    import sys
+    import types
+    from posepipeline_amd import video
+    from posepipeline_amd.utils import standard_pipelines as sp
+    from posepipeline_amd.wrappers import mmpose as wmm, videopose3d as wvp
+    path = str(tmp_path / "v.ppvid")
+    video.write_ppvid(path, np.zeros((9, 32, 48, 3), np.uint8), 30.0)
+    vkey = {"video_project": "p", "filename": "g"}
+    pl.Video.insert1({**vkey, "video": path, "start_time": datetime.datetime(2024, 5, 1)})
+    one = [[{"track_id": 3, "tlbr": np.array([1.0, 2, 11, 22]), "tlhw": np.array([1.0, 2, 10, 20]), "confidence": 0.9}]] * 9
+    fake = types.ModuleType("posepipeline_amd.wrappers.mmtrack")
+    fake.mmtrack_bounding_boxes = lambda file_path, method="tracktor": one
+    monkeypatch.setitem(sys.modules, "posepipeline_amd.wrappers.mmtrack", fake)
+    import posepipeline_amd.wrappers as W
+    monkeypatch.setattr(W, "mmtrack", fake, raising=False)
+    monkeypatch.setattr(wmm, "mmpose_top_down_person", lambda key, method="x": np.ones((9, 17, 3), np.float32))
+    monkeypatch.setattr(wvp, "process_videopose3d",
+                        lambda key, **kw: {"keypoints_3d": np.zeros((9, 17, 3)), "keypoints_valid": [True] * 9})
+    assert sp.lifting_pipeline(vkey) is True
+    assert (pl.PersonBboxValid & vkey).fetch1("keep_tracks").tolist() == [3]       # auto-annotated: one identity
+    assert len(pl.TopDownPerson & vkey) == 1 and len(pl.LiftingPerson & vkey) == 1
+    assert (pl.LiftingMethod & vkey).fetch1("lifting_method") == 1
+    # a second call is a no-op that still reports success
+    assert sp.lifting_pipeline(vkey) is True
+    # two identities: no automatic annotation -> the recipe waits
+    vkey2 = {"video_project": "p", "filename": "h"}
+    pl.Video.insert1({**vkey2, "video": path, "start_time": datetime.datetime(2024, 5, 1)})
+    two = [one[0] + [{"track_id": 4, "tlbr": np.array([30.0, 2, 40, 22]), "tlhw": np.array([30.0, 2, 10, 20]), "confidence": 0.8}]] * 9
+    fake.mmtrack_bounding_boxes = lambda file_path, method="tracktor": two
+    assert sp.lifting_pipeline(vkey2) is False or sp.lifting_pipeline(vkey2) == []
+    assert len(pl.PersonBbox & vkey2) == 0
