@@ -133,7 +133,9 @@ def keypoints_from_heatmaps(heatmaps, center, scale, post_process="unbiased", ke
     n, k, h, w = heatmaps.shape
     preds, maxvals = get_max_preds(heatmaps)
     if post_process == "unbiased":
-        heatmaps = np.log(np.maximum(gaussian_blur(heatmaps, kernel), f32(1e-10))).astype(f32)
+        # float32 log, evaluated in double and rounded once so that the value does not depend on a libm
+        # (numpy's own float32 log is within 1 ulp of this; DARK's Hessian can amplify that ulp on flat maps)
+        heatmaps = np.log(np.maximum(gaussian_blur(heatmaps, kernel), f32(1e-10)).astype(f64)).astype(f32)
         for i in range(n):
             for j in range(k):
                 preds[i][j] = taylor(heatmaps[i][j], preds[i][j])

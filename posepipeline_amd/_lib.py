@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libposepipe_hip.so")
+LIB_PATH = os.environ.get("POSEPIPE_LIB", os.path.join(_HERE, "libposepipe_hip.so"))   # override: kernel A/B builds
 
 PP_MEM_HOST, PP_MEM_DEVICE = 0, 1
 PP_OP_CONV, PP_OP_MAXPOOL, PP_OP_ROIALIGN, PP_OP_COPY = 1, 2, 3, 4

@@ -39,6 +39,12 @@ __device__ __forceinline__ int swz(int j) {
     return ((j >> 1) & 1) | ((j & 1) << 1) | ((((j >> 1) ^ (j >> 2)) & 1) << 2);
 }
 
+// unsigned division by an invariant divisor (Granlund & Montgomery 1994, Fig. 4.1): exact for all 32-bit n
+__device__ __forceinline__ unsigned udiv(unsigned n, unsigned m, unsigned s1, unsigned s2) {
+    const unsigned t = __umulhi(m, n);
+    return (t + ((n - t) >> s1)) >> s2;
+}
+
 template <int CT, int PT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int BC = 16 * CT;          // output channels per block
@@ -65,9 +71,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     for (int i = 0; i < NQ; ++i) {
         const int m = m0 + prow0 + 32 * i;
         if (m < a.M) {
-            const int n = m / a.HWout;
+            const int n = (int)udiv((unsigned)m, a.div_hw_m, a.div_hw_s1, a.div_hw_s2);
             const int rem = m - n * a.HWout;
-            const int ho = rem / a.Wout;
+            const int ho = (int)udiv((unsigned)rem, a.div_w_m, a.div_w_s1, a.div_w_s2);
             const int wo = rem - ho * a.Wout;
             pbase[i] = (unsigned)n * (unsigned)(a.Hin * a.Win * a.Cin);
             phw[i] = ((ho * a.stride - a.pad_h) << 16) | ((wo * a.stride - a.pad_w) & 0xffff);
@@ -172,6 +178,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             for (int ct = 0; ct < CT; ++ct) av[ct] = *reinterpret_cast<const f32x4*>(wrd + ct * 16 * BK + so);
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) bv[pt] = *reinterpret_cast<const f32x4*>(xrd + pt * 16 * BK + so);
+#ifdef PP_CONV_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -179,6 +188,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt)
                         acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct][s], bv[pt][s], acc[ct][pt], 0, 0, 0);
+#ifdef PP_CONV_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
     }
 
@@ -188,13 +200,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int Ho2 = a.Hout << up, Wo2 = a.Wout << up;   // dims of the out buffer
     const bool vec4 = ((a.Cout & 3) == 0) && !a.out_nchw;
     const bool res1_plain = (a.res1_shift == 0 && a.res1_off_w == 0 && a.res1_H == Ho2 && a.res1_W == Wo2);
+    if (up == 0 && vec4 && (!a.res1 || res1_plain)) {
+        // common case (BasicBlock / Bottleneck / plain convs): the output pixel index IS m, no coordinate math
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int m = m0 + wave * (16 * PT) + pt * 16 + lcol;
+            if (m >= a.M) continue;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int co = c0 + ct * 16 + 4 * lrow;
+                if (co >= a.Cout) continue;
+                const size_t off = (size_t)m * a.Cout + co;
+                const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
+                float4 o = make_float4(acc[ct][pt][0] + b4.x, acc[ct][pt][1] + b4.y, acc[ct][pt][2] + b4.z, acc[ct][pt][3] + b4.w);
+                if (a.relu == PP_RELU_FIRST) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                if (a.res1) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(a.res1 + off);
+                    o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
+                }
+                if (a.res2) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(a.res2 + off);
+                    o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
+                }
+                if (a.relu == PP_RELU_LAST) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                *reinterpret_cast<float4*>(a.y + off) = o;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int pt = 0; pt < PT; ++pt) {
         const int m = m0 + wave * (16 * PT) + pt * 16 + lcol;
         if (m >= a.M) continue;
-        const int n = m / a.HWout;
+        const int n = (int)udiv((unsigned)m, a.div_hw_m, a.div_hw_s1, a.div_hw_s2);
         const int rem = m - n * a.HWout;
-        const int ho = rem / a.Wout;
+        const int ho = (int)udiv((unsigned)rem, a.div_w_m, a.div_w_s1, a.div_w_s2);
         const int wo = rem - ho * a.Wout;
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -322,7 +362,18 @@ int pp_conv_out_dim(int in, int k, int stride, int pad, int dil) {
     return (in + 2 * pad - dil * (k - 1) - 1) / stride + 1;
 }
 
-int pp_launch_conv(const ConvArgs& a, hipStream_t stream) {
+static void magic_u32(unsigned d, unsigned* m, unsigned* s1, unsigned* s2) {
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;                               // ceil(log2 d)
+    *m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    *s1 = l < 1 ? l : 1;
+    *s2 = l > 0 ? l - 1 : 0;
+}
+
+int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
+    ConvArgs a = a_in;
+    magic_u32((unsigned)a.HWout, &a.div_hw_m, &a.div_hw_s1, &a.div_hw_s2);
+    magic_u32((unsigned)a.Wout, &a.div_w_m, &a.div_w_s1, &a.div_w_s2);
     if (a.Cin % 4 != 0) {
         pp_set_error("conv: Cin=%d must be a multiple of 4 (pad the input channels)", a.Cin);
         return PP_ERR_ARG;
@@ -355,6 +406,13 @@ int pp_launch_conv(const ConvArgs& a, hipStream_t stream) {
     int pt = 2;
     while (pt > 1 && (long)((a.M + 64 * pt - 1) / (64 * pt)) * cblocks < min_blocks) pt >>= 1;
     if (force_pt) pt = force_pt;
+    {
+        // experiment knob: POSEPIPE_CONV_PT_CT<ct>=<pt> forces the pixel tile for one channel-tile class
+        static const int pt_by_ct[5] = {0, env_int("POSEPIPE_CONV_PT_CT1", 0), env_int("POSEPIPE_CONV_PT_CT2", 0),
+                                        env_int("POSEPIPE_CONV_PT_CT3", 0), env_int("POSEPIPE_CONV_PT_CT4", 0)};
+        if (pt_by_ct[best_ct] && (long)((a.M + 64 * pt_by_ct[best_ct] - 1) / (64 * pt_by_ct[best_ct])) * cblocks >= min_blocks)
+            pt = pt_by_ct[best_ct];
+    }
     switch (best_ct) {
         case 4: return launch_ct<4>(a, pt, stream);
         case 3: return launch_ct<3>(a, pt, stream);

@@ -182,7 +182,8 @@ class Detector:
 
     def close(self):
         if getattr(self, "handle", None):
-            self.ctx.lib.pp_detector_destroy(self.handle)
+            if getattr(self.ctx, "handle", None):
+                self.ctx.lib.pp_detector_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -24,6 +24,18 @@ from .. import _lib as L
 from ..program import ProgramBuilder, Program, fold_bn
 
 COCO_FLIP_PAIRS = [(1, 2), (3, 4), (5, 6), (7, 8), (9, 10), (11, 12), (13, 14), (15, 16)]
+# Halpe-136: derived from the `swap=` fields of /root/reference/3rdparty/mmpose/config/_base_/halpe.py
+HALPE_FLIP_PAIRS = COCO_FLIP_PAIRS + [
+    (20, 21), (22, 23), (24, 25), (26, 42), (27, 41), (28, 40), (29, 39), (30, 38), (31, 37), (32, 36), (33, 35),
+    (43, 52), (44, 51), (45, 50), (46, 49), (47, 48), (57, 61), (58, 60), (62, 71), (63, 70), (64, 69), (65, 68),
+    (66, 73), (67, 72), (74, 80), (75, 79), (76, 78), (81, 85), (82, 84), (86, 90), (87, 89), (91, 93)
+] + [(94 + i, 115 + i) for i in range(21)]
+# COCO-WholeBody-133: the dataset file the vendored config points to (_base_/datasets/coco_wholebody.py) is NOT in the
+# reference tree; pairs restated from the published dataset definition (unpinned).
+WHOLEBODY_FLIP_PAIRS = COCO_FLIP_PAIRS + [(17, 20), (18, 21), (19, 22)] + [(23 + i, 39 - i) for i in range(8)] + [
+    (40, 49), (41, 48), (42, 47), (43, 46), (44, 45), (54, 58), (55, 57), (59, 68), (60, 67), (61, 66), (62, 65),
+    (63, 70), (64, 69), (71, 77), (72, 76), (73, 75), (78, 82), (79, 81), (83, 87), (84, 86), (88, 90)
+] + [(91 + i, 112 + i) for i in range(21)]
 
 
 @dataclass(frozen=True)

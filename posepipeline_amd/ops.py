@@ -96,7 +96,8 @@ class TopDown:
 
     def close(self):
         if getattr(self, "handle", None):
-            self.ctx.lib.pp_topdown_destroy(self.handle)
+            if getattr(self.ctx, "handle", None) and getattr(self.net, "handle", None):
+                self.ctx.lib.pp_topdown_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

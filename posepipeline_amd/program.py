@@ -217,7 +217,8 @@ class Net:
 
     def close(self):
         if getattr(self, "handle", None):
-            self.ctx.lib.pp_net_destroy(self.handle)
+            if getattr(self.ctx, "handle", None):      # a closed context already released the device
+                self.ctx.lib.pp_net_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -21,6 +21,14 @@ from ..program import Net
 from ..video import open_video
 
 mmpose_joint_dictionary = {
+    'MMPoseWholebody': ["Nose", "Left Eye", "Right Eye", "Left Ear", "Right Ear", "Left Shoulder", "Right Shoulder",
+                        "Left Elbow", "Right Elbow", "Left Wrist", "Right Wrist", "Left Hip", "Right Hip", "Left Knee",
+                        "Right Knee", "Left Ankle", "Right Ankle", "Left Big Toe", "Left Little Toe", "Left Heel",
+                        "Right Big Toe", "Right Little Toe", "Right Heel"],
+    'MMPoseHalpe': ["Nose", "Left Eye", "Right Eye", "Left Ear", "Right Ear", "Left Shoulder", "Right Shoulder",
+                    "Left Elbow", "Right Elbow", "Left Wrist", "Right Wrist", "Left Hip", "Right Hip", "Left Knee",
+                    "Right Knee", "Left Ankle", "Right Ankle", "Head", "Neck", "Pelvis", "Left Big Toe", "Right Big Toe",
+                    "Left Little Toe", "Right Little Toe", "Left Heel", "Right Heel"],
     'MMPose': ["Nose", "Left Eye", "Right Eye", "Left Ear", "Right Ear", "Left Shoulder", "Right Shoulder",
                "Left Elbow", "Right Elbow", "Left Wrist", "Right Wrist", "Left Hip", "Right Hip", "Left Knee",
                "Right Knee", "Left Ankle", "Right Ankle"],
@@ -30,6 +38,13 @@ mmpose_joint_dictionary = {
 _METHODS = {
     "HRNet_W48_COCO": (hrnet.hrnet_w48_384x288, "mmpose/checkpoints/hrnet_w48_coco_384x288_dark-e881a4b6_20210203.pth",
                        17, hrnet.COCO_FLIP_PAIRS, "unbiased", 17),
+    # same backbone, wider head + other flip pairs (wrappers/mmpose.py:41-52; configs
+    # 3rdparty/mmpose/config/halpe/hrnet_w48_halpe_384x288_dark_plus.py, coco-wholebody/hrnet_w48_coco_wholebody_384x288_dark_plus.py)
+    "HRNet_W48_HALPE": (hrnet.hrnet_w48_384x288, "mmpose/checkpoints/hrnet_w48_halpe_384x288_dark_plus-d13c2588_20211021.pth",
+                        136, hrnet.HALPE_FLIP_PAIRS, "unbiased", 17),
+    "HRNet_W48_COCOWholeBody": (hrnet.hrnet_w48_384x288,
+                                "mmpose/checkpoints/hrnet_w48_coco_wholebody_384x288_dark-f5726563_20200918.pth",
+                                133, hrnet.WHOLEBODY_FLIP_PAIRS, "unbiased", 17),
     # BASELINE.json configs[0-1] name the W32 256x192 member of the family (mmpose's plain W32 config decodes 'default')
     "HRNet_W32_COCO": (hrnet.hrnet_w32_256x192, "mmpose/checkpoints/hrnet_w32_coco_256x192-c78dce93_20200708.pth",
                        17, hrnet.COCO_FLIP_PAIRS, "default", 11),

@@ -77,19 +77,38 @@ def synth_clip(rng, n, h, w):
     return frames, np.array(boxes, np.float64)
 
 
-def oracle_topdown(sd, width, frames_bgr, bboxes, image_size, post, kernel):
-    model = onets.HRNetRef(sd, width)
+def oracle_topdown(sd, width, frames_bgr, bboxes, image_size, post, kernel, pairs=hrnet.COCO_FLIP_PAIRS, num_joints=17):
+    model = onets.HRNetRef(sd, width, num_joints=num_joints)
     out = []
     for fr, bb in zip(frames_bgr, bboxes):
         if np.isnan(bb).any():
-            out.append(np.zeros((17, 3)))
+            out.append(np.zeros((num_joints, 3)))
             continue
         t, c, s, _ = opre.top_down_input(fr[:, :, ::-1], bb, image_size)      # wrapper's BGR->RGB, then mmpose's swap
         hm = model.forward(t[None])
         hmf = model.forward(np.ascontiguousarray(t[None, :, :, ::-1]))
-        k, _ = odec.decode_topdown(hm, hmf, hrnet.COCO_FLIP_PAIRS, c[None], s[None], post_process=post, kernel=kernel)
+        k, _ = odec.decode_topdown(hm, hmf, pairs, c[None], s[None], post_process=post, kernel=kernel)
         out.append(k[0])
     return out
+
+
+def test_halpe_136_head_and_flip_pairs(ctx):
+    """MMPoseHalpe (the method scripts/process_h36m.py uses): same backbone, K = 136, Halpe flip pairs"""
+    assert len(hrnet.HALPE_FLIP_PAIRS) == 61 and len(hrnet.WHOLEBODY_FLIP_PAIRS) == 61
+    for pairs, k in ((hrnet.HALPE_FLIP_PAIRS, 136), (hrnet.WHOLEBODY_FLIP_PAIRS, 133)):
+        perm = hrnet.flip_perm(k, pairs)
+        assert np.array_equal(perm[perm], np.arange(k)) and (perm != np.arange(k)).sum() == 122
+    spec = hrnet.HRNetSpec(32, 136, 128, 96)
+    sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(spec), seed=6)
+    net = Net(ctx, hrnet.build_hrnet_program(spec, sd), max_batch=8)
+    td = ops.TopDown(net, 136, flip_perm=hrnet.flip_perm(136, hrnet.HALPE_FLIP_PAIRS), post="unbiased", blur_kernel=17)
+    frames, bboxes = synth_clip(np.random.default_rng(4), 2, 240, 320)
+    kp, valid = td.run(frames, np.arange(2, dtype=np.int32), bboxes)
+    ref = oracle_topdown(sd, 32, frames, bboxes, (96, 128), "unbiased", 17, hrnet.HALPE_FLIP_PAIRS, 136)
+    assert kp.shape == (2, 136, 3)
+    for i in range(2):
+        assert np.array_equal(kp[i][:, 2], ref[i][:, 2].astype(np.float32))
+        assert np.abs(kp[i][:, :2] - ref[i][:, :2]).max() <= 1e-3
 
 
 def test_topdown_stage_matches_oracle_cascade(ctx):
