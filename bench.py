@@ -42,6 +42,16 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(key):
+    """HBM bytes per conv launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json); the
+    counters cannot be read from inside the process, so the figure is the profiled one for this exact shape."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)[key]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 class Dist:
     def __init__(self):
         self.rank = int(os.environ.get("RANK", "0"))
@@ -171,6 +181,20 @@ def run_cascade(args, D):
     K = args.steps
     stage = {k: v / K for k, v in stage.items()}
     conv_ms = stage["det_image"] + stage["det_roihead"] + stage["pose_backbone"]
+    # serial leg (outside the timed region): the same step with every launch on one stream, so that the per-kernel
+    # durations rocprofv3 reports are additive and comparable (POSEPIPE_NET_LANES=1 profile under profiles/)
+    nets = (cas.detector.net_a, cas.detector.net_b, cas.pose_net, cas.lift_net)
+    for nt in nets:
+        nt.set_lanes(False)
+    step()
+    serial = dict.fromkeys(stage, 0.0)
+    saved, stage = stage, serial
+    for _ in range(2):
+        step(True)
+    stage = saved
+    serial_conv_ms = (serial["det_image"] + serial["det_roihead"] + serial["pose_backbone"]) / 2
+    for nt in nets:
+        nt.set_lanes(True)
     n_launch = len(cas.detector.prog_a.ops) + len(cas.detector.prog_b.ops) + len(cas.pose_net.prog.ops)
     flops_step = B * (cas.detector.flops_per_frame + 2 * P * cas.pose_net.prog.flops)
     achieved = flops_step / (conv_ms * 1e-3) / 1e12
@@ -185,8 +209,15 @@ def run_cascade(args, D):
                    "detector_boxes": "detector runs on every frame; downstream boxes are replayed synthetic GT (random-weight detector)"},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (%d launches per step: detector image + RoI-head programs, HRNet-W48)" % n_launch,
                      "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                     "flops_per_launch": flops_step / n_launch, "avg_launch_ms": conv_ms / n_launch, "stage_ms": stage},
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                     "traffic": pmc_traffic("cascade_chunk%d_persons%d" % (B, P)),
+                     "flops_per_launch": flops_step / n_launch, "avg_launch_ms": conv_ms / n_launch, "stage_ms": stage,
+                     "launch_overlap": "programs run on 4 HIP streams; avg_launch_ms = wall time of the conv programs / launches "
+                                       "(rocprof per-kernel durations overlap and sum to more)",
+                     "serial": {"avg_launch_ms": serial_conv_ms / n_launch,
+                                "achieved": flops_step / (serial_conv_ms * 1e-3) / 1e12,
+                                "note": "same step, one stream (pp_net_set_lanes 0): comparable with rocprofv3 --stats AverageNs "
+                                        "of profiles/*_serial_kernel_stats.csv"}},
     }
     n_cpu = 1 if args.cpu_frames is None else args.cpu_frames
     if n_cpu > 0:
@@ -277,7 +308,7 @@ def run_c2(args, D):
                    "not_in_this_line": "detector, tracker, 3D lifting (see --workload cascade)"},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (all %d conv launches of the backbone program)" % n_launch,
                      "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "flops_per_launch": flops_step / n_launch, "avg_launch_ms": net_ms / n_launch,
+                     "traffic": pmc_traffic("c2_batch%d" % n), "flops_per_launch": flops_step / n_launch, "avg_launch_ms": net_ms / n_launch,
                      "stage_ms": {"pre": t_pre / args.steps, "backbone": net_ms, "decode": t_dec / args.steps}},
     }
     n_cpu = 6 if args.cpu_frames is None else args.cpu_frames

@@ -118,6 +118,10 @@ int pp_net_run(pp_net* net, int batch, int first_op, int last_op);
 /* convenience: copy `in` into buffer in_buf, run everything, copy buffer out_buf to `out` */
 int pp_net_forward(pp_net* net, int batch, int in_buf, const float* in, int out_buf, float* out,
                    int mem);
+/* Programs with >= 8 ops run on 4 HIP streams ("lanes"): independent ops (HRNet branches, FPN / RPN levels)
+ * overlap, dependencies become event waits.  enable = 0 launches every op on the ctx stream in program order
+ * (profiling: per-kernel durations are additive only then).  Results are identical either way. */
+int pp_net_set_lanes(pp_net* net, int enable);
 /* capture ops [0, n_ops) at `batch` into a hipGraph and replay it on later pp_net_run calls */
 int pp_net_capture(pp_net* net, int batch);
 /* per-op elapsed time of the last profiled run (HIP events around each op), ms; NULL-safe */

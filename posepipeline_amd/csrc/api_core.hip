@@ -152,6 +152,7 @@ struct pp_net {
     int max_batch = 0;
     hipGraphExec_t graph_exec = nullptr;
     int graph_batch = 0;
+    bool use_lanes = true;
     // multi-lane execution: independent ops (HRNet branches, FPN / RPN levels) run on separate HIP streams so
     // that the tail of one launch overlaps the head of another; dependencies (RAW on inputs / residuals, WAR
     // and WAW on recycled buffers) become event waits.
@@ -377,7 +378,7 @@ int pp_net_run(pp_net* net, int batch, int first_op, int last_op) {
         return PP_OK;
     }
     hipStream_t main = net->ctx->stream;
-    if (net->lanes.empty() || last_op - first_op < 8) {
+    if (net->lanes.empty() || !net->use_lanes || last_op - first_op < 8) {
         for (int i = first_op; i < last_op; ++i) {
             int rc = net_launch_op(net, net->ops[i], batch, main);
             if (rc != PP_OK) return rc;
@@ -400,6 +401,13 @@ int pp_net_run(pp_net* net, int batch, int first_op, int last_op) {
         PP_HIP_CHECK(hipEventRecord(net->join_ev[l], net->lanes[l]));
         PP_HIP_CHECK(hipStreamWaitEvent(main, net->join_ev[l], 0));
     }
+    return PP_OK;
+}
+
+int pp_net_set_lanes(pp_net* net, int enable) {
+    PP_REQUIRE(net, "pp_net_set_lanes: net is NULL");
+    PP_HIP_CHECK(hipStreamSynchronize(net->ctx->stream));
+    net->use_lanes = enable != 0;
     return PP_OK;
 }
 

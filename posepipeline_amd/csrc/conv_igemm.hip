@@ -51,15 +51,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int BP = 64 * PT;          // pixels per block (4 waves x PT x 16)
     constexpr int NQ = 2 * PT;           // pixel quads per thread and chunk
     constexpr int NW = (BC * 8 + 255) / 256;   // weight float4s per thread and chunk
-    __shared__ __attribute__((aligned(16))) float smem[(BC + BP) * BK];
+#ifdef PP_CONV_DB
+    constexpr int NBUF = 2;      // double-buffered LDS: one barrier per K chunk
+#else
+    constexpr int NBUF = 1;
+#endif
+    constexpr int BUF = (BC + BP) * BK;
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF];
     float* Ws = smem;
     float* Xs = smem + BC * BK;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int m0 = blockIdx.x * BP;
-    const int c0 = blockIdx.y * BC;
+    // XCD-aware tile order: the dispatcher places linear workgroup id L on XCD L % 8, each XCD has its own L2.
+    // Give every XCD a contiguous range of tiles, channel tile fastest, so that the channel tiles of one pixel
+    // tile (same im2col data) and vertically adjacent pixel tiles (shared halo rows) meet in the same L2.
+    int tile_x = blockIdx.x, tile_y = blockIdx.y;
+    if (a.xcd_remap) {
+        const unsigned total = gridDim.x * gridDim.y;
+        const unsigned L = blockIdx.x + blockIdx.y * gridDim.x;
+        const unsigned xcd = L & 7u, j = L >> 3;
+        const unsigned q = total >> 3, r = total & 7u;
+        const unsigned Lp = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        tile_y = (int)(Lp % gridDim.y);
+        tile_x = (int)(Lp / gridDim.y);
+    }
+    const int m0 = tile_x * BP;
+    const int c0 = tile_y * BC;
 
     // ---- pixel loader role: k-quad kq of rows prow0 + 32*i ------------------------------------------
     const int kq = tid & 7;
@@ -131,12 +150,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
     };
 
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](int boff) {
         // transpose: element r of the quad is k = 4*kq + r  ->  operand position 8*r + kq
         const int within = kq & 3, hi_slot = kq >> 2;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            float* row = Xs + (prow0 + 32 * i) * BK + within;
+            float* row = Xs + boff + (prow0 + 32 * i) * BK + within;
             row[((0 + hi_slot) ^ wsw) * 4] = xr[i].x;
             row[((2 + hi_slot) ^ wsw) * 4] = xr[i].y;
             row[((4 + hi_slot) ^ wsw) * 4] = xr[i].z;
@@ -147,7 +166,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             const int q = tid + 256 * j;
             if (q < BC * 8) {
                 const int row = q >> 3, sl = q & 7;
-                *reinterpret_cast<float4*>(Ws + row * BK + ((sl ^ wsw) * 4)) = wr[j];
+                *reinterpret_cast<float4*>(Ws + boff + row * BK + ((sl ^ wsw) * 4)) = wr[j];
             }
         }
     };
@@ -165,14 +184,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const float* xrd = Xs + (wave * (16 * PT) + lcol) * BK;
 
     load_chunk(0);
+#ifdef PP_CONV_DB
+    store_chunk(0);
+    __syncthreads();
+#endif
     for (int k0 = 0; k0 < a.Kpad; k0 += BK) {
+#ifdef PP_CONV_DB
+        const int boff = ((k0 / BK) & 1) * BUF;
+        if (k0 + BK < a.Kpad) load_chunk(k0 + BK);
+#else
+        const int boff = 0;
         __syncthreads();
-        store_chunk();
+        store_chunk(0);
         __syncthreads();
         if (k0 + BK < a.Kpad) load_chunk(k0 + BK);
+#endif
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int so = ((2 * lrow + h) ^ rsw) * 4;
+            const int so = boff + ((2 * lrow + h) ^ rsw) * 4;
             f32x4 av[CT], bv[PT];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) av[ct] = *reinterpret_cast<const f32x4*>(wrd + ct * 16 * BK + so);
@@ -192,6 +221,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             __builtin_amdgcn_s_setprio(0);
 #endif
         }
+#ifdef PP_CONV_DB
+        // the other buffer was last read one iteration ago, before the barrier that ended it
+        if (k0 + BK < a.Kpad) store_chunk(BUF - boff);
+        __syncthreads();
+#endif
     }
 
     // ---- epilogue: bias, residuals, ReLU, (upsampled / NCHW) store ----------------------------
@@ -374,6 +408,8 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
     ConvArgs a = a_in;
     magic_u32((unsigned)a.HWout, &a.div_hw_m, &a.div_hw_s1, &a.div_hw_s2);
     magic_u32((unsigned)a.Wout, &a.div_w_m, &a.div_w_s1, &a.div_w_s2);
+    static const int xcd_remap = env_int("POSEPIPE_CONV_XCD", 1);
+    a.xcd_remap = xcd_remap;
     if (a.Cin % 4 != 0) {
         pp_set_error("conv: Cin=%d must be a multiple of 4 (pad the input channels)", a.Cin);
         return PP_ERR_ARG;

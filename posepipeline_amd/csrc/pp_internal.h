@@ -67,6 +67,7 @@ struct ConvArgs {
     int K, Kpad, M, HWout;
     // division by the invariants HWout and Wout (Granlund-Montgomery): q = (t + ((n - t) >> s1)) >> s2, t = mulhi(m, n)
     unsigned div_hw_m, div_hw_s1, div_hw_s2, div_w_m, div_w_s1, div_w_s2;
+    int xcd_remap;   // XCD-aware tile order (performance only)
     int relu, up_log2, out_nchw;
     int res1_shift, res1_off_w, res1_H, res1_W;
 };

@@ -239,6 +239,10 @@ class Net:
         last = len(self.prog.ops) if last is None else last
         L.check(self.ctx.lib.pp_net_run(self.handle, batch, first, last), "pp_net_run")
 
+    def set_lanes(self, enable: bool):
+        """multi-stream execution of independent ops on/off (off = serial launches, for additive kernel profiles)"""
+        L.check(self.ctx.lib.pp_net_set_lanes(self.handle, int(bool(enable))), "pp_net_set_lanes")
+
     def capture(self, batch):
         L.check(self.ctx.lib.pp_net_capture(self.handle, batch), "pp_net_capture")
 
