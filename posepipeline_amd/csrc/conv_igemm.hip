@@ -79,6 +79,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
     const int m0 = tile_x * BP;
     const int c0 = tile_y * BC;
+#ifdef PP_CONV_PRIO_MODE
+    {
+        // Stagger the workgroups that share a CU: equal-priority waves advance in lockstep, so all resident blocks
+        // hit their prologue / epilogue (no MFMA work) at the same time.  Distinct wave priorities let one block own
+        // the matrix pipe while the others do their memory phases in its shadow.
+        const unsigned L = blockIdx.x + blockIdx.y * gridDim.x;
+#if PP_CONV_PRIO_MODE == 1
+        const unsigned p = (L >> 8) & 3u;
+#else
+        const unsigned p = (L >> 3) & 3u;
+#endif
+        if (p == 0) __builtin_amdgcn_s_setprio(0);
+        else if (p == 1) __builtin_amdgcn_s_setprio(1);
+        else if (p == 2) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(3);
+    }
+#endif
 
     // ---- pixel loader role: k-quad kq of rows prow0 + 32*i ------------------------------------------
     const int kq = tid & 7;
@@ -194,10 +211,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         if (k0 + BK < a.Kpad) load_chunk(k0 + BK);
 #else
         const int boff = 0;
+#if defined(PP_CONV_NOFILL) && PP_CONV_NOFILL == 1
+        // timing experiment only (wrong results): fill LDS once, then run the ds_read + MFMA loop alone
+        if (k0 == 0) {
+            __syncthreads();
+            store_chunk(0);
+            __syncthreads();
+        }
+#elif defined(PP_CONV_NOFILL) && PP_CONV_NOFILL == 2
+        // timing experiment only (wrong results): keep the LDS stores and barriers, drop the global loads
+        __syncthreads();
+        store_chunk(0);
+        __syncthreads();
+#else
         __syncthreads();
         store_chunk(0);
         __syncthreads();
         if (k0 + BK < a.Kpad) load_chunk(k0 + BK);
+#endif
 #endif
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -229,36 +260,90 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
 
     // ---- epilogue: bias, residuals, ReLU, (upsampled / NCHW) store ----------------------------
+#ifdef PP_CONV_NOEPI
+    {   // timing experiment only (wrong results): one scalar store per lane instead of the epilogue
+        float s = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) s += acc[ct][pt][0] + acc[ct][pt][1] + acc[ct][pt][2] + acc[ct][pt][3];
+        const int m = m0 + wave * (16 * PT) + lcol;
+        if (m < a.M && c0 + 4 * lrow < a.Cout) a.y[(size_t)m * a.Cout + c0 + 4 * lrow] = s;
+        return;
+    }
+#endif
     const int up = a.up_log2;
     const int f = 1 << up;
     const int Ho2 = a.Hout << up, Wo2 = a.Wout << up;   // dims of the out buffer
     const bool vec4 = ((a.Cout & 3) == 0) && !a.out_nchw;
     const bool res1_plain = (a.res1_shift == 0 && a.res1_off_w == 0 && a.res1_H == Ho2 && a.res1_W == Wo2);
     if (up == 0 && vec4 && (!a.res1 || res1_plain)) {
-        // common case (BasicBlock / Bottleneck / plain convs): the output pixel index IS m, no coordinate math
+        // common case (BasicBlock / Bottleneck / plain convs): the output pixel index IS m, no coordinate math.
+        // All bias / residual loads are issued back to back from clamped (always valid) addresses before anything
+        // consumes them: one memory round trip per phase instead of one per 16x16 tile.
+        // Loads are batched PB pixel tiles at a time so the live set stays inside the main loop's register budget.
+        constexpr int PB = (CT * PT <= 6) ? PT : 1;
+        bool cok[CT];
+        int cos[CT];
+        float4 b4[CT];
 #pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            const int m = m0 + wave * (16 * PT) + pt * 16 + lcol;
-            if (m >= a.M) continue;
+        for (int ct = 0; ct < CT; ++ct) {
+            const int co = c0 + ct * 16 + 4 * lrow;
+            cok[ct] = co < a.Cout;
+            cos[ct] = cok[ct] ? co : 0;
+            b4[ct] = *reinterpret_cast<const float4*>(a.bias + cos[ct]);
+        }
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int co = c0 + ct * 16 + 4 * lrow;
-                if (co >= a.Cout) continue;
-                const size_t off = (size_t)m * a.Cout + co;
-                const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
-                float4 o = make_float4(acc[ct][pt][0] + b4.x, acc[ct][pt][1] + b4.y, acc[ct][pt][2] + b4.z, acc[ct][pt][3] + b4.w);
-                if (a.relu == PP_RELU_FIRST) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-                if (a.res1) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(a.res1 + off);
-                    o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
-                }
-                if (a.res2) {
-                    const float4 r4 = *reinterpret_cast<const float4*>(a.res2 + off);
-                    o.x += r4.x; o.y += r4.y; o.z += r4.z; o.w += r4.w;
-                }
-                if (a.relu == PP_RELU_LAST) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-                *reinterpret_cast<float4*>(a.y + off) = o;
+        for (int p0 = 0; p0 < PT; p0 += PB) {
+            bool mok[PB];
+            size_t moff[PB];
+#pragma unroll
+            for (int pb = 0; pb < PB; ++pb) {
+                const int m = m0 + wave * (16 * PT) + (p0 + pb) * 16 + lcol;
+                mok[pb] = m < a.M;
+                moff[pb] = (size_t)(mok[pb] ? m : 0) * (size_t)a.Cout;
             }
+            float4 o[CT][PB];
+            if (a.res1) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb)
+                        o[ct][pb] = *reinterpret_cast<const float4*>(a.res1 + moff[pb] + cos[ct]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) {
+                    const f32x4 c = acc[ct][p0 + pb];
+                    float4 v = make_float4(c[0] + b4[ct].x, c[1] + b4[ct].y, c[2] + b4[ct].z, c[3] + b4[ct].w);
+                    if (a.relu == PP_RELU_FIRST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (a.res1) { v.x += o[ct][pb].x; v.y += o[ct][pb].y; v.z += o[ct][pb].z; v.w += o[ct][pb].w; }
+                    o[ct][pb] = v;
+                }
+            if (a.res2) {
+                float4 r2[CT][PB];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb)
+                        r2[ct][pb] = *reinterpret_cast<const float4*>(a.res2 + moff[pb] + cos[ct]);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                    for (int pb = 0; pb < PB; ++pb) {
+                        o[ct][pb].x += r2[ct][pb].x; o[ct][pb].y += r2[ct][pb].y;
+                        o[ct][pb].z += r2[ct][pb].z; o[ct][pb].w += r2[ct][pb].w;
+                    }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pb = 0; pb < PB; ++pb) {
+                    float4 v = o[ct][pb];
+                    if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (mok[pb] && cok[ct]) *reinterpret_cast<float4*>(a.y + moff[pb] + cos[ct]) = v;
+                }
         }
         return;
     }
