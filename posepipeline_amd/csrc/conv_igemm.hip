@@ -51,15 +51,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int BP = 64 * PT;          // pixels per block (4 waves x PT x 16)
     constexpr int NQ = 2 * PT;           // pixel quads per thread and chunk
     constexpr int NW = (BC * 8 + 255) / 256;   // weight float4s per thread and chunk
-#ifdef PP_CONV_DB
-    constexpr int NBUF = 2;      // double-buffered LDS: one barrier per K chunk
-#else
-    constexpr int NBUF = 1;
-#endif
-    constexpr int BUF = (BC + BP) * BK;
-    __shared__ __attribute__((aligned(16))) float smem[NBUF * BUF];
+    constexpr int WROWS = NW * 32;       // weight rows staged per chunk (>= BC; the extra rows are never read)
+    __shared__ __attribute__((aligned(16))) float smem[(WROWS + BP) * BK];
     float* Ws = smem;
-    float* Xs = smem + BC * BK;
+    float* Xs = smem + WROWS * BK;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -79,113 +74,76 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
     const int m0 = tile_x * BP;
     const int c0 = tile_y * BC;
-#ifdef PP_CONV_PRIO_MODE
-    {
-        // Stagger the workgroups that share a CU: equal-priority waves advance in lockstep, so all resident blocks
-        // hit their prologue / epilogue (no MFMA work) at the same time.  Distinct wave priorities let one block own
-        // the matrix pipe while the others do their memory phases in its shadow.
-        const unsigned L = blockIdx.x + blockIdx.y * gridDim.x;
-#if PP_CONV_PRIO_MODE == 1
-        const unsigned p = (L >> 8) & 3u;
-#else
-        const unsigned p = (L >> 3) & 3u;
-#endif
-        if (p == 0) __builtin_amdgcn_s_setprio(0);
-        else if (p == 1) __builtin_amdgcn_s_setprio(1);
-        else if (p == 2) __builtin_amdgcn_s_setprio(2);
-        else __builtin_amdgcn_s_setprio(3);
-    }
-#endif
 
-    // ---- pixel loader role: k-quad kq of rows prow0 + 32*i ------------------------------------------
+    // ---- loader role: k-quad kq of pixel rows prow0 + 32*i, weight float4s tid + 256*j ------------------
+    // Everything between the two barriers of a K step is straight-line code (clamped addresses + selects instead
+    // of branches), so the scheduler is free to slot the address arithmetic of the next chunk's loads into the
+    // issue gaps of this chunk's MFMAs.
     const int kq = tid & 7;
     const int prow0 = tid >> 3;
     const int wsw = swz(prow0 & 15);     // rows prow0 + 32*i share (row & 15)
     unsigned pbase[NQ];                  // element offset of the pixel's image
-    int phw[NQ];                         // (hi0 << 16) | (wi0 & 0xffff), or INT_MIN for rows past M
+    int phw[NQ];                         // (hi0 << 16) | (wi0 & 0xffff); hi0 = -32768 for rows past M (never in range)
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int m = m0 + prow0 + 32 * i;
-        if (m < a.M) {
-            const int n = (int)udiv((unsigned)m, a.div_hw_m, a.div_hw_s1, a.div_hw_s2);
-            const int rem = m - n * a.HWout;
-            const int ho = (int)udiv((unsigned)rem, a.div_w_m, a.div_w_s1, a.div_w_s2);
-            const int wo = rem - ho * a.Wout;
-            pbase[i] = (unsigned)n * (unsigned)(a.Hin * a.Win * a.Cin);
-            phw[i] = ((ho * a.stride - a.pad_h) << 16) | ((wo * a.stride - a.pad_w) & 0xffff);
-        } else {
-            pbase[i] = 0;
-            phw[i] = (int)0x80000000;
-        }
+        const bool mok = m < a.M;
+        const unsigned mm = mok ? (unsigned)m : 0u;
+        const int n = (int)udiv(mm, a.div_hw_m, a.div_hw_s1, a.div_hw_s2);
+        const int rem = (int)mm - n * a.HWout;
+        const int ho = (int)udiv((unsigned)rem, a.div_w_m, a.div_w_s1, a.div_w_s2);
+        const int wo = rem - ho * a.Wout;
+        pbase[i] = (unsigned)n * (unsigned)(a.Hin * a.Win * a.Cin);
+        phw[i] = mok ? (((ho * a.stride - a.pad_h) << 16) | ((wo * a.stride - a.pad_w) & 0xffff)) : (int)0x80000000;
     }
-    // (kh, kw, c) of this thread's quad in the current chunk
-    int qkh, qkw, qc;
-    {
-        const int k4 = 4 * kq;
-        const int tap = k4 / a.Cin;
-        qc = k4 - tap * a.Cin;
-        qkh = tap / a.KW;
-        qkw = tap - qkh * a.KW;
-    }
+    static_assert(NW <= 2, "weight loader handles at most 64 rows");
+    // float offset of this thread's weight float4s inside a chunk of the blob (rows past the blob re-read row 0)
+    const unsigned wofs0 = (unsigned)(((c0 + prow0 < a.CoutPad) ? prow0 : 0) * BK + kq * 4);
+    const unsigned wofs1 = (unsigned)(((c0 + prow0 + 32 < a.CoutPad) ? prow0 + 32 : 0) * BK + kq * 4);
     const float* wblob = a.w + (size_t)c0 * BK;
 
     float4 xr[NQ];
-    float4 wr[NW];
+    float4 wr0, wr1;
+    // raw buffer descriptor over the whole input (x_bytes < 4 GiB: the launcher splits larger batches)
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
 
     auto load_chunk = [&](int k0) {
-        const bool kok = k0 + 4 * kq < a.K;
+        // (kh, kw, c) of this thread's quad: k = k0 + 4*kq = (kh*KW + kw)*Cin + c
+        const unsigned k4 = (unsigned)(k0 + 4 * kq);
+        const unsigned tap = udiv(k4, a.div_c_m, a.div_c_s1, a.div_c_s2);
+        const int qc = (int)(k4 - tap * (unsigned)a.Cin);
+        const int qkh = (int)udiv(tap, a.div_kw_m, a.div_kw_s1, a.div_kw_s2);
+        const int qkw = (int)tap - qkh * a.KW;
+        const bool kok = (int)k4 < a.K;
         const int dh = qkh * a.dil_h, dw = qkw * a.dil_w;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int hi = (phw[i] >> 16) + dh;
             const int wi = (int)(short)(phw[i] & 0xffff) + dw;
-            const bool ok = kok && phw[i] != (int)0x80000000 && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
-            if (ok) {
-                xr[i] = *reinterpret_cast<const float4*>(a.x + (size_t)pbase[i] + (size_t)((hi * a.Win + wi) * a.Cin + qc));
-            } else {
-                xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-        qc += BK;
-        while (qc >= a.Cin) {
-            qc -= a.Cin;
-            if (++qkw == a.KW) {
-                qkw = 0;
-                ++qkh;
-            }
+            const bool ok = kok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
+            // out-of-image taps / rows past M / k past K: an out-of-range byte offset, for which the buffer load
+            // returns zeros -- no branch, no select
+            const unsigned off = ok ? (pbase[i] + (unsigned)((hi * a.Win + wi) * a.Cin + qc)) * 4u : 0xffffffffu;
+            xr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
         }
         const float* wsrc = wblob + (size_t)(k0 / BK) * a.CoutPad * BK;
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const int q = tid + 256 * j;
-            const int row = q >> 3;
-            if (q < BC * 8 && c0 + row < a.CoutPad) {
-                wr[j] = *reinterpret_cast<const float4*>(wsrc + (size_t)q * 4);
-            } else {
-                wr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
+        wr0 = *reinterpret_cast<const float4*>(wsrc + wofs0);
+        if (NW > 1) wr1 = *reinterpret_cast<const float4*>(wsrc + wofs1);
     };
 
-    auto store_chunk = [&](int boff) {
+    auto store_chunk = [&]() {
         // transpose: element r of the quad is k = 4*kq + r  ->  operand position 8*r + kq
         const int within = kq & 3, hi_slot = kq >> 2;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
-            float* row = Xs + boff + (prow0 + 32 * i) * BK + within;
+            float* row = Xs + (prow0 + 32 * i) * BK + within;
             row[((0 + hi_slot) ^ wsw) * 4] = xr[i].x;
             row[((2 + hi_slot) ^ wsw) * 4] = xr[i].y;
             row[((4 + hi_slot) ^ wsw) * 4] = xr[i].z;
             row[((6 + hi_slot) ^ wsw) * 4] = xr[i].w;
         }
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-            const int q = tid + 256 * j;
-            if (q < BC * 8) {
-                const int row = q >> 3, sl = q & 7;
-                *reinterpret_cast<float4*>(Ws + boff + row * BK + ((sl ^ wsw) * 4)) = wr[j];
-            }
-        }
+        *reinterpret_cast<float4*>(Ws + prow0 * BK + ((kq ^ wsw) * 4)) = wr0;
+        if (NW > 1) *reinterpret_cast<float4*>(Ws + (prow0 + 32) * BK + ((kq ^ wsw) * 4)) = wr1;
     };
 
     f32x4 acc[CT][PT];
@@ -200,78 +158,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const float* wrd = Ws + lcol * BK;
     const float* xrd = Xs + (wave * (16 * PT) + lcol) * BK;
 
+    auto mma_half = [&](int h) {
+        const int so = ((2 * lrow + h) ^ rsw) * 4;
+        f32x4 av[CT], bv[PT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) av[ct] = *reinterpret_cast<const f32x4*>(wrd + ct * 16 * BK + so);
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) bv[pt] = *reinterpret_cast<const f32x4*>(xrd + pt * 16 * BK + so);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct][s], bv[pt][s], acc[ct][pt], 0, 0, 0);
+    };
+
     load_chunk(0);
-#ifdef PP_CONV_DB
-    store_chunk(0);
-    __syncthreads();
-#endif
-    for (int k0 = 0; k0 < a.Kpad; k0 += BK) {
-#ifdef PP_CONV_DB
-        const int boff = ((k0 / BK) & 1) * BUF;
-        if (k0 + BK < a.Kpad) load_chunk(k0 + BK);
-#else
-        const int boff = 0;
-#if defined(PP_CONV_NOFILL) && PP_CONV_NOFILL == 1
-        // timing experiment only (wrong results): fill LDS once, then run the ds_read + MFMA loop alone
-        if (k0 == 0) {
-            __syncthreads();
-            store_chunk(0);
-            __syncthreads();
-        }
-#elif defined(PP_CONV_NOFILL) && PP_CONV_NOFILL == 2
-        // timing experiment only (wrong results): keep the LDS stores and barriers, drop the global loads
+    int k0 = 0;
+    for (; k0 + BK < a.Kpad; k0 += BK) {
         __syncthreads();
-        store_chunk(0);
+        store_chunk();
         __syncthreads();
-#else
-        __syncthreads();
-        store_chunk(0);
-        __syncthreads();
-        if (k0 + BK < a.Kpad) load_chunk(k0 + BK);
-#endif
-#endif
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int so = boff + ((2 * lrow + h) ^ rsw) * 4;
-            f32x4 av[CT], bv[PT];
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) av[ct] = *reinterpret_cast<const f32x4*>(wrd + ct * 16 * BK + so);
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) bv[pt] = *reinterpret_cast<const f32x4*>(xrd + pt * 16 * BK + so);
-#ifdef PP_CONV_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                    for (int pt = 0; pt < PT; ++pt)
-                        acc[ct][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ct][s], bv[pt][s], acc[ct][pt], 0, 0, 0);
-#ifdef PP_CONV_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
-        }
-#ifdef PP_CONV_DB
-        // the other buffer was last read one iteration ago, before the barrier that ended it
-        if (k0 + BK < a.Kpad) store_chunk(BUF - boff);
-        __syncthreads();
-#endif
+        load_chunk(k0 + BK);
+        mma_half(0);
+        mma_half(1);
     }
+    __syncthreads();
+    store_chunk();
+    __syncthreads();
+    mma_half(0);
+    if (k0 + 16 < a.K) mma_half(1);   // the second half of the last chunk may hold no taps (e.g. K = 9*48)
 
     // ---- epilogue: bias, residuals, ReLU, (upsampled / NCHW) store ----------------------------
-#ifdef PP_CONV_NOEPI
-    {   // timing experiment only (wrong results): one scalar store per lane instead of the epilogue
-        float s = 0.f;
-#pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int pt = 0; pt < PT; ++pt) s += acc[ct][pt][0] + acc[ct][pt][1] + acc[ct][pt][2] + acc[ct][pt][3];
-        const int m = m0 + wave * (16 * PT) + lcol;
-        if (m < a.M && c0 + 4 * lrow < a.Cout) a.y[(size_t)m * a.Cout + c0 + 4 * lrow] = s;
-        return;
-    }
-#endif
     const int up = a.up_log2;
     const int f = 1 << up;
     const int Ho2 = a.Hout << up, Wo2 = a.Wout << up;   // dims of the out buffer
@@ -493,14 +412,12 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
     ConvArgs a = a_in;
     magic_u32((unsigned)a.HWout, &a.div_hw_m, &a.div_hw_s1, &a.div_hw_s2);
     magic_u32((unsigned)a.Wout, &a.div_w_m, &a.div_w_s1, &a.div_w_s2);
+    magic_u32((unsigned)a.Cin, &a.div_c_m, &a.div_c_s1, &a.div_c_s2);
+    magic_u32((unsigned)a.KW, &a.div_kw_m, &a.div_kw_s1, &a.div_kw_s2);
     static const int xcd_remap = env_int("POSEPIPE_CONV_XCD", 1);
     a.xcd_remap = xcd_remap;
     if (a.Cin % 4 != 0) {
         pp_set_error("conv: Cin=%d must be a multiple of 4 (pad the input channels)", a.Cin);
-        return PP_ERR_ARG;
-    }
-    if ((size_t)a.N * a.Hin * a.Win * a.Cin >= (size_t)1 << 32) {
-        pp_set_error("conv: input of %zu elements exceeds the 32-bit offset range", (size_t)a.N * a.Hin * a.Win * a.Cin);
         return PP_ERR_ARG;
     }
     if (a.Hin >= 32768 || a.Win >= 32768) {
@@ -508,6 +425,32 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
         return PP_ERR_ARG;
     }
     if (a.M <= 0) return PP_OK;
+    // The pixel loader addresses the input through one raw buffer descriptor (32-bit byte offsets, out-of-range
+    // offsets read as zero), so one launch covers < 4 GiB of input: larger batches are cut into image ranges.
+    const size_t img_bytes = (size_t)a.Hin * a.Win * a.Cin * sizeof(float);
+    const size_t max_bytes = 0xfffffff0u;
+    if (img_bytes > max_bytes) {
+        pp_set_error("conv: one input image of %zu bytes exceeds the 4 GiB buffer range", img_bytes);
+        return PP_ERR_ARG;
+    }
+    if ((size_t)a.N * img_bytes > max_bytes) {
+        const int per = (int)(max_bytes / img_bytes);
+        const size_t y_img = (size_t)(a.Hout << a.up_log2) * (a.Wout << a.up_log2) * a.Cout;
+        const size_t r1_img = (size_t)a.res1_H * a.res1_W * a.Cout;
+        for (int n0 = 0; n0 < a.N; n0 += per) {
+            ConvArgs p = a_in;
+            p.N = std::min(per, a.N - n0);
+            p.M = p.N * a.HWout;
+            p.x = a.x + (size_t)n0 * (img_bytes / sizeof(float));
+            p.y = a.y + (size_t)n0 * y_img;
+            if (a.res1) p.res1 = a.res1 + (size_t)n0 * r1_img;
+            if (a.res2) p.res2 = a.res2 + (size_t)n0 * y_img;
+            const int rc = pp_launch_conv(p, stream);
+            if (rc != PP_OK) return rc;
+        }
+        return PP_OK;
+    }
+    a.x_bytes = (unsigned)((size_t)a.N * img_bytes);
     static const int force_ct = env_int("POSEPIPE_CONV_CT", 0), force_pt = env_int("POSEPIPE_CONV_PT", 0),
                      min_blocks = env_int("POSEPIPE_CONV_MIN_BLOCKS", 512);
     const int tiles = a.CoutPad / 16;

@@ -67,7 +67,9 @@ struct ConvArgs {
     int K, Kpad, M, HWout;
     // division by the invariants HWout and Wout (Granlund-Montgomery): q = (t + ((n - t) >> s1)) >> s2, t = mulhi(m, n)
     unsigned div_hw_m, div_hw_s1, div_hw_s2, div_w_m, div_w_s1, div_w_s2;
+    unsigned div_c_m, div_c_s1, div_c_s2, div_kw_m, div_kw_s1, div_kw_s2;   // / Cin, / KW
     int xcd_remap;   // XCD-aware tile order (performance only)
+    unsigned x_bytes; // size of the input tensor of this launch (buffer-load range check)
     int relu, up_log2, out_nchw;
     int res1_shift, res1_off_w, res1_H, res1_W;
 };
