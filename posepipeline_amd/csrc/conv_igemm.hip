@@ -123,7 +123,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             const bool ok = kok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
             // out-of-image taps / rows past M / k past K: an out-of-range byte offset, for which the buffer load
             // returns zeros -- no branch, no select
+#ifdef PP_CONV_L1ONLY
+            const unsigned off = ok ? ((pbase[i] + (unsigned)((hi * a.Win + wi) * a.Cin + qc)) * 4u) & 0x3ff0u : 0xffffffffu;   // timing experiment: every load hits a 16 KB window
+#else
             const unsigned off = ok ? (pbase[i] + (unsigned)((hi * a.Win + wi) * a.Cin + qc)) * 4u : 0xffffffffu;
+#endif
             xr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
         }
         const float* wsrc = wblob + (size_t)(k0 / BK) * a.CoutPad * BK;
@@ -158,15 +162,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const float* wrd = Ws + lcol * BK;
     const float* xrd = Xs + (wave * (16 * PT) + lcol) * BK;
 
-    auto mma_half = [&](int h) {
+    f32x4 av[CT], bv[PT];
+    auto read_operands = [&](int h) {
         const int so = ((2 * lrow + h) ^ rsw) * 4;
-        f32x4 av[CT], bv[PT];
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) av[ct] = *reinterpret_cast<const f32x4*>(wrd + ct * 16 * BK + so);
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) bv[pt] = *reinterpret_cast<const f32x4*>(xrd + pt * 16 * BK + so);
+    };
+    auto mma_steps = [&](int s0, int s1) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s = s0; s < s1; ++s)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -180,15 +186,27 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         __syncthreads();
         store_chunk();
         __syncthreads();
+        // Order after the barrier: operand reads first (their LDS latency hides behind what follows), one MFMA step
+        // to get the matrix pipe going, and only then the address arithmetic + issue of the next chunk's loads.
+        read_operands(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_steps(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
         load_chunk(k0 + BK);
-        mma_half(0);
-        mma_half(1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_steps(1, 4);
+        read_operands(1);
+        mma_steps(0, 4);
     }
     __syncthreads();
     store_chunk();
     __syncthreads();
-    mma_half(0);
-    if (k0 + 16 < a.K) mma_half(1);   // the second half of the last chunk may hold no taps (e.g. K = 9*48)
+    read_operands(0);
+    mma_steps(0, 4);
+    if (k0 + 16 < a.K) {   // the second half of the last chunk may hold no taps (e.g. K = 9*48)
+        read_operands(1);
+        mma_steps(0, 4);
+    }
 
     // ---- epilogue: bias, residuals, ReLU, (upsampled / NCHW) store ----------------------------
     const int up = a.up_log2;

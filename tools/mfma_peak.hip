@@ -10,11 +10,14 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int CT, int PT, int MODE>
-__global__ __launch_bounds__(256) void mfma_loop(float* out, int iters) {
+//   mode 2: mode 1 + two __syncthreads per 32-k step (the conv kernel's barrier structure, still no fill work)
+// THREADS = 256 or 128: how many SIMDs one block's barrier couples
+//   mode 3: mode 1 + NV independent full-rate VALU instructions per 32-k step (do VALU and MFMA overlap on a SIMD?)
+template <int CT, int PT, int MODE, int THREADS = 256, int NV = 0>
+__global__ __launch_bounds__(THREADS) void mfma_loop(float* out, int iters) {
     __shared__ __attribute__((aligned(16))) float smem[(16 * CT + 64 * PT) * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < (16 * CT + 64 * PT) * 32; i += 256) smem[i] = (float)(i & 7) * 0.125f;
+    for (int i = tid; i < (16 * CT + 64 * PT) * 32; i += THREADS) smem[i] = (float)(i & 7) * 0.125f;
     __syncthreads();
     f32x4 acc[CT][PT];
     for (int ct = 0; ct < CT; ++ct)
@@ -24,10 +27,24 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters) {
     f32x4 av[CT], bv[PT];
     for (int ct = 0; ct < CT; ++ct) av[ct] = *reinterpret_cast<const f32x4*>(wrd + ct * 512);
     for (int pt = 0; pt < PT; ++pt) bv[pt] = *reinterpret_cast<const f32x4*>(xrd + pt * 512);
+    unsigned vx[4] = {(unsigned)tid, (unsigned)tid * 3u, (unsigned)tid * 5u, (unsigned)tid * 7u};
+    unsigned vy[4] = {1u, 2u, 3u, 4u};
     for (int it = 0; it < iters; ++it) {
+        if (MODE == 3) {
+#pragma unroll
+            for (int v = 0; v < NV / 2; ++v) {
+                vx[v & 3] += vy[v & 3];
+                vy[v & 3] ^= vx[v & 3];
+            }
+        }
+        if (MODE == 2) {
+            __syncthreads();
+            if (it == 0x7fffffff) smem[tid] = 1.f;   // never true: keeps the barriers from merging
+            __syncthreads();
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            if (MODE == 1) {
+            if (MODE >= 1) {
                 // volatile-ish: the offset depends on the loop counter so the reads stay in the loop
                 const int so = ((it + h) & 1) * 4;
 #pragma unroll
@@ -47,29 +64,30 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters) {
     float s = 0.f;
     for (int ct = 0; ct < CT; ++ct)
         for (int pt = 0; pt < PT; ++pt) s += acc[ct][pt][0] + acc[ct][pt][1] + acc[ct][pt][2] + acc[ct][pt][3];
+    if (MODE == 3) s += (float)(vx[0] ^ vx[1] ^ vx[2] ^ vx[3] ^ vy[0] ^ vy[1] ^ vy[2] ^ vy[3]);
     if (s == 12345.678f) out[0] = s;   // keep the loop alive
 }
 
-template <int CT, int PT, int MODE>
+template <int CT, int PT, int MODE, int THREADS = 256, int NV = 0>
 void run(const char* name, int blocks_per_cu, float* d_out) {
     const int iters = 4000;
     const int blocks = 256 * blocks_per_cu;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL((mfma_loop<CT, PT, MODE>), dim3(blocks), dim3(256), 0, 0, d_out, iters);
+    hipLaunchKernelGGL((mfma_loop<CT, PT, MODE, THREADS, NV>), dim3(blocks), dim3(THREADS), 0, 0, d_out, iters);
     hipDeviceSynchronize();
     float best = 1e30f;
     for (int rep = 0; rep < 5; ++rep) {
         hipEventRecord(e0, 0);
-        hipLaunchKernelGGL((mfma_loop<CT, PT, MODE>), dim3(blocks), dim3(256), 0, 0, d_out, iters);
+        hipLaunchKernelGGL((mfma_loop<CT, PT, MODE, THREADS, NV>), dim3(blocks), dim3(THREADS), 0, 0, d_out, iters);
         hipEventRecord(e1, 0);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         if (ms < best) best = ms;
     }
-    const double flops = (double)blocks * 4 /*waves*/ * iters * 8.0 * CT * PT * (16 * 16 * 4 * 2);
+    const double flops = (double)blocks * (THREADS / 64) * iters * 8.0 * CT * PT * (16 * 16 * 4 * 2);
     printf("%-28s blocks/CU %d  %8.3f ms  %7.2f TFLOP/s\n", name, blocks_per_cu, best, flops / best / 1e9);
 }
 
@@ -85,6 +103,15 @@ int main() {
     run<4, 2, 0>("reg-only CT4 PT2", 4, d_out);
     run<4, 2, 1>("lds-read CT4 PT2", 4, d_out);
     run<2, 1, 1>("lds-read CT2 PT1", 4, d_out);
+    for (int b = 2; b <= 4; ++b) run<3, 2, 2>("barriers CT3 PT2 256thr", b, d_out);
+    for (int b = 4; b <= 8; b += 2) run<3, 2, 2, 128>("barriers CT3 PT2 128thr", b, d_out);
+    for (int b = 8; b <= 16; b += 4) run<3, 2, 2, 64>("barriers CT3 PT2 64thr", b, d_out);
+    run<3, 2, 3, 256, 32>("lds-read + 32 VALU", 4, d_out);
+    run<3, 2, 3, 256, 64>("lds-read + 64 VALU", 4, d_out);
+    run<3, 2, 3, 256, 128>("lds-read + 128 VALU", 4, d_out);
+    run<3, 2, 3, 256, 256>("lds-read + 256 VALU", 4, d_out);
+    run<1, 2, 2>("barriers CT1 PT2 256thr", 4, d_out);
+    run<4, 2, 2>("barriers CT4 PT2 256thr", 4, d_out);
     // sustained: 40 back-to-back launches (~power/clock steady state)
     {
         hipEvent_t e0, e1;
