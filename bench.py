@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cascade", choices=["cascade", "c2"])
-    ap.add_argument("--chunk", type=int, default=16, help="cascade: frames per step per GPU")
+    ap.add_argument("--chunk", type=int, default=32, help="cascade: frames per step per GPU")
     ap.add_argument("--persons", type=int, default=1, help="cascade: tracked persons per frame")
     ap.add_argument("--batch", type=int, default=64, help="c2: person-frames per step per GPU")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the CPU-baseline sample (0 = skip)")
@@ -219,6 +219,26 @@ def run_cascade(args, D):
                                 "note": "same step, one stream (pp_net_set_lanes 0): comparable with rocprofv3 --stats AverageNs "
                                         "of profiles/*_serial_kernel_stats.csv"}},
     }
+    if D.rank == 0:
+        # PCIe-inclusive leg (reported beside `value`, never as it): the same chunks streamed from host memory through
+        # page-locked staging buffers and the copy stream (posepipeline_amd/streaming.py), upload overlapped with compute
+        from posepipeline_amd.video import ArrayVideo
+        n_chunks = 6
+        host_clip = ArrayVideo(np.concatenate([frames] * n_chunks))
+        cas.reset()
+        rb = replay_boxes()
+        n_seen, t1 = 0, None
+        for o in cas.run_video(host_clip, replay_fn=lambda first, n: rb[:n]):
+            if t1 is None:
+                t1 = time.perf_counter()      # steady state: staging-buffer allocation and the first upload are start-up
+            else:
+                n_seen += len(o["tracks"])
+        ctx.synchronize()
+        dt_stream = time.perf_counter() - t1
+        out["pcie_inclusive"] = {"value": n_seen / dt_stream, "unit": "frames/s",
+                                 "note": "steady state over %d frames read once from host memory, copied into page-locked "
+                                         "staging buffers by a reader thread and uploaded on a copy stream while the previous "
+                                         "chunk computes (posepipeline_amd/streaming.py)" % n_seen}
     n_cpu = 1 if args.cpu_frames is None else args.cpu_frames
     if n_cpu > 0:
         out["cpu_baseline"] = cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames[0], gt[0][0], cas, ctx)

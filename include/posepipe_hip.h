@@ -64,6 +64,17 @@ int pp_malloc(pp_ctx* ctx, size_t bytes, void** dptr);
 int pp_free(pp_ctx* ctx, void* dptr);
 int pp_memcpy_h2d(pp_ctx* ctx, void* dst, const void* src, size_t bytes);
 int pp_memcpy_d2h(pp_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* Frame upload path (replaces the per-frame cv2.VideoCapture.read() -> model H2D of wrappers/mmtrack.py:38-45 and
+ * wrappers/mmpose.py:60-75 with a chunked, double-buffered transfer): page-locked host staging buffers and an
+ * asynchronous host->device copy on the context's copy stream, so chunk k+1 is uploaded while chunk k computes.
+ *   pp_upload_begin   enqueue the copy (waits, on the device, for the last pp_upload_release);
+ *   pp_upload_wait    make the compute stream wait for the last upload (host_sync != 0: also block the host);
+ *   pp_upload_release mark, in compute-stream order, that the device buffer may be overwritten again. */
+int pp_host_alloc(pp_ctx* ctx, size_t bytes, void** host_ptr);
+int pp_host_free(pp_ctx* ctx, void* host_ptr);
+int pp_upload_begin(pp_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
+int pp_upload_wait(pp_ctx* ctx, int host_sync);
+int pp_upload_release(pp_ctx* ctx);
 
 /* ---- layer programs (backbones) ----------------------------------------------------------
  * A network is a straight-line program of ops over numbered NHWC fp32 activation buffers.

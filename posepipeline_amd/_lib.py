@@ -72,6 +72,11 @@ SIGNATURES = {
     "pp_free": (_i, [_vp, _vp]),
     "pp_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "pp_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "pp_host_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "pp_host_free": (_i, [_vp, _vp]),
+    "pp_upload_begin": (_i, [_vp, _vp, _vp, _sz]),
+    "pp_upload_wait": (_i, [_vp, _i]),
+    "pp_upload_release": (_i, [_vp]),
     "pp_net_create": (_i, [_vp, C.POINTER(pp_op), _i, C.POINTER(pp_buf), _i, _vp, _sz, _i, C.POINTER(_vp)]),
     "pp_net_destroy": (None, [_vp]),
     "pp_net_buffer": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_sz)]),

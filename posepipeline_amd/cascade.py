@@ -92,3 +92,19 @@ class Cascade:
                 kp[tid] = arr[-n_new:]
                 kp3d[tid] = out[-n_new:]
         return dict(tracks=chunk_tracks, keypoints=kp, keypoints_3d=kp3d)
+
+    def run_video(self, video, replay_fn=None, max_frames=None):
+        """Whole clip, read once: frames stream through page-locked staging buffers and the copy stream
+        (streaming.FrameStreamer) while the previous chunk computes.  video: video.open_video() object.
+        replay_fn(first, n) -> per-frame replay boxes (see step).  Yields step() results, one per chunk."""
+        from .streaming import FrameStreamer
+        assert (video.height, video.width) == self.src, ((video.height, video.width), self.src)
+        streamer = FrameStreamer(self.ctx, video, self.chunk, max_frames=max_frames)
+        try:
+            for dev_ptr, n, first in streamer:
+                out = self.step(None, frames_dev=(dev_ptr, n), replay=None if replay_fn is None else replay_fn(first, n))
+                streamer.release()
+                out["first_frame"] = first
+                yield out
+        finally:
+            streamer.close()

@@ -62,6 +62,9 @@ int pp_ctx_create(int device, pp_ctx** out) {
     PP_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     PP_HIP_CHECK(hipEventCreate(&c->ev_start));
     PP_HIP_CHECK(hipEventCreate(&c->ev_stop));
+    PP_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    PP_HIP_CHECK(hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+    PP_HIP_CHECK(hipEventCreateWithFlags(&c->ev_consumed, hipEventDisableTiming));
     *out = c.release();
     return PP_OK;
 }
@@ -73,6 +76,12 @@ void pp_ctx_destroy(pp_ctx* ctx) {
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
+    if (ctx->ev_upload) (void)hipEventDestroy(ctx->ev_upload);
+    if (ctx->ev_consumed) (void)hipEventDestroy(ctx->ev_consumed);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -125,6 +134,42 @@ int pp_memcpy_h2d(pp_ctx* ctx, void* dst, const void* src, size_t bytes) {
     PP_REQUIRE(ctx && (bytes == 0 || (dst && src)), "pp_memcpy_h2d: NULL argument");
     PP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
     PP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PP_OK;
+}
+
+int pp_host_alloc(pp_ctx* ctx, size_t bytes, void** out) {
+    PP_REQUIRE(ctx && out, "pp_host_alloc: NULL argument");
+    *out = nullptr;
+    PP_HIP_CHECK(hipSetDevice(ctx->device));
+    PP_HIP_CHECK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return PP_OK;
+}
+
+int pp_host_free(pp_ctx* ctx, void* p) {
+    PP_REQUIRE(ctx != nullptr, "pp_host_free: ctx is NULL");
+    if (p) PP_HIP_CHECK(hipHostFree(p));
+    return PP_OK;
+}
+
+int pp_upload_begin(pp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    PP_REQUIRE(ctx && (bytes == 0 || (dst && src)), "pp_upload_begin: NULL argument");
+    // the destination may still be read by compute work enqueued before the last pp_upload_release
+    PP_HIP_CHECK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_consumed, 0));
+    PP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    PP_HIP_CHECK(hipEventRecord(ctx->ev_upload, ctx->copy_stream));
+    return PP_OK;
+}
+
+int pp_upload_wait(pp_ctx* ctx, int host_sync) {
+    PP_REQUIRE(ctx != nullptr, "pp_upload_wait: ctx is NULL");
+    PP_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_upload, 0));
+    if (host_sync) PP_HIP_CHECK(hipEventSynchronize(ctx->ev_upload));
+    return PP_OK;
+}
+
+int pp_upload_release(pp_ctx* ctx) {
+    PP_REQUIRE(ctx != nullptr, "pp_upload_release: ctx is NULL");
+    PP_HIP_CHECK(hipEventRecord(ctx->ev_consumed, ctx->stream));
     return PP_OK;
 }
 

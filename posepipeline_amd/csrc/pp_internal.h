@@ -34,6 +34,10 @@ struct pp_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = true;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    // frame upload path: a second (copy) stream so that host->device transfers of the next chunk overlap compute
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_upload = nullptr;     // recorded after the last pp_upload_begin
+    hipEvent_t ev_consumed = nullptr;   // recorded by pp_upload_release: compute no longer reads the buffer
     // grow-only device scratch used to stage PP_MEM_HOST arguments
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
