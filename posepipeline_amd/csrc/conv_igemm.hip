@@ -45,7 +45,12 @@ __device__ __forceinline__ unsigned udiv(unsigned n, unsigned m, unsigned s1, un
     return (t + ((n - t) >> s1)) >> s2;
 }
 
-template <int CT, int PT>
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+// WALK: Cin >= 32, so a 32-k chunk spans at most two kernel taps and the tap bookkeeping can live on the scalar unit
+// (see load_chunk).  The generic variant decodes every lane's tap with two magic divisions per chunk.
+template <int CT, int PT, bool WALK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     constexpr int BC = 16 * CT;          // output channels per block
     constexpr int BP = 64 * PT;          // pixels per block (4 waves x PT x 16)
@@ -93,8 +98,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const int rem = (int)mm - n * a.HWout;
         const int ho = (int)udiv((unsigned)rem, a.div_w_m, a.div_w_s1, a.div_w_s2);
         const int wo = rem - ho * a.Wout;
-        pbase[i] = (unsigned)n * (unsigned)(a.Hin * a.Win * a.Cin);
-        phw[i] = mok ? (((ho * a.stride - a.pad_h) << 16) | ((wo * a.stride - a.pad_w) & 0xffff)) : (int)0x80000000;
+        const int hi0 = ho * a.stride - a.pad_h, wi0 = wo * a.stride - a.pad_w;
+        // WALK: byte offset of (n, hi0, wi0, channel 0) modulo 2^32 (hi0 / wi0 may be negative); else: the image's
+        // element offset
+        pbase[i] = WALK ? (unsigned)(((n * a.Hin + hi0) * a.Win + wi0) * a.Cin) * 4u
+                        : (unsigned)n * (unsigned)(a.Hin * a.Win * a.Cin);
+        phw[i] = mok ? ((hi0 << 16) | (wi0 & 0xffff)) : (int)0x80000000;
     }
     static_assert(NW <= 2, "weight loader handles at most 64 rows");
     // float offset of this thread's weight float4s inside a chunk of the blob (rows past the blob re-read row 0)
@@ -107,28 +116,63 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     // raw buffer descriptor over the whole input (x_bytes < 4 GiB: the launcher splits larger batches)
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
 
+    // WALK state, all wave-uniform (SGPRs): the chunk starts c0s channels into tap (kh0, kw0)
+    int c0s = 0, kh0 = 0, kw0 = 0;
+    const int kq16 = 16 * kq;
+    const unsigned lim = ((unsigned)(a.Hin - 1) << 16) | (unsigned)(a.Win - 1);
+
     auto load_chunk = [&](int k0) {
-        // (kh, kw, c) of this thread's quad: k = k0 + 4*kq = (kh*KW + kw)*Cin + c
-        const unsigned k4 = (unsigned)(k0 + 4 * kq);
-        const unsigned tap = udiv(k4, a.div_c_m, a.div_c_s1, a.div_c_s2);
-        const int qc = (int)(k4 - tap * (unsigned)a.Cin);
-        const int qkh = (int)udiv(tap, a.div_kw_m, a.div_kw_s1, a.div_kw_s2);
-        const int qkw = (int)tap - qkh * a.KW;
-        const bool kok = (int)k4 < a.K;
-        const int dh = qkh * a.dil_h, dw = qkw * a.dil_w;
+        const bool kok = k0 + 4 * kq < a.K;
+        if constexpr (WALK) {
+            // VALU instructions take matrix-pipe time on this chip (~2.5 cycles each, tools/mfma_peak.hip), so the tap
+            // walk is scalar: lanes whose quad lies before the tap boundary of this chunk use (tap0, d0), the others
+            // (tap1, d1); per pixel that leaves one packed 16-bit add + max + compare for the bounds check and one add
+            // + select for the byte offset.
+            int kw1 = kw0 + 1, kh1 = kh0;
+            if (kw1 == a.KW) {
+                kw1 = 0;
+                kh1 = kh0 + 1;
+            }
+            const unsigned d0 = (unsigned)((kh0 * a.dil_h * a.Win + kw0 * a.dil_w) * a.Cin + c0s) * 4u;
+            const unsigned d1 = (unsigned)((kh1 * a.dil_h * a.Win + kw1 * a.dil_w) * a.Cin + c0s - a.Cin) * 4u;
+            const unsigned p0 = ((unsigned)(kh0 * a.dil_h) << 16) | (unsigned)(kw0 * a.dil_w);
+            const unsigned p1 = ((unsigned)(kh1 * a.dil_h) << 16) | (unsigned)(kw1 * a.dil_w);
+            const bool first = 4 * kq < a.Cin - c0s;
+            // k >= K (zero-padded tail of the last chunk): a tap offset that no pixel can satisfy
+            const unsigned dpk = kok ? (first ? p0 : p1) : 0x7fff7fffu;
+            const unsigned delta = (first ? d0 : d1) + (unsigned)kq16;
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const int hi = (phw[i] >> 16) + dh;
-            const int wi = (int)(short)(phw[i] & 0xffff) + dw;
-            const bool ok = kok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
-            // out-of-image taps / rows past M / k past K: an out-of-range byte offset, for which the buffer load
-            // returns zeros -- no branch, no select
-#ifdef PP_CONV_L1ONLY
-            const unsigned off = ok ? ((pbase[i] + (unsigned)((hi * a.Win + wi) * a.Cin + qc)) * 4u) & 0x3ff0u : 0xffffffffu;   // timing experiment: every load hits a 16 KB window
-#else
-            const unsigned off = ok ? (pbase[i] + (unsigned)((hi * a.Win + wi) * a.Cin + qc)) * 4u : 0xffffffffu;
-#endif
-            xr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+            for (int i = 0; i < NQ; ++i) {
+                // (hi, wi) as two u16 halves; in range iff max(hi, Hin-1) == Hin-1 and max(wi, Win-1) == Win-1
+                const u16x2 hw = __builtin_bit_cast(u16x2, __builtin_bit_cast(i16x2, phw[i]) + __builtin_bit_cast(i16x2, dpk));
+                const bool ok = __builtin_bit_cast(unsigned, __builtin_elementwise_max(hw, __builtin_bit_cast(u16x2, lim))) == lim;
+                const unsigned off = ok ? pbase[i] + delta : 0xffffffffu;
+                xr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+            }
+            c0s += BK;
+            if (c0s >= a.Cin) {
+                c0s -= a.Cin;
+                kh0 = kh1;
+                kw0 = kw1;
+            }
+        } else {
+            // (kh, kw, c) of this thread's quad: k = k0 + 4*kq = (kh*KW + kw)*Cin + c
+            const unsigned k4 = (unsigned)(k0 + 4 * kq);
+            const unsigned tap = udiv(k4, a.div_c_m, a.div_c_s1, a.div_c_s2);
+            const int qc = (int)(k4 - tap * (unsigned)a.Cin);
+            const int qkh = (int)udiv(tap, a.div_kw_m, a.div_kw_s1, a.div_kw_s2);
+            const int qkw = (int)tap - qkh * a.KW;
+            const int dh = qkh * a.dil_h, dw = qkw * a.dil_w;
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const int hi = (phw[i] >> 16) + dh;
+                const int wi = (int)(short)(phw[i] & 0xffff) + dw;
+                const bool ok = kok && (unsigned)hi < (unsigned)a.Hin && (unsigned)wi < (unsigned)a.Win;
+                // out-of-image taps / rows past M / k past K: an out-of-range byte offset, for which the buffer load
+                // returns zeros -- no branch, no select
+                const unsigned off = ok ? (pbase[i] + (unsigned)((hi * a.Win + wi) * a.Cin + qc)) * 4u : 0xffffffffu;
+                xr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+            }
         }
         const float* wsrc = wblob + (size_t)(k0 / BK) * a.CoutPad * BK;
         wr0 = *reinterpret_cast<const float4*>(wsrc + wofs0);
@@ -362,7 +406,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 template <int CT, int PT>
 int launch_t(const ConvArgs& a, hipStream_t stream) {
     dim3 grid((a.M + 64 * PT - 1) / (64 * PT), (a.CoutPad + 16 * CT - 1) / (16 * CT));
-    hipLaunchKernelGGL((conv_igemm_kernel<CT, PT>), grid, dim3(256), 0, stream, a);
+    if (a.Cin >= BK)
+        hipLaunchKernelGGL((conv_igemm_kernel<CT, PT, true>), grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<CT, PT, false>), grid, dim3(256), 0, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         pp_set_error("conv_igemm launch failed: %s", hipGetErrorString(e));
@@ -373,11 +420,7 @@ int launch_t(const ConvArgs& a, hipStream_t stream) {
 
 template <int CT>
 int launch_ct(const ConvArgs& a, int pt, hipStream_t stream) {
-    switch (pt) {
-        case 4: return launch_t<CT, 4>(a, stream);
-        case 2: return launch_t<CT, 2>(a, stream);
-        default: return launch_t<CT, 1>(a, stream);
-    }
+    return pt >= 2 ? launch_t<CT, 2>(a, stream) : launch_t<CT, 1>(a, stream);
 }
 
 // ---- max pool (NHWC, 4 channels per thread) ---------------------------------------------------
@@ -438,7 +481,7 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
         pp_set_error("conv: Cin=%d must be a multiple of 4 (pad the input channels)", a.Cin);
         return PP_ERR_ARG;
     }
-    if (a.Hin >= 32768 || a.Win >= 32768) {
+    if (a.Hin + a.pad_h >= 32768 || a.Win + a.pad_w >= 32768) {
         pp_set_error("conv: spatial dims must be < 32768");
         return PP_ERR_ARG;
     }
