@@ -17,6 +17,7 @@ template <int CT, int PT, int MODE, int THREADS = 256, int NV = 0>
 __global__ __launch_bounds__(THREADS) void mfma_loop(float* out, int iters) {
     __shared__ __attribute__((aligned(16))) float smem[(16 * CT + 64 * PT) * 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float scratch[8 * THREADS];
     for (int i = tid; i < (16 * CT + 64 * PT) * 32; i += THREADS) smem[i] = (float)(i & 7) * 0.125f;
     __syncthreads();
     f32x4 acc[CT][PT];
@@ -36,6 +37,15 @@ __global__ __launch_bounds__(THREADS) void mfma_loop(float* out, int iters) {
                 vx[v & 3] += vy[v & 3];
                 vy[v & 3] ^= vx[v & 3];
             }
+        }
+        if (MODE == 4) {   // NV extra ds_write_b32 per step (conflict-free, private slots): what does an LDS write cost?
+#pragma unroll
+            for (int v = 0; v < NV; ++v) scratch[(v & 7) * THREADS + tid] = (float)it;
+        }
+        if (MODE == 5) {   // NV/4 extra ds_write_b128
+#pragma unroll
+            for (int v = 0; v < NV / 4; ++v)
+                *reinterpret_cast<f32x4*>(scratch + ((v & 1) * THREADS + tid) * 4) = f32x4{(float)it, 0.f, 1.f, 2.f};
         }
         if (MODE == 2) {
             __syncthreads();
@@ -64,6 +74,7 @@ __global__ __launch_bounds__(THREADS) void mfma_loop(float* out, int iters) {
     float s = 0.f;
     for (int ct = 0; ct < CT; ++ct)
         for (int pt = 0; pt < PT; ++pt) s += acc[ct][pt][0] + acc[ct][pt][1] + acc[ct][pt][2] + acc[ct][pt][3];
+    if (MODE >= 4) s += scratch[(tid * 7) % (8 * THREADS)];
     if (MODE == 3) s += (float)(vx[0] ^ vx[1] ^ vx[2] ^ vx[3] ^ vy[0] ^ vy[1] ^ vy[2] ^ vy[3]);
     if (s == 12345.678f) out[0] = s;   // keep the loop alive
 }
@@ -110,6 +121,10 @@ int main() {
     run<3, 2, 3, 256, 64>("lds-read + 64 VALU", 4, d_out);
     run<3, 2, 3, 256, 128>("lds-read + 128 VALU", 4, d_out);
     run<3, 2, 3, 256, 256>("lds-read + 256 VALU", 4, d_out);
+    run<3, 2, 4, 256, 16>("lds-read + 16 ds_write_b32", 4, d_out);
+    run<3, 2, 4, 256, 32>("lds-read + 32 ds_write_b32", 4, d_out);
+    run<3, 2, 5, 256, 16>("lds-read + 4 ds_write_b128", 4, d_out);
+    run<3, 2, 5, 256, 32>("lds-read + 8 ds_write_b128", 4, d_out);
     run<1, 2, 2>("barriers CT1 PT2 256thr", 4, d_out);
     run<4, 2, 2>("barriers CT4 PT2 256thr", 4, d_out);
     // sustained: 40 back-to-back launches (~power/clock steady state)
