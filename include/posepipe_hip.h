@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 1
+#define PP_ABI_VERSION 2   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations */
 
 typedef enum {
     PP_OK = 0,
@@ -98,6 +98,12 @@ typedef enum {
 #define PP_RELU_NONE 0
 #define PP_RELU_LAST 1   /* y = relu(conv + bias + res...) */
 #define PP_RELU_FIRST 2  /* y = res + relu(conv + bias)   (VideoPose3D blocks) */
+/* activations of the DeepSortYOLOv4 path (wrappers/deep_sort_yolov4/yolo4/model.py:25-75, tools/freeze_model.py),
+ * applied like PP_RELU_FIRST: y = res + act(conv + bias).  Transcendentals are evaluated in double precision and
+ * rounded to float once per reference op (softplus, tanh, product for Mish). */
+#define PP_ACT_LEAKY 3   /* LeakyReLU(alpha = 0.1f) */
+#define PP_ACT_MISH 4    /* x * tanh(softplus(x)) */
+#define PP_ACT_ELU 5     /* x > 0 ? x : exp(x) - 1 */
 
 typedef struct pp_op {
     int32_t type;
@@ -110,6 +116,9 @@ typedef struct pp_op {
     int32_t out_nchw;         /* 1: write `out` as [n][cout][H][W] planes (heatmaps) */
     int32_t res1_shift;       /* read res1 at (h >> s, w >> s)  (FPN top-down add) */
     int32_t res1_off_w;       /* read res1 at w + off (VideoPose3D centre-cropped residual) */
+    int32_t out_c_off;        /* write channels [out_c_off, out_c_off + cout) of a wider `out` buffer (Concatenate) */
+    int32_t in_c_off;         /* max pool only: read channels [in_c_off, in_c_off + cin) of `in` */
+    int32_t pad_end;          /* bit 0 / 1: one extra zero row at the bottom / column at the right (TensorFlow SAME) */
     int64_t w_off, b_off;     /* float offsets into the weight blob: W (layout below), bias[cout_pad16] */
 } pp_op;
 

@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("POSEPIPE_LIB", os.path.join(_HERE, "libposepipe_hip.s
 PP_MEM_HOST, PP_MEM_DEVICE = 0, 1
 PP_OP_CONV, PP_OP_MAXPOOL, PP_OP_ROIALIGN, PP_OP_COPY = 1, 2, 3, 4
 PP_RELU_NONE, PP_RELU_LAST, PP_RELU_FIRST = 0, 1, 2
+PP_ACT_LEAKY, PP_ACT_MISH, PP_ACT_ELU = 3, 4, 5
 
 
 class PosePipeHipError(RuntimeError):
@@ -44,6 +45,9 @@ class pp_op(C.Structure):
         ("out_nchw", C.c_int32),
         ("res1_shift", C.c_int32),
         ("res1_off_w", C.c_int32),
+        ("out_c_off", C.c_int32),
+        ("in_c_off", C.c_int32),
+        ("pad_end", C.c_int32),
         ("w_off", C.c_int64),
         ("b_off", C.c_int64),
     ]

@@ -262,11 +262,18 @@ static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
     PP_REQUIRE(op.res1 < nb && op.res2 < nb, "op %d: residual buffer id out of range", idx);
     const pp_buf& bi = net.bufs[op.in];
     const pp_buf& bo = net.bufs[op.out];
+    const int eh = op.pad_end & 1, ew = (op.pad_end >> 1) & 1;   // TensorFlow SAME: the odd padding row / column goes last
+    PP_REQUIRE(op.out_c_off >= 0 && op.in_c_off >= 0 && (op.out_c_off & 3) == 0 && (op.in_c_off & 3) == 0,
+               "op %d: channel offsets must be non-negative multiples of 4", idx);
     if (op.type == PP_OP_CONV) {
-        PP_REQUIRE(bi.c == op.cin, "op %d: in buffer has %d channels, op.cin=%d", idx, bi.c, op.cin);
-        PP_REQUIRE(bo.c == op.cout, "op %d: out buffer has %d channels, op.cout=%d", idx, bo.c, op.cout);
-        const int ho = pp_conv_out_dim(bi.h, op.kh, op.stride, op.pad_h, op.dil_h);
-        const int wo = pp_conv_out_dim(bi.w, op.kw, op.stride, op.pad_w, op.dil_w);
+        PP_REQUIRE(bi.c == op.cin && op.in_c_off == 0, "op %d: in buffer has %d channels, op.cin=%d", idx, bi.c, op.cin);
+        PP_REQUIRE(op.out_c_off + op.cout <= bo.c && (op.out_c_off == 0 ? true : !op.out_nchw),
+                   "op %d: channels [%d, %d) do not fit the out buffer (%d channels)", idx, op.out_c_off,
+                   op.out_c_off + op.cout, bo.c);
+        PP_REQUIRE(bo.c == op.cout || ((bo.c & 3) == 0 && !op.out_nchw), "op %d: a sliced out buffer needs c %% 4 == 0", idx);
+        PP_REQUIRE(op.relu >= PP_RELU_NONE && op.relu <= PP_ACT_ELU, "op %d: unknown activation %d", idx, op.relu);
+        const int ho = pp_conv_out_dim(bi.h + eh, op.kh, op.stride, op.pad_h, op.dil_h);
+        const int wo = pp_conv_out_dim(bi.w + ew, op.kw, op.stride, op.pad_w, op.dil_w);
         PP_REQUIRE((ho << op.up_log2) == bo.h && (wo << op.up_log2) == bo.w,
                    "op %d: conv output %dx%d (<<%d) does not match out buffer %dx%d", idx, ho, wo, op.up_log2,
                    bo.h, bo.w);
@@ -280,9 +287,11 @@ static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
             PP_REQUIRE(net.bufs[op.res2].c == op.cout && net.bufs[op.res2].h == bo.h && net.bufs[op.res2].w == bo.w,
                        "op %d: res2 shape mismatch", idx);
     } else if (op.type == PP_OP_MAXPOOL) {
-        PP_REQUIRE(bi.c == bo.c, "op %d: maxpool channel mismatch", idx);
-        PP_REQUIRE(pp_conv_out_dim(bi.h, op.kh, op.stride, op.pad_h, 1) == bo.h &&
-                       pp_conv_out_dim(bi.w, op.kw, op.stride, op.pad_w, 1) == bo.w,
+        PP_REQUIRE(op.cin == op.cout && (op.cin & 3) == 0 && op.in_c_off + op.cin <= bi.c && op.out_c_off + op.cout <= bo.c &&
+                       (bi.c & 3) == 0 && (bo.c & 3) == 0,
+                   "op %d: maxpool channel slices do not fit", idx);
+        PP_REQUIRE(pp_conv_out_dim(bi.h + eh, op.kh, op.stride, op.pad_h, 1) == bo.h &&
+                       pp_conv_out_dim(bi.w + ew, op.kw, op.stride, op.pad_w, 1) == bo.w,
                    "op %d: maxpool output dims mismatch", idx);
     } else if (op.type == PP_OP_COPY) {
         PP_REQUIRE(bi.c == bo.c && bi.h == bo.h && bi.w == bo.w, "op %d: copy shape mismatch", idx);
@@ -315,11 +324,13 @@ static int net_launch_op(pp_net* net, const pp_op& op, int batch, hipStream_t s)
         a.res1_shift = op.res1_shift; a.res1_off_w = op.res1_off_w;
         a.res1_H = op.res1 >= 0 ? net->bufs[op.res1].h : 0;
         a.res1_W = op.res1 >= 0 ? net->bufs[op.res1].w : 0;
+        a.y_stride = bo.c; a.y_coff = op.out_c_off;
         return pp_launch_conv(a, s);
     } else if (op.type == PP_OP_MAXPOOL) {
         PoolArgs p{};
         p.x = net->buf_ptr(op.in); p.y = net->buf_ptr(op.out);
-        p.N = batch; p.Hin = bi.h; p.Win = bi.w; p.C = bi.c; p.Hout = bo.h; p.Wout = bo.w;
+        p.N = batch; p.Hin = bi.h; p.Win = bi.w; p.C = op.cin; p.Hout = bo.h; p.Wout = bo.w;
+        p.x_stride = bi.c; p.x_coff = op.in_c_off; p.y_stride = bo.c; p.y_coff = op.out_c_off;
         p.KH = op.kh; p.KW = op.kw; p.stride = op.stride; p.pad_h = op.pad_h; p.pad_w = op.pad_w;
         return pp_launch_maxpool(p, s);
     } else if (op.type == PP_OP_COPY) {
@@ -530,8 +541,8 @@ int pp_conv2d(pp_ctx* ctx, const pp_op* op, int n, int hin, int win, const float
     PP_REQUIRE(n > 0 && hin > 0 && win > 0, "pp_conv2d: empty input");
     ConvArgs a{};
     a.N = n; a.Hin = hin; a.Win = win; a.Cin = op->cin;
-    a.Hout = pp_conv_out_dim(hin, op->kh, op->stride, op->pad_h, op->dil_h);
-    a.Wout = pp_conv_out_dim(win, op->kw, op->stride, op->pad_w, op->dil_w);
+    a.Hout = pp_conv_out_dim(hin + (op->pad_end & 1), op->kh, op->stride, op->pad_h, op->dil_h);
+    a.Wout = pp_conv_out_dim(win + ((op->pad_end >> 1) & 1), op->kw, op->stride, op->pad_w, op->dil_w);
     PP_REQUIRE(a.Hout > 0 && a.Wout > 0, "pp_conv2d: empty output");
     a.Cout = op->cout; a.CoutPad = (op->cout + 15) / 16 * 16;
     a.KH = op->kh; a.KW = op->kw; a.stride = op->stride; a.pad_h = op->pad_h; a.pad_w = op->pad_w;
@@ -543,6 +554,8 @@ int pp_conv2d(pp_ctx* ctx, const pp_op* op, int n, int hin, int win, const float
     const int Ho2 = a.Hout << op->up_log2, Wo2 = a.Wout << op->up_log2;
     a.res1_H = res1 ? (res1_h > 0 ? res1_h : Ho2) : 0;
     a.res1_W = res1 ? (res1_w > 0 ? res1_w : Wo2) : 0;
+    a.y_stride = op->cout; a.y_coff = 0;
+    PP_REQUIRE(op->out_c_off == 0 && op->in_c_off == 0, "pp_conv2d: channel slices need a layer program");
     const size_t x_e = (size_t)n * hin * win * op->cin;
     const size_t w_e = (size_t)a.Kpad * a.CoutPad;
     const size_t b_e = a.CoutPad;

@@ -48,6 +48,20 @@ __device__ __forceinline__ unsigned udiv(unsigned n, unsigned m, unsigned s1, un
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
+// Activations of the DeepSortYOLOv4 path.  The reference evaluates them as separate float32 TensorFlow ops
+// (yolo4/model.py:48 `inputs * K.tanh(K.softplus(inputs))`, LeakyReLU(0.1), tf.nn.elu); here every transcendental op is
+// evaluated in double precision and rounded to float once, which is what oracle/yolo.py restates.
+__device__ __forceinline__ float activate(float x, int act) {
+    if (act == PP_ACT_LEAKY) return x >= 0.f ? x : 0.1f * x;
+    if (act == PP_ACT_MISH) {
+        const float sp = (float)log1p(exp((double)x));
+        const float th = (float)tanh((double)sp);
+        return x * th;
+    }
+    if (act == PP_ACT_ELU) return x > 0.f ? x : (float)expm1((double)x);
+    return x;
+}
+
 // WALK: Cin >= 32, so a 32-k chunk spans at most two kernel taps and the tap bookkeeping can live on the scalar unit
 // (see load_chunk).  The generic variant decodes every lane's tap with two magic divisions per chunk.
 template <int CT, int PT, bool WALK>
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int Ho2 = a.Hout << up, Wo2 = a.Wout << up;   // dims of the out buffer
     const bool vec4 = ((a.Cout & 3) == 0) && !a.out_nchw;
     const bool res1_plain = (a.res1_shift == 0 && a.res1_off_w == 0 && a.res1_H == Ho2 && a.res1_W == Wo2);
-    if (up == 0 && vec4 && (!a.res1 || res1_plain)) {
+    if (up == 0 && vec4 && (!a.res1 || res1_plain) && a.relu <= PP_RELU_FIRST && a.y_stride == a.Cout) {
         // common case (BasicBlock / Bottleneck / plain convs): the output pixel index IS m, no coordinate math.
         // All bias / residual loads are issued back to back from clamped (always valid) addresses before anything
         // consumes them: one memory round trip per phase instead of one per 16x16 tile.
@@ -346,6 +360,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             if (a.relu == PP_RELU_FIRST) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            } else if (a.relu >= PP_ACT_LEAKY) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = activate(v[r], a.relu);
             }
             for (int dy = 0; dy < f; ++dy) {
                 for (int dx = 0; dx < f; ++dx) {
@@ -390,9 +407,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                         for (int r = 0; r < 4; ++r)
                             if (co + r < a.Cout) yp[r * plane] = o[r];
                     } else if (vec4) {
-                        *reinterpret_cast<float4*>(a.y + opix * a.Cout + co) = make_float4(o[0], o[1], o[2], o[3]);
+                        *reinterpret_cast<float4*>(a.y + opix * a.y_stride + a.y_coff + co) = make_float4(o[0], o[1], o[2], o[3]);
                     } else {
-                        float* yp = a.y + opix * a.Cout + co;
+                        float* yp = a.y + opix * a.y_stride + a.y_coff + co;
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (co + r < a.Cout) yp[r] = o[r];
@@ -426,6 +443,7 @@ int launch_ct(const ConvArgs& a, int pt, hipStream_t stream) {
 // ---- max pool (NHWC, 4 channels per thread) ---------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool_kernel(PoolArgs a) {
     const int c4n = a.C >> 2;
+    const size_t xs = a.x_stride ? a.x_stride : a.C, ys = a.y_stride ? a.y_stride : a.C;   // channel slices of wider buffers
     const size_t total = (size_t)a.N * a.Hout * a.Wout * c4n;
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c4 = i % c4n;
@@ -442,11 +460,11 @@ __global__ __launch_bounds__(256) void maxpool_kernel(PoolArgs a) {
                 const int wi = wo * a.stride - a.pad_w + kw;
                 if ((unsigned)wi >= (unsigned)a.Win) continue;
                 const float4 v = *reinterpret_cast<const float4*>(
-                    a.x + (((size_t)n * a.Hin + hi) * a.Win + wi) * a.C + 4 * c4);
+                    a.x + (((size_t)n * a.Hin + hi) * a.Win + wi) * xs + a.x_coff + 4 * c4);
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
-        *reinterpret_cast<float4*>(a.y + (((size_t)n * a.Hout + ho) * a.Wout + wo) * a.C + 4 * c4) = m;
+        *reinterpret_cast<float4*>(a.y + (((size_t)n * a.Hout + ho) * a.Wout + wo) * ys + a.y_coff + 4 * c4) = m;
     }
 }
 
@@ -496,7 +514,7 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
     }
     if ((size_t)a.N * img_bytes > max_bytes) {
         const int per = (int)(max_bytes / img_bytes);
-        const size_t y_img = (size_t)(a.Hout << a.up_log2) * (a.Wout << a.up_log2) * a.Cout;
+        const size_t y_img = (size_t)(a.Hout << a.up_log2) * (a.Wout << a.up_log2) * (a.y_stride ? a.y_stride : a.Cout);
         const size_t r1_img = (size_t)a.res1_H * a.res1_W * a.Cout;
         for (int n0 = 0; n0 < a.N; n0 += per) {
             ConvArgs p = a_in;
@@ -512,6 +530,7 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
         return PP_OK;
     }
     a.x_bytes = (unsigned)((size_t)a.N * img_bytes);
+    if (a.y_stride == 0) a.y_stride = a.Cout;
     static const int force_ct = env_int("POSEPIPE_CONV_CT", 0), force_pt = env_int("POSEPIPE_CONV_PT", 0),
                      min_blocks = env_int("POSEPIPE_CONV_MIN_BLOCKS", 512);
     const int tiles = a.CoutPad / 16;

@@ -76,6 +76,7 @@ struct ConvArgs {
     unsigned x_bytes; // size of the input tensor of this launch (buffer-load range check)
     int relu, up_log2, out_nchw;
     int res1_shift, res1_off_w, res1_H, res1_W;
+    int y_stride, y_coff;   // channels per pixel of the out buffer, first channel written (0 / 0: y_stride = Cout)
 };
 int pp_conv_out_dim(int in, int k, int stride, int pad, int dil);
 int pp_launch_conv(const ConvArgs& a, hipStream_t stream);
@@ -84,6 +85,7 @@ struct PoolArgs {
     const float* x;
     float* y;
     int N, Hin, Win, C, Hout, Wout, KH, KW, stride, pad_h, pad_w;
+    int x_stride, x_coff, y_stride, y_coff;   // channel slices of wider buffers (0 stride: = C)
 };
 int pp_launch_maxpool(const PoolArgs& a, hipStream_t stream);
 

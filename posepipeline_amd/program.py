@@ -102,8 +102,11 @@ class ProgramBuilder:
 
     # ---- ops ---------------------------------------------------------------------------------
     def conv(self, x, weight, bias, *, stride=1, pad=(0, 0), dil=(1, 1), relu=L.PP_RELU_NONE, res1=-1, res2=-1,
-             up_log2=0, out=None, out_nchw=False, res1_shift=0, res1_off_w=0, name="conv") -> int:
-        """weight: torch layout, BN already folded.  Returns the (virtual) output buffer."""
+             up_log2=0, out=None, out_nchw=False, res1_shift=0, res1_off_w=0, out_c_off=0, pad_end=(0, 0),
+             name="conv") -> int:
+        """weight: torch layout, BN already folded.  Returns the (virtual) output buffer.
+        out / out_c_off: write channels [out_c_off, out_c_off + cout) of an existing wider buffer (Concatenate).
+        pad_end: (rows, cols) in {0, 1}: one extra zero row / column at the bottom / right (TensorFlow SAME)."""
         if isinstance(pad, int):
             pad = (pad, pad)
         if isinstance(dil, int):
@@ -115,29 +118,42 @@ class ProgramBuilder:
         cout, cin, kh, kw = wt.shape
         assert cin <= cin_buf and cin_buf % 4 == 0, (cin, cin_buf)
         W, b = pack_conv(wt, bias, cin_pad=cin_buf)
-        ho = (h + 2 * pad[0] - dil[0] * (kh - 1) - 1) // stride + 1
-        wo = (w + 2 * pad[1] - dil[1] * (kw - 1) - 1) // stride + 1
+        ho = (h + pad_end[0] + 2 * pad[0] - dil[0] * (kh - 1) - 1) // stride + 1
+        wo = (w + pad_end[1] + 2 * pad[1] - dil[1] * (kw - 1) - 1) // stride + 1
         if out is None:
+            assert out_c_off == 0
             out = self.buf(ho << up_log2, wo << up_log2, cout)
         else:
-            assert self.dims(out) == (ho << up_log2, wo << up_log2, cout), (self.dims(out), ho, wo, cout)
+            oh, ow, oc = self.dims(out)
+            assert (oh, ow) == (ho << up_log2, wo << up_log2) and out_c_off + cout <= oc and out_c_off % 4 == 0, \
+                (self.dims(out), ho, wo, cout, out_c_off)
         w_off = self._add_blob(W)
         b_off = self._add_blob(b)
         self.vops.append(dict(type=L.PP_OP_CONV, in_=x, out=out, res1=res1, res2=res2, cin=cin_buf, cout=cout, kh=kh,
                               kw=kw, stride=stride, pad_h=pad[0], pad_w=pad[1], dil_h=dil[0], dil_w=dil[1], relu=relu,
                               up_log2=up_log2, out_nchw=int(out_nchw), res1_shift=res1_shift, res1_off_w=res1_off_w,
+                              out_c_off=out_c_off, in_c_off=0, pad_end=pad_end[0] | (pad_end[1] << 1),
                               w_off=w_off, b_off=b_off, name=name,
                               flops=2.0 * ho * wo * cout * cin * kh * kw))
         return out
 
-    def maxpool(self, x, k, stride, pad, name="maxpool") -> int:
-        h, w, c = self.dims(x)
+    def maxpool(self, x, k, stride, pad, name="maxpool", out=None, out_c_off=0, in_c_off=0, c=None) -> int:
+        """c / in_c_off: pool channels [in_c_off, in_c_off + c) of x; out / out_c_off: into a slice of a wider buffer."""
+        h, w, cx = self.dims(x)
+        c = cx if c is None else c
+        assert in_c_off + c <= cx and c % 4 == 0 and in_c_off % 4 == 0
         ho = (h + 2 * pad - (k - 1) - 1) // stride + 1
         wo = (w + 2 * pad - (k - 1) - 1) // stride + 1
-        out = self.buf(ho, wo, c)
+        if out is None:
+            assert out_c_off == 0
+            out = self.buf(ho, wo, c)
+        else:
+            oh, ow, oc = self.dims(out)
+            assert (oh, ow) == (ho, wo) and out_c_off + c <= oc and out_c_off % 4 == 0
         self.vops.append(dict(type=L.PP_OP_MAXPOOL, in_=x, out=out, res1=-1, res2=-1, cin=c, cout=c, kh=k, kw=k,
                               stride=stride, pad_h=pad, pad_w=pad, dil_h=1, dil_w=1, relu=0, up_log2=0, out_nchw=0,
-                              res1_shift=0, res1_off_w=0, w_off=0, b_off=0, name=name, flops=0.0))
+                              res1_shift=0, res1_off_w=0, out_c_off=out_c_off, in_c_off=in_c_off, pad_end=0,
+                              w_off=0, b_off=0, name=name, flops=0.0))
         return out
 
     # ---- finalize ----------------------------------------------------------------------------
