@@ -36,9 +36,9 @@ def test_binding_table_matches_header():
 
 
 def test_struct_layout_matches_header():
-    # pp_op: 19 int32 + (padding to 8) + 2 int64
+    # pp_op (ABI v2): 22 int32 + 2 int64
     assert ctypes.sizeof(_lib.pp_op) == 104
-    assert _lib.pp_op.w_off.offset == 80 and _lib.pp_op.b_off.offset == 88
+    assert _lib.pp_op.w_off.offset == 88 and _lib.pp_op.b_off.offset == 96
     assert ctypes.sizeof(_lib.pp_buf) == 12
 
 
