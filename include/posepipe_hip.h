@@ -221,6 +221,9 @@ int pp_topdown_timing(pp_topdown* t, float* ms3);
  * convention 1 = in-tree deep_sort preprocessing.non_max_suppression
  * (wrappers/deep_sort_yolov4/deep_sort/preprocessing.py:5-70): boxes [n][4] (x, y, w, h) FLOAT64,
  * scores [n] FLOAT64, +1 areas, overlap = inter / area_other.
+ * convention 2 = tf.image.non_max_suppression as called by wrappers/deep_sort_yolov4/yolo4/model.py:278-281:
+ * boxes [n][4] (y1, x1, y2, x2) float32 with corners in any order, IoU = inter / (Sa + Sb - inter), 0 when an
+ * area is <= 0; the caller truncates to max_output_size.
  * keep[n] receives the surviving indices in descending score order, *n_keep their count; n <= 8192.
  */
 int pp_nms(pp_ctx* ctx, const void* boxes, const void* scores, int n, double iou_thr, int convention,
@@ -287,6 +290,31 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
 /* HIP-event stage times of the last run, ms6 = {preprocess, image program, RPN proposals + NMS, RoIAlign,
  * RoI-head program, final decode + NMS} */
 int pp_detector_timing(pp_detector* d, float* ms6);
+
+/* ---- DeepSortYOLOv4 pre / post-processing ------------------------------------------------------------
+ * tracking_method 0 (pipeline.py:519-523 -> wrappers/deep_sort_yolov4/parser.py:21): YOLOv4 detector + mars-small128
+ * appearance encoder + the in-tree DeepSORT tracker (pp_tracker mode 0).  The two networks are layer programs
+ * (posepipeline_amd/models/yolov4.py, mars.py); these entry points are the image and box arithmetic around them.
+ *
+ * pp_letterbox_bicubic: letterbox_image (yolo4/utils.py:21-32: PIL Image.resize BICUBIC = Pillow's 8-bit two-pass
+ *   resampler, then paste on a (128,128,128) canvas) + yolo.py:93-95 float32 / 255, with the BGR->RGB swap of
+ *   parser.py:55 folded in.  frames [n][src_h][src_w][3] u8 BGR; out: device [n][size_h][size_w][4] fp32 (R,G,B,0).
+ *   xtab [nw][2+kx] / ytab [nh][2+ky] int32 (host): per output index (first source index, tap count, coefficients
+ *   << 22) as Pillow's precompute_coeffs + normalize_coeffs_8bpc produce them (models/yolov4.py:pil_bicubic_table).
+ * pp_yolo_decode: yolo_head + yolo_correct_boxes + box_confidence * class probability of ONE class
+ *   (yolo4/model.py:193-254; yolo.py:112 keeps 'person' only).  feats: device [n][gh][gw][3*(5+num_classes)];
+ *   boxes [n][gh*gw*3][4] (y1, x1, y2, x2 in image pixels), scores [n][gh*gw*3], host or device per out_mem.
+ * pp_reid_patches: the cv2.resize(INTER_LINEAR) of extract_image_patch (tools/generate_detections.py:61-62) + the
+ *   encoder graph's uint8->float cast and channel reversal (tools/freeze_model.py:239-255).  rects: host [n][5]
+ *   int32 (frame, sx, sy, ex, ey) from the clipped box (:44-60, host side); out: device [n][ph][pw][4] fp32. */
+int pp_letterbox_bicubic(pp_ctx* ctx, const uint8_t* frames, int n, int src_h, int src_w, int frames_mem,
+                         const int32_t* xtab, int nw, int kx, const int32_t* ytab, int nh, int ky, int size_h,
+                         int size_w, float* out_device);
+int pp_yolo_decode(pp_ctx* ctx, const float* feats, int n, int gh, int gw, int num_classes, int cls,
+                   const float* anchors3x2, int input_h, int input_w, int image_h, int image_w, float* boxes,
+                   float* scores, int out_mem);
+int pp_reid_patches(pp_ctx* ctx, const uint8_t* frames, int n_frames, int src_h, int src_w, int frames_mem,
+                    const int32_t* rects, int n, int ph, int pw, float* out_device);
 
 /* ---- 3D lifting -----------------------------------------------------------------------------
  * Replaces VideoPose3D TemporalModelOptimized1f + ChunkedGenerator windows reached from

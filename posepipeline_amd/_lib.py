@@ -103,6 +103,9 @@ SIGNATURES = {
     "pp_detector_timing": (_i, [_vp, _vp]),
     "pp_nms": (_i, [_vp, _vp, _vp, _i, C.c_double, _i, _vp, C.POINTER(C.c_int32), _i]),
     "pp_videopose3d_lift": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "pp_letterbox_bicubic": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp]),
+    "pp_yolo_decode": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i]),
+    "pp_reid_patches": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "pp_tracker_create": (_i, [_i, _i, C.c_double, C.c_double, _i, _i, C.POINTER(_vp)]),
     "pp_tracker_destroy": (None, [_vp]),
     "pp_tracker_step": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, C.POINTER(C.c_int32)]),

@@ -9,6 +9,10 @@
 // convention 1 -- the in-tree greedy NMS, wrappers/deep_sort_yolov4/deep_sort/preprocessing.py:5-70:
 //   float64 (x, y, w, h) boxes, +1-pixel areas (:47), overlap = intersection / area of the OTHER box (:66),
 //   suppress overlap > thr, survivors in descending score order.
+// convention 2 -- tf.image.non_max_suppression as called by wrappers/deep_sort_yolov4/yolo4/model.py:278-281:
+//   float32 (y1, x1, y2, x2) with corners in any order, IoU = inter / (Sa + Sb - inter) (0 when an area is <= 0),
+//   suppress IoU > thr, survivors in descending score order (ties: lower index first); the caller truncates to
+//   max_output_size.
 #include "pp_internal.h"
 #include "det_internal.h"
 
@@ -66,6 +70,15 @@ __device__ __forceinline__ bool suppresses(const T* a, const T* b, T thr) {
         const T inter = w * h;
         // mmcv devIoU: interS > threshold * (Sa + Sb - interS), no division (-ffp-contract=off: no fma)
         return inter > thr * ((area_a + area_b) - inter);
+    } else if (CONV == 2) {
+        const T ay1 = min(a[0], a[2]), ay2 = max(a[0], a[2]), ax1 = min(a[1], a[3]), ax2 = max(a[1], a[3]);
+        const T by1 = min(b[0], b[2]), by2 = max(b[0], b[2]), bx1 = min(b[1], b[3]), bx2 = max(b[1], b[3]);
+        const T area_a = (ay2 - ay1) * (ax2 - ax1), area_b = (by2 - by1) * (bx2 - bx1);
+        if (area_a <= (T)0 || area_b <= (T)0) return false;
+        const T h = max(min(ay2, by2) - max(ay1, by1), (T)0);
+        const T w = max(min(ax2, bx2) - max(ax1, bx1), (T)0);
+        const T inter = h * w;
+        return inter / ((area_a + area_b) - inter) > thr;
     } else {
         const T ax2 = a[2] + a[0], ay2 = a[3] + a[1], bx2 = b[2] + b[0], by2 = b[3] + b[1];
         const T area_b = (bx2 - b[0] + 1) * (by2 - b[1] + 1);
@@ -211,7 +224,8 @@ int pp_enqueue_nms_batched(hipStream_t s, const float* boxes, const float* score
 extern "C" int pp_nms(pp_ctx* ctx, const void* boxes, const void* scores, int n, double iou_thr, int convention,
                       int32_t* keep, int32_t* n_keep, int mem) {
     PP_REQUIRE(ctx && n_keep && (n == 0 || (boxes && scores && keep)), "pp_nms: NULL argument");
-    PP_REQUIRE(convention == 0 || convention == 1, "pp_nms: convention must be 0 (mmcv, float32 xyxy) or 1 (deep_sort, float64 tlwh)");
+    PP_REQUIRE(convention >= 0 && convention <= 2,
+               "pp_nms: convention must be 0 (mmcv, float32 xyxy), 1 (deep_sort, float64 tlwh) or 2 (TensorFlow, float32 yxyx)");
     PP_REQUIRE(n >= 0 && n <= MAX_N, "pp_nms: n=%d not in [0,%d]", n, MAX_N);
     hipStream_t s = ctx->stream;
     if (n == 0) {
@@ -219,7 +233,7 @@ extern "C" int pp_nms(pp_ctx* ctx, const void* boxes, const void* scores, int n,
         else PP_HIP_CHECK(hipMemsetAsync(n_keep, 0, sizeof(int32_t), s));
         return PP_OK;
     }
-    const size_t esz = convention == 0 ? 4 : 8;
+    const size_t esz = convention == 1 ? 8 : 4;
     size_t need = scratch_bytes(n, 1) + ScratchCursor::align(4);
     if (mem == PP_MEM_HOST) need += ScratchCursor::align((size_t)n * 4 * esz) + ScratchCursor::align((size_t)n * esz) + 2 * ScratchCursor::align((size_t)n * 4 + 256);
     int rc = ctx->ensure_scratch(need);
@@ -246,6 +260,8 @@ extern "C" int pp_nms(pp_ctx* ctx, const void* boxes, const void* scores, int n,
     }
     if (convention == 0)
         rc = run_nms<float, 0>(s, (const float*)d_boxes, (const float*)d_scores, d_n, n, 1, (float)iou_thr, d_order, d_mask, d_keep, d_nkeep);
+    else if (convention == 2)
+        rc = run_nms<float, 2>(s, (const float*)d_boxes, (const float*)d_scores, d_n, n, 1, (float)iou_thr, d_order, d_mask, d_keep, d_nkeep);
     else
         rc = run_nms<double, 1>(s, (const double*)d_boxes, (const double*)d_scores, d_n, n, 1, iou_thr, d_order, d_mask, d_keep, d_nkeep);
     if (rc != PP_OK) return rc;

@@ -63,8 +63,9 @@ def flip_merge_decode(ctx: L.Context, hm: np.ndarray, hm_flip, center_scale, fli
 
 
 def nms(ctx: L.Context, boxes, scores, thr, convention=0):
-    """convention 0: float32 x1y1x2y2 (mmcv); 1: float64 tlwh (deep_sort).  Returns kept indices (int64)."""
-    dt = np.float32 if convention == 0 else np.float64
+    """convention 0: float32 x1y1x2y2 (mmcv); 1: float64 tlwh (deep_sort); 2: float32 y1x1y2x2 (TensorFlow).
+    Returns kept indices (int64)."""
+    dt = np.float64 if convention == 1 else np.float32
     boxes = np.ascontiguousarray(boxes, dt).reshape(-1, 4)
     scores = np.ascontiguousarray(scores, dt).reshape(-1)
     n = boxes.shape[0]

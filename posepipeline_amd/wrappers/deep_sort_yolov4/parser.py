@@ -1,0 +1,90 @@
+"""Drop-in for pose_pipeline/wrappers/deep_sort_yolov4/parser.py:21-136 `tracking_bounding_boxes`
+(tracking_method 0 `DeepSortYOLOv4`, pipeline.py:519-523; the default of every recipe in utils/standard_pipelines.py).
+
+Same signature and return structure: one list per decoded frame with one dict per LIVE track (tentative and missed
+ones included, parser.py:76-86):
+    {"track_id": int, "tlhw": ndarray(4,) [x, y, w, h], "tlbr": ndarray(4,), "time_since_update": int}
+The reference runs, per frame: YOLOv4 (`yolo.detect_image`, persons only) -> mars-small128 features of the boxes ->
+`preprocessing.non_max_suppression(nms_max_overlap=1.0)` -> DeepSORT (max_cosine_distance 0.3, no budget).  Here frames are
+read in batches; letterbox, the two networks and the box decode run on the GPU, NMS through pp_nms, the strictly
+sequential association in C++ (pp_tracker mode 0, fixture-pinned against the reference's own deep_sort package).
+`outfile` (annotated video writer, parser.py:29-31,88-129) is not supported.
+Checkpoints: yolo4.h5 (Keras/HDF5) and mars-small128.pb (TensorFlow GraphDef) cannot be parsed in this environment;
+POSEPIPE_SYNTHETIC_WEIGHTS=1 runs seeded weights of the same architectures.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from ... import _lib, ops, weights
+from ...models import mars, yolov4
+from ...tracking import Tracker
+from ...video import open_video
+
+BATCH = 4
+_cache: dict = {}
+
+
+def _params(relpath, shapes, seed, **kw):
+    path = os.path.join(weights.model_data_dir(), relpath)
+    if os.environ.get("POSEPIPE_SYNTHETIC_WEIGHTS") == "1":
+        return yolov4.synth_params(shapes, seed, **kw)
+    if os.path.exists(path):
+        raise NotImplementedError(f"{path}: no Keras-HDF5 / TensorFlow-GraphDef reader in this environment "
+                                  "(set POSEPIPE_SYNTHETIC_WEIGHTS=1 for seeded weights)")
+    raise FileNotFoundError(f"{path} (set POSEPIPE_SYNTHETIC_WEIGHTS=1 to run with seeded synthetic weights)")
+
+
+def _models(src_h, src_w, device=0):
+    key = (src_h, src_w, device)
+    if key not in _cache:
+        ysd = yolov4.seed_person_head(_params("deep_sort_yolov4/yolo4.h5", yolov4.yolov4_param_shapes(), seed=4))
+        msd = _params("deep_sort_yolov4/mars-small128.pb", mars.mars_param_shapes(), seed=5)
+        ctx = _lib.Context(device)
+        _cache[key] = (ctx, yolov4.YoloV4Detector(ctx, ysd, src_h, src_w, max_frames=BATCH),
+                       mars.MarsEncoder(ctx, msd, src_h, src_w))
+    return _cache[key]
+
+
+def tracking_bounding_boxes(file_path, outfile=None):
+    if outfile is not None:
+        raise NotImplementedError("annotated video output (parser.py:29-31) is not part of the hot path")
+    cap = open_video(file_path)
+    video_length = int(cap.num_frames)
+    ctx, yolo, encoder = _models(cap.height, cap.width)
+
+    # Definition of the parameters (parser.py:35-47)
+    max_cosine_distance = 0.3
+    nms_max_overlap = 1.0
+    tracker = Tracker(mode=0, feat_dim=128, max_cosine_distance=max_cosine_distance)
+
+    tracks = []
+    done = 0
+    while done < video_length:
+        frames = cap.read_batch(min(BATCH, video_length - done))
+        if frames.shape[0] == 0:
+            break                                                    # read failure ends the loop (:52-53)
+        frames = np.ascontiguousarray(frames)
+        dets = yolo.run(frames)                                      # per frame: boxes [m][4] int, confidences [m]
+        feats = encoder.encode(frames, [b for b, _ in dets])
+        for (boxes, conf), feat in zip(dets, feats):
+            tlwh = boxes.astype(np.float64)                          # Detection.tlwh (detection.py:29)
+            scores = conf.astype(np.float64)
+            keep = ops.nms(ctx, tlwh, scores, nms_max_overlap, convention=1) if len(tlwh) else np.zeros(0, np.int64)
+            ids, t_tlwh, info = tracker.step(tlwh[keep], scores[keep], feat[keep])
+            tracks.append(
+                [
+                    {
+                        "track_id": int(i),
+                        "tlhw": b.copy(),
+                        "tlbr": np.concatenate([b[:2], b[:2] + b[2:]]),
+                        "time_since_update": int(s[3]),
+                    }
+                    for i, b, s in zip(ids, t_tlwh, info)
+                ]
+            )
+        done += frames.shape[0]
+    cap.release()
+    return tracks
