@@ -123,7 +123,10 @@ class TrackingBbox(dj.Computed):  # pipeline.py:508-513
     def make(self, key):  # pipeline.py:515-578
         video = Video.get_robust_reader(key, return_cap=False)
         name = (TrackingBboxMethodLookup & key).fetch1("tracking_method_name")
-        if name in "MMTrack_tracktor":     # sic: substring test, pipeline.py:525
+        if name == "DeepSortYOLOv4":       # pipeline.py:519-523
+            from .wrappers.deep_sort_yolov4.parser import tracking_bounding_boxes
+            tracks = tracking_bounding_boxes(video)
+        elif name in "MMTrack_tracktor":   # sic: substring test, pipeline.py:525
             from .wrappers.mmtrack import mmtrack_bounding_boxes
             tracks = mmtrack_bounding_boxes(video, "tracktor")
         elif name == "MMTrack_deepsort":

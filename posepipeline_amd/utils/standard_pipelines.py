@@ -2,8 +2,8 @@
 (pose_pipeline/utils/standard_pipelines.py:10-164 `tracking_pipeline`, `top_down_pipeline`,
 `lifting_pipeline`; pose_pipeline/utils/tracking.py:5-21 `annotate_single_person`).
 
-Differences kept deliberately small: the default tracking method is the one built here
-("MMTrack_deepsort" instead of the TensorFlow "DeepSortYOLOv4"), the default lifter is "VideoPose3D"
+Differences kept deliberately small: the default tracking method stays "MMTrack_deepsort" (the reference's default
+"DeepSortYOLOv4" is built too -- pass tracking_method_name="DeepSortYOLOv4"), the default lifter is "VideoPose3D"
 (instead of "GastNet"), the reference's "MMpose" default for the 2D method -- a name that is not in its own
 lookup table -- is "MMPose", and `BestDetectedFrames` / OpenPose branches (out of scope) are not called.
 """

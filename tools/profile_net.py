@@ -20,6 +20,12 @@ def main():
         from posepipeline_amd.models import faster_rcnn as fr
         sd = synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2)
         prog = fr.build_image_program(sd, 640, 1088) if which == "det" else fr.build_roi_program(sd)
+    elif which in ("yolo", "mars"):
+        from posepipeline_amd.models import mars, yolov4
+        if which == "yolo":
+            prog = yolov4.build_yolov4_program(yolov4.synth_params(yolov4.yolov4_param_shapes(), seed=4))
+        else:
+            prog = mars.build_mars_program(yolov4.synth_params(mars.mars_param_shapes(), seed=5))
     else:
         spec = hrnet.hrnet_w32_256x192() if which == "w32" else hrnet.hrnet_w48_384x288()
         sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(spec), seed=1)
