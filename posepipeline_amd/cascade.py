@@ -23,13 +23,24 @@ from .wrappers.videopose3d import lift, normalize_screen_coordinates
 
 
 class Cascade:
-    def __init__(self, ctx: L.Context, det_sd: dict, pose_sd: dict, lift_sd: dict, src_h: int, src_w: int,
-                 chunk: int = 8, max_persons: int = 1, pose_spec=None, post="unbiased", blur_kernel=17):
+    """tracking: "MMTrack_deepsort" (Faster-RCNN R50-FPN + SORT, det_sd = detector weights) or "DeepSortYOLOv4"
+    (tracking_method 0, the reference recipes' default: det_sd = (yolov4 weights, mars-small128 weights))."""
+
+    def __init__(self, ctx: L.Context, det_sd, pose_sd: dict, lift_sd: dict, src_h: int, src_w: int,
+                 chunk: int = 8, max_persons: int = 1, pose_spec=None, post="unbiased", blur_kernel=17,
+                 tracking: str = "MMTrack_deepsort"):
         self.ctx = ctx
         self.src = (src_h, src_w)
         self.chunk = chunk
         self.max_persons = max_persons
-        self.detector = fr.Detector(ctx, det_sd, src_h, src_w, max_frames=chunk)
+        self.tracking = tracking
+        if tracking == "DeepSortYOLOv4":
+            from .models import mars, yolov4
+            self.detector = yolov4.YoloV4Detector(ctx, det_sd[0], src_h, src_w, max_frames=chunk)
+            self.encoder = mars.MarsEncoder(ctx, det_sd[1], src_h, src_w, max_patches=max(64, chunk * max_persons))
+        else:
+            assert tracking == "MMTrack_deepsort", tracking
+            self.detector = fr.Detector(ctx, det_sd, src_h, src_w, max_frames=chunk)
         self.pose_spec = pose_spec or hrnet.hrnet_w48_384x288()
         self.pose_net = Net(ctx, hrnet.build_hrnet_program(self.pose_spec, pose_sd), max_batch=2 * chunk * max_persons)
         self.topdown = ops.TopDown(self.pose_net, 17, flip_perm=hrnet.flip_perm(17), post=post, blur_kernel=blur_kernel)
@@ -38,7 +49,10 @@ class Cascade:
         self.reset()
 
     def reset(self):
-        self.tracker = Tracker(mode=1, match_iou_thr=0.5, obj_score_thr=0.5)
+        if self.tracking == "DeepSortYOLOv4":
+            self.tracker = Tracker(mode=0, feat_dim=128, max_cosine_distance=0.3)       # parser.py:35-47
+        else:
+            self.tracker = Tracker(mode=1, match_iou_thr=0.5, obj_score_thr=0.5)
         self.tracks = []          # per frame: list of (track_id, x1, y1, x2, y2, score)
         self.kp2d = {}            # track_id -> list of (frame, (17,3))
 
@@ -55,13 +69,26 @@ class Cascade:
         Returns dict(tracks=per-frame rows, keypoints={track_id: (B,17,3)}, keypoints_3d={track_id: (B,17,3)})."""
         b = frames_dev[1] if frames_dev is not None else frames.shape[0]
         dets = self.detector.run(frames, frames_dev=frames_dev)
-        if replay is not None:
-            dets = replay
         chunk_tracks = []
-        for rows in dets:
-            rows = np.asarray(rows, np.float32).reshape(-1, 5)
-            ids, _, info = self.tracker.step(rows[:, :4].astype(np.float64), rows[:, 4].astype(np.float64))
-            chunk_tracks.append([(int(i), *rows[j]) for i, j in zip(ids, info[:, 1])])
+        if self.tracking == "DeepSortYOLOv4":
+            # wrappers/deep_sort_yolov4/parser.py:52-86 per frame: persons -> appearance features -> NMS(1.0) -> DeepSORT;
+            # every live track is reported (tentative and missed ones with their Kalman box), like the reference's tables
+            if replay is not None:      # [n][5] x1 y1 x2 y2 score -> the int (x, y, w, h) boxes yolo.detect_image returns
+                dets = [(np.array([[int(r[0]), int(r[1]), int(r[2] - r[0]), int(r[3] - r[1])] for r in rows], np.int64).reshape(-1, 4),
+                         np.asarray(rows, np.float32).reshape(-1, 5)[:, 4]) for rows in replay]
+            feats = self.encoder.encode(frames, [bx for bx, _ in dets], frames_dev=frames_dev)
+            for (boxes, conf), feat in zip(dets, feats):
+                tlwh, sc = boxes.astype(np.float64), conf.astype(np.float64)
+                keep = ops.nms(self.ctx, tlwh, sc, 1.0, convention=1) if len(tlwh) else np.zeros(0, np.int64)
+                ids, t, _ = self.tracker.step(tlwh[keep], sc[keep], feat[keep])
+                chunk_tracks.append([(int(i), bb[0], bb[1], bb[0] + bb[2], bb[1] + bb[3], 1.0) for i, bb in zip(ids, t)])
+        else:
+            if replay is not None:
+                dets = replay
+            for rows in dets:
+                rows = np.asarray(rows, np.float32).reshape(-1, 5)
+                ids, _, info = self.tracker.step(rows[:, :4].astype(np.float64), rows[:, 4].astype(np.float64))
+                chunk_tracks.append([(int(i), *rows[j]) for i, j in zip(ids, info[:, 1])])
         f0 = len(self.tracks)
         self.tracks += chunk_tracks
         # person-frames for the 2D stage: every tracked box of the chunk (up to max_persons per frame)

@@ -336,7 +336,9 @@ class YoloV4Detector:
 
     def run(self, frames, frames_dev=None):
         n = self.preprocess(frames, frames_dev)
+        self.ctx.timer_start()
         self.net.run(n)
+        self.last_net_ms = self.ctx.timer_stop()       # HIP events around the program (bench stage times)
         return self.decode(n)
 
     def close(self):

@@ -108,3 +108,34 @@ def test_streamed_video_equals_host_chunks(ctx, tmp_path):
     first = next(gen)
     gen.close()
     assert first["tracks"] == ref_first["tracks"]
+
+
+def test_cascade_with_default_tracking_method(ctx):
+    """tracking="DeepSortYOLOv4" (tracking_method 0): YOLOv4 + mars-small128 + DeepSORT feed the same 2D / 3D stages;
+    the 2D stage crops the tracker's (Kalman) boxes, like PersonBbox does with the reference's track dicts."""
+    from posepipeline_amd.cascade import Cascade
+    from posepipeline_amd.models import mars, yolov4
+    rng = np.random.default_rng(11)
+    h, w = 135, 240
+    frames = np.stack([synth_frame(rng, h, w) for _ in range(4)])
+    ysd = yolov4.synth_params(yolov4.yolov4_param_shapes(), seed=4, head_bias=-2.0)
+    msd = yolov4.synth_params(mars.mars_param_shapes(), seed=5)
+    pose_spec = hrnet.HRNetSpec(32, 17, 128, 96)
+    pose_sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(pose_spec), seed=1)
+    lift_sd = synth.synth_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3)
+    cas = Cascade(ctx, (ysd, msd), pose_sd, lift_sd, h, w, chunk=2, max_persons=1, pose_spec=pose_spec,
+                  tracking="DeepSortYOLOv4")
+    gt = [np.array([[60 + 4 * t, 20, 130 + 4 * t, 120, 0.9]], np.float32) for t in range(4)]
+    out = [cas.step(frames[0:2], replay=gt[0:2]), cas.step(frames[2:4], replay=gt[2:4])]
+    tracks = [t for o in out for t in o["tracks"]]
+    assert [len(t) for t in tracks] == [1, 1, 1, 1] and len({t[0][0] for t in tracks}) == 1     # one identity (id 1)
+    assert tracks[0][0][0] == 1                                                                 # deep_sort ids start at 1
+    tid = tracks[0][0][0]
+    k2 = np.concatenate([o["keypoints"][tid] for o in out])
+    boxes = np.array([[t[0][1], t[0][2], t[0][3] - t[0][1], t[0][4] - t[0][2]] for t in tracks], np.float64)
+    # first frame: the Kalman mean is initialised from the detection, so the track box is the (int-truncated) input box
+    assert np.allclose(boxes[0], [60, 20, 70, 100])
+    ref2 = oracle_topdown(pose_sd, 32, frames, boxes, (96, 128), "unbiased", 17)
+    for i in range(4):
+        assert np.abs(k2[i][:, :2] - ref2[i][:, :2]).max() <= 1e-3
+    assert out[1]["keypoints_3d"][tid].shape == (2, 17, 3)
