@@ -100,7 +100,7 @@ typedef enum {
 #define PP_RELU_FIRST 2  /* y = res + relu(conv + bias)   (VideoPose3D blocks) */
 /* activations of the DeepSortYOLOv4 path (wrappers/deep_sort_yolov4/yolo4/model.py:25-75, tools/freeze_model.py),
  * applied like PP_RELU_FIRST: y = res + act(conv + bias).  Transcendentals are evaluated in double precision and
- * rounded to float once per reference op (softplus, tanh, product for Mish). */
+ * rounded to float once (Mish: tanh(softplus(x)) in double, rounded, then a float product with x). */
 #define PP_ACT_LEAKY 3   /* LeakyReLU(alpha = 0.1f) */
 #define PP_ACT_MISH 4    /* x * tanh(softplus(x)) */
 #define PP_ACT_ELU 5     /* x > 0 ? x : exp(x) - 1 */

@@ -116,9 +116,13 @@ def leaky(x):
 
 
 def mish(x):
-    sp = np.log1p(np.exp(x.astype(np.float64))).astype(F32)          # K.softplus
-    th = np.tanh(sp.astype(np.float64)).astype(F32)                  # K.tanh
-    return (x * th).astype(F32)                                      # inputs * ...
+    """inputs * K.tanh(K.softplus(inputs)) (yolo4/model.py:48).  tanh(softplus(x)) is evaluated in float64 through the
+    identity tanh(log(1 + e^x)) = n(n + 2) / (n(n + 2) + 2), n = e^x, and rounded to float32 once; the product is a
+    float32 multiply."""
+    n = np.exp(np.minimum(x, F32(20)).astype(np.float64))
+    t = n * (n + 2.0)
+    th = np.where(x > F32(20), 1.0, t / (t + 2.0)).astype(F32)
+    return (x * th).astype(F32)
 
 
 def sigmoid(x):

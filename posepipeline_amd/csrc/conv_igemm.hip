@@ -54,8 +54,12 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float activate(float x, int act) {
     if (act == PP_ACT_LEAKY) return x >= 0.f ? x : 0.1f * x;
     if (act == PP_ACT_MISH) {
-        const float sp = (float)log1p(exp((double)x));
-        const float th = (float)tanh((double)sp);
+        // tanh(log(1 + e^x)) = n(n + 2) / (n(n + 2) + 2) with n = e^x: one exp and one division in fp64, rounded to float
+        // once; 1.0f beyond x = 20 (the true value is 1 - 2e-18) keeps n*n finite
+        if (x > 20.f) return x;
+        const double n = exp((double)x);
+        const double t = n * (n + 2.0);
+        const float th = (float)(t / (t + 2.0));
         return x * th;
     }
     if (act == PP_ACT_ELU) return x > 0.f ? x : (float)expm1((double)x);
