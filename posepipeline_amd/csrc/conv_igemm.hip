@@ -99,9 +99,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     const int c0 = tile_y * BC;
 
     // ---- loader role: k-quad kq of pixel rows prow0 + 32*i, weight float4s tid + 256*j ------------------
-    // Everything between the two barriers of a K step is straight-line code (clamped addresses + selects instead
-    // of branches), so the scheduler is free to slot the address arithmetic of the next chunk's loads into the
-    // issue gaps of this chunk's MFMAs.
+    // Everything after the second barrier of a K step is ONE basic block (out-of-range buffer offsets and clamped
+    // weight rows instead of branches), so loads, address arithmetic and MFMAs can be ordered freely (see the loop).
     const int kq = tid & 7;
     const int prow0 = tid >> 3;
     const int wsw = swz(prow0 & 15);     // rows prow0 + 32*i share (row & 15)
@@ -511,7 +510,8 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
     // The pixel loader addresses the input through one raw buffer descriptor (32-bit byte offsets, out-of-range
     // offsets read as zero), so one launch covers < 4 GiB of input: larger batches are cut into image ranges.
     const size_t img_bytes = (size_t)a.Hin * a.Win * a.Cin * sizeof(float);
-    const size_t max_bytes = 0xfffffff0u;
+    static const size_t max_bytes_env = (size_t)env_int("POSEPIPE_CONV_MAX_MB", 0) << 20;   // test knob for the split below
+    const size_t max_bytes = max_bytes_env ? max_bytes_env : 0xfffffff0u;
     if (img_bytes > max_bytes) {
         pp_set_error("conv: one input image of %zu bytes exceeds the 4 GiB buffer range", img_bytes);
         return PP_ERR_ARG;
@@ -520,6 +520,7 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
         const int per = (int)(max_bytes / img_bytes);
         const size_t y_img = (size_t)(a.Hout << a.up_log2) * (a.Wout << a.up_log2) * (a.y_stride ? a.y_stride : a.Cout);
         const size_t r1_img = (size_t)a.res1_H * a.res1_W * a.Cout;
+        const size_t r2_img = (size_t)(a.Hout << a.up_log2) * (a.Wout << a.up_log2) * a.Cout;
         for (int n0 = 0; n0 < a.N; n0 += per) {
             ConvArgs p = a_in;
             p.N = std::min(per, a.N - n0);
@@ -527,7 +528,7 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
             p.x = a.x + (size_t)n0 * (img_bytes / sizeof(float));
             p.y = a.y + (size_t)n0 * y_img;
             if (a.res1) p.res1 = a.res1 + (size_t)n0 * r1_img;
-            if (a.res2) p.res2 = a.res2 + (size_t)n0 * y_img;
+            if (a.res2) p.res2 = a.res2 + (size_t)n0 * r2_img;
             const int rc = pp_launch_conv(p, stream);
             if (rc != PP_OK) return rc;
         }

@@ -99,3 +99,37 @@ def test_error_strings_and_bad_programs(ctx):
     y = np.zeros((1, 4, 4, 8), np.float32)
     rc = lib.pp_conv2d(ctx.handle, C.byref(bad), 1, 4, 4, L.ptr(x), L.ptr(blob), L.ptr(blob), None, None, L.ptr(y), 0, 0, 0)
     assert rc == -1 and "multiple of 4" in L.last_error()
+
+
+def test_conv_batch_split_for_large_inputs(tmp_path):
+    """Inputs of more than 4 GiB are cut into image ranges (one raw buffer descriptor per launch).  The threshold is
+    lowered to 1 MiB in a subprocess (POSEPIPE_CONV_MAX_MB) so that a 7-image batch takes the split path, with shifted
+    FPN-style residual, second residual and upsample epilogues; results must equal the oracle."""
+    import os
+    import subprocess
+    import sys
+    script = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from posepipeline_amd import _lib
+from tests.helpers import hip_conv_op, ref_conv_op
+ctx = _lib.Context(0)
+rng = np.random.default_rng(21)
+x = rng.standard_normal((7, 48, 40, 32)).astype(np.float32)          # 245 KB per image -> 4 images per launch
+w = (rng.standard_normal((24, 32, 3, 3)) * 0.1).astype(np.float32)
+b = rng.standard_normal(24).astype(np.float32)
+cases = [dict(pad=(1, 1), relu=1, res1=rng.standard_normal((7, 48, 40, 24)).astype(np.float32),
+              res2=rng.standard_normal((7, 48, 40, 24)).astype(np.float32)),
+         dict(pad=(1, 1), up_log2=1, res1=rng.standard_normal((7, 96, 80, 24)).astype(np.float32)),
+         dict(pad=(1, 1), res1=rng.standard_normal((7, 24, 20, 24)).astype(np.float32), res1_shift=1),
+         dict(pad=(1, 1), stride=2, out_nchw=True)]
+for kw in cases:
+    got = hip_conv_op(ctx, x, w, b, **kw)
+    ref = ref_conv_op(x, w, b, **kw)
+    assert np.array_equal(got, ref), kw.keys()
+print("SPLIT_OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, POSEPIPE_CONV_MAX_MB="1")
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+    assert "SPLIT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
