@@ -219,7 +219,7 @@ def run_cascade(args, D):
                                 "note": "same step, one stream (pp_net_set_lanes 0): comparable with rocprofv3 --stats AverageNs "
                                         "of profiles/*_serial_kernel_stats.csv"}},
     }
-    if D.rank == 0:
+    if D.world == 1:
         # PCIe-inclusive leg (reported beside `value`, never as it): the same chunks streamed from host memory through
         # page-locked staging buffers and the copy stream (posepipeline_amd/streaming.py), upload overlapped with compute
         from posepipeline_amd.video import ArrayVideo
@@ -240,7 +240,7 @@ def run_cascade(args, D):
                                          "staging buffers by a reader thread and uploaded on a copy stream while the previous "
                                          "chunk computes (posepipeline_amd/streaming.py)" % n_seen}
     n_cpu = 1 if args.cpu_frames is None else args.cpu_frames
-    if n_cpu > 0:
+    if n_cpu > 0 and D.world == 1:          # the CPU baseline is a rank-0, N=1 leg
         out["cpu_baseline"] = cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames[0], gt[0][0], cas, ctx)
     print(json.dumps(out), flush=True)
 
@@ -332,7 +332,7 @@ def run_c2(args, D):
                      "stage_ms": {"pre": t_pre / args.steps, "backbone": net_ms, "decode": t_dec / args.steps}},
     }
     n_cpu = 6 if args.cpu_frames is None else args.cpu_frames
-    if n_cpu > 0:
+    if n_cpu > 0 and D.world == 1:
         out["cpu_baseline"] = cpu_baseline_c2(sd, x[:n_cpu], cs[:n_cpu], kp[:n_cpu])
     print(json.dumps(out), flush=True)
 
