@@ -77,3 +77,111 @@ def test_oracle_yolo_decode_and_nms_known_answers():
     s = np.array([0.9, 0.8, 0.7, 0.9], np.float32)
     assert list(oyolo.tf_nms(b, s, 200, 0.5)) == [0, 2]       # tie 0/3 -> lower index; 1 overlaps 0 (IoU .82)
     assert list(oyolo.tf_nms(b, s, 1, 0.5)) == [0]
+
+
+# ---- independent torch-CPU statements of the two networks (unfolded BatchNorm, torch's own ops and summation order) -----
+def _torch_yolov4(sd, x_nhwc):
+    """yolo4/model.py:78-190 written against torch ops only (NCHW, F.mish / F.leaky_relu / torch.cat / F.interpolate)."""
+    import torch
+    import torch.nn.functional as F
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    idx = [0]
+
+    def conv(x, stride=1, act="mish"):
+        i = idx[0]
+        idx[0] += 1
+        w = t[f"l{i}.weight"]
+        k = w.shape[2]
+        if stride == 2:                    # ZeroPadding2D(((1, 0), (1, 0))) + 'valid'
+            y = F.conv2d(F.pad(x, (1, 0, 1, 0)), w, t.get(f"l{i}.bias"), 2, 0)
+        else:
+            y = F.conv2d(x, w, t.get(f"l{i}.bias"), 1, k // 2)
+        if f"l{i}.bn.gamma" in t:
+            y = F.batch_norm(y, t[f"l{i}.bn.mean"], t[f"l{i}.bn.var"], t[f"l{i}.bn.gamma"], t[f"l{i}.bn.beta"], False, 0.1, 1e-3)
+        return {"mish": F.mish, "leaky": lambda v: F.leaky_relu(v, 0.1), None: lambda v: v}[act](y)
+
+    def resblock(x, blocks):
+        pre = conv(x, 2)
+        short = conv(pre)
+        main = conv(pre)
+        for _ in range(blocks):
+            main = main + conv(conv(main))
+        return conv(torch.cat([conv(main), short], 1))
+
+    def five(x):
+        for _ in range(5):
+            x = conv(x, act="leaky")
+        return x
+
+    x = torch.from_numpy(np.ascontiguousarray(np.transpose(x_nhwc, (0, 3, 1, 2))))
+    x = conv(x)
+    x = resblock(x, 1)
+    x = resblock(x, 2)
+    f76 = x = resblock(x, 8)
+    f38 = x = resblock(x, 8)
+    x = resblock(x, 4)
+    y19 = conv(conv(conv(x, act="leaky"), act="leaky"), act="leaky")
+    y19 = torch.cat([F.max_pool2d(y19, k, 1, k // 2) for k in (13, 9, 5)] + [y19], 1)
+    y19 = conv(conv(conv(y19, act="leaky"), act="leaky"), act="leaky")
+    up = F.interpolate(conv(y19, act="leaky"), scale_factor=2, mode="nearest")
+    y38 = five(torch.cat([conv(f38, act="leaky"), up], 1))
+    up = F.interpolate(conv(y38, act="leaky"), scale_factor=2, mode="nearest")
+    y76 = five(torch.cat([conv(f76, act="leaky"), up], 1))
+    o76 = conv(conv(y76, act="leaky"), act=None)
+    y38 = five(torch.cat([conv(y76, 2, act="leaky"), y38], 1))
+    o38 = conv(conv(y38, act="leaky"), act=None)
+    y19 = five(torch.cat([conv(y38, 2, act="leaky"), y19], 1))
+    o19 = conv(conv(y19, act="leaky"), act=None)
+    return [np.transpose(o.numpy(), (0, 2, 3, 1)) for o in (o19, o38, o76)]
+
+
+def test_yolov4_oracle_vs_torch():
+    nc = 2
+    sd = yolov4.synth_params(yolov4.yolov4_param_shapes(nc), seed=8)
+    x = np.random.default_rng(8).uniform(0, 1, (1, 64, 64, 3)).astype(np.float32)
+    ref = _torch_yolov4(sd, x)
+    got = oyolo.YOLOv4Ref(sd, nc).forward(x)
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape
+        np.testing.assert_allclose(g, r, rtol=2e-3, atol=2e-4)
+
+
+def test_mars_oracle_vs_torch():
+    """tools/freeze_model.py:119-229 against torch ops (NCHW, explicit TensorFlow-SAME padding, F.elu, unfolded BN)."""
+    import torch
+    import torch.nn.functional as F
+    sd = yolov4.synth_params(mars.mars_param_shapes(), seed=9)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+
+    def bn(x, p):
+        return F.batch_norm(x, t[p + ".mean"], t[p + ".var"], None, t[p + ".beta"], False, 0.1, 1e-3)
+
+    def same(x, k, s):
+        pads = []
+        for n in (x.shape[3], x.shape[2]):          # F.pad order: W first
+            tot = max((-(-n // s) - 1) * s + k - n, 0)
+            pads += [tot // 2, tot - tot // 2]
+        return F.pad(x, pads)
+
+    def conv(x, name, stride=1, norm=True, act=True):
+        w = t[name + ".weight"]
+        y = F.conv2d(same(x, w.shape[2], stride), w, t.get(name + ".bias"), stride, 0)
+        if norm:
+            y = bn(y, name + ".bn")
+        return F.elu(y) if act else y
+
+    rng = np.random.default_rng(9)
+    patches = rng.integers(0, 256, (2, 128, 64, 3), dtype=np.uint8)
+    x = torch.from_numpy(np.ascontiguousarray(np.transpose(patches[..., ::-1].astype(np.float32), (0, 3, 1, 2))))
+    x = conv(conv(x, "conv1_1"), "conv1_2")
+    x = F.max_pool2d(x, 3, 2, 0)
+    for scope, c, inc, first in mars.BLOCKS:
+        net = x if first else F.elu(bn(x, scope + ".bn"))
+        y = conv(conv(net, scope + ".1", 2 if inc else 1), scope + ".2", norm=False, act=False)
+        x = (conv(x, scope + ".projection", 2, norm=False, act=False) if inc else x) + y
+    flat = x.permute(0, 2, 3, 1).reshape(x.shape[0], -1)            # slim.flatten of an NHWC tensor
+    f = F.elu(F.batch_norm(flat @ t["fc1.weight"].T, t["fc1.bn.mean"], t["fc1.bn.var"], None, t["fc1.bn.beta"], False, 0.1, 1e-3))
+    f = F.batch_norm(f, t["ball.mean"], t["ball.var"], None, t["ball.beta"], False, 0.1, 1e-3)
+    ref = (f / torch.sqrt(1e-8 + (f * f).sum(1, keepdim=True))).numpy()
+    got = oreid.MarsSmall128Ref(sd).forward(patches)
+    np.testing.assert_allclose(got, ref, rtol=2e-3, atol=2e-5)
