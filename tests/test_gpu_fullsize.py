@@ -54,3 +54,48 @@ def test_hrnet_w48_384x288_full_size(ctx):
     hm = net.forward(x).reshape(2, 17, 96, 72)
     ref = onets.HRNetRef(sd, 48).forward(np.transpose(x[:, :, :, :3], (0, 3, 1, 2)))
     assert np.array_equal(hm, ref)
+
+
+@pytest.mark.parametrize("n", [40, 66])
+def test_conv_input_beyond_2_gib(ctx, n):
+    """n = 40: a 2.7 GB input tensor (byte offsets past 2^31 in the raw buffer loads); n = 66: 4.4 GB, i.e. past the 4 GiB
+    range of one buffer descriptor, so the launcher really cuts the batch.  All images but the last share one pattern;
+    the first, an image 2.35 GB in, and the last image of the output must equal the oracle on those images alone."""
+    import ctypes as C
+    from oracle import clib
+    from posepipeline_amd import _lib as L
+    from posepipeline_amd.program import pack_conv
+    h, w, cin, cout = 256, 256, 256, 32
+    rng = np.random.default_rng(77)
+    img_a = rng.standard_normal((1, h, w, cin)).astype(np.float32)
+    img_z = rng.standard_normal((1, h, w, cin)).astype(np.float32)
+    weight = (rng.standard_normal((cout, cin, 3, 3)) * 0.02).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    W, b = pack_conv(weight, bias, cin_pad=cin)
+    img_bytes = img_a.nbytes
+    assert n * img_bytes > 2 ** 31
+    dx = ctx.malloc(n * img_bytes)
+    for i in range(n - 1):
+        ctx.h2d(dx + i * img_bytes, img_a)
+    ctx.h2d(dx + (n - 1) * img_bytes, img_z)
+    out_img = h * w * cout * 4
+    dy = ctx.malloc(n * out_img)
+    dw, db = ctx.malloc(W.nbytes), ctx.malloc(b.nbytes)
+    ctx.h2d(dw, W)
+    ctx.h2d(db, b)
+    op = L.pp_op(type=L.PP_OP_CONV, in_=0, out=0, res1=-1, res2=-1, cin=cin, cout=cout, kh=3, kw=3, stride=1, pad_h=1, pad_w=1,
+                 dil_h=1, dil_w=1, relu=L.PP_RELU_LAST, up_log2=0, out_nchw=0, res1_shift=0, res1_off_w=0, w_off=0, b_off=0)
+    L.check(ctx.lib.pp_conv2d(ctx.handle, C.byref(op), n, h, w, L.ptr(dx), L.ptr(dw), L.ptr(db), None, None, L.ptr(dy), 0, 0,
+                              L.PP_MEM_DEVICE), "pp_conv2d")
+    ctx.synchronize()
+    first = np.empty((1, h, w, cout), np.float32)
+    mid = np.empty((1, h, w, cout), np.float32)
+    last = np.empty((1, h, w, cout), np.float32)
+    ctx.d2h(first, dy)
+    ctx.d2h(mid, dy + 35 * out_img)                # starts 2.35 GB into the input
+    ctx.d2h(last, dy + (n - 1) * out_img)
+    ref_a = np.maximum(clib.conv2d_nhwc(img_a, weight, bias, stride=1, pad=(1, 1)), 0)
+    ref_z = np.maximum(clib.conv2d_nhwc(img_z, weight, bias, stride=1, pad=(1, 1)), 0)
+    assert np.array_equal(first, ref_a) and np.array_equal(mid, ref_a) and np.array_equal(last, ref_z)
+    for p in (dx, dy, dw, db):
+        ctx.free(p)
