@@ -23,7 +23,7 @@ from ...models import mars, yolov4
 from ...tracking import Tracker
 from ...video import open_video
 
-BATCH = 4
+BATCH = 16
 _cache: dict = {}
 
 
@@ -60,15 +60,17 @@ def tracking_bounding_boxes(file_path, outfile=None):
     nms_max_overlap = 1.0
     tracker = Tracker(mode=0, feat_dim=128, max_cosine_distance=max_cosine_distance)
 
+    from ...streaming import FrameStreamer
     tracks = []
-    done = 0
-    while done < video_length:
-        frames = cap.read_batch(min(BATCH, video_length - done))
-        if frames.shape[0] == 0:
-            break                                                    # read failure ends the loop (:52-53)
-        frames = np.ascontiguousarray(frames)
-        dets = yolo.run(frames)                                      # per frame: boxes [m][4] int, confidences [m]
-        feats = encoder.encode(frames, [b for b, _ in dets])
+    if video_length <= 0:
+        cap.release()
+        return tracks
+    # the clip is read once and streamed to the device BATCH frames at a time; a read failure ends the stream (:52-53)
+    streamer = FrameStreamer(ctx, cap, min(BATCH, video_length), max_frames=video_length)
+    for dev_ptr, n, _first in streamer:
+        dets = yolo.run(None, frames_dev=(dev_ptr, n))               # per frame: boxes [m][4] int, confidences [m]
+        feats = encoder.encode(None, [b for b, _ in dets], frames_dev=(dev_ptr, n))
+        streamer.release()
         for (boxes, conf), feat in zip(dets, feats):
             tlwh = boxes.astype(np.float64)                          # Detection.tlwh (detection.py:29)
             scores = conf.astype(np.float64)
@@ -85,6 +87,6 @@ def tracking_bounding_boxes(file_path, outfile=None):
                     for i, b, s in zip(ids, t_tlwh, info)
                 ]
             )
-        done += frames.shape[0]
+    streamer.close()
     cap.release()
     return tracks

@@ -50,7 +50,7 @@ _METHODS = {
                        17, hrnet.COCO_FLIP_PAIRS, "default", 11),
 }
 
-BATCH = 64
+BATCH = 32
 _cache: dict = {}
 
 
@@ -72,22 +72,29 @@ def _model(method, device=0):
 
 
 def top_down_batches(td, num_keypoints, cap, bboxes, batch=BATCH):
-    """Shared frame loop: read `batch` frames, run the fused stage, keep the reference's row contract."""
+    """Shared frame loop: the clip is read once and streamed to the device `batch` frames at a time (page-locked
+    staging + copy stream, streaming.FrameStreamer) while the previous batch runs the fused stage; rows keep the
+    reference's contract."""
+    from ..streaming import FrameStreamer
     results = []
     n = len(bboxes)
-    i = 0
-    while i < n:
-        frames = cap.read_batch(min(batch, n - i))
-        # should match the length of identified person tracks (wrappers/mmpose.py:63-64)
-        assert frames.shape[0] == min(batch, n - i), "video ended before the bbox track did"
-        bb = np.asarray(bboxes[i:i + frames.shape[0]], dtype=np.float64)
-        kp, valid = td.run(np.ascontiguousarray(frames), np.arange(frames.shape[0], dtype=np.int32), bb)
-        for j in range(frames.shape[0]):
-            if np.any(np.isnan(bb[j])):
-                results.append(np.zeros((num_keypoints, 3)))      # person not tracked in this frame (:67-69)
-            else:
-                results.append(kp[j])
-        i += frames.shape[0]
+    if n == 0:
+        return results
+    streamer = FrameStreamer(td.ctx, cap, min(batch, n), max_frames=n)
+    try:
+        for dev_ptr, m, first in streamer:
+            bb = np.asarray(bboxes[first:first + m], dtype=np.float64)
+            kp, valid = td.run(dev_ptr, np.arange(m, dtype=np.int32), bb, frames_dev_shape=(m, streamer.h, streamer.w))
+            streamer.release()
+            for j in range(m):
+                if np.any(np.isnan(bb[j])):
+                    results.append(np.zeros((num_keypoints, 3)))      # person not tracked in this frame (:67-69)
+                else:
+                    results.append(kp[j])
+    finally:
+        streamer.close()
+    # should match the length of identified person tracks (wrappers/mmpose.py:63-64)
+    assert len(results) == n, "video ended before the bbox track did"
     return results
 
 

@@ -20,7 +20,7 @@ from ..models import faster_rcnn as fr
 from ..tracking import Tracker
 from ..video import open_video
 
-BATCH = 4
+BATCH = 16
 _KNOWN = ("tracktor", "deepsort", "bytetrack", "qdtrack")
 _cache: dict = {}
 
@@ -41,18 +41,22 @@ def mmtrack_bounding_boxes(file_path, method="tracktor"):
     if method != "deepsort":
         raise NotImplementedError(f"MMTrack method {method!r}: only the Faster-RCNN + SORT family is built (see module docstring)")
 
+    from ..streaming import FrameStreamer
     cap = open_video(file_path)
     video_length = int(cap.num_frames)
-    _, det = _detector(cap.height, cap.width)
+    ctx, det = _detector(cap.height, cap.width)
     tracker = Tracker(mode=1, match_iou_thr=0.5, obj_score_thr=0.5)
 
     tracks = []
-    done = 0
-    while done < video_length:
-        frames = cap.read_batch(min(BATCH, video_length - done))
-        if frames.shape[0] == 0:
-            break                                                   # read failure ends the loop (:41-42)
-        per_frame = det.run(np.ascontiguousarray(frames))           # [n][5] float32: x1 y1 x2 y2 score
+    if video_length <= 0:
+        cap.release()
+        return tracks
+    # the clip is read once and streamed to the device BATCH frames at a time (the reference: one cap.read() and one
+    # blocking upload per frame, :38-45); a read failure simply ends the stream (:41-42)
+    streamer = FrameStreamer(ctx, cap, min(BATCH, video_length), max_frames=video_length)
+    for dev_ptr, n, _first in streamer:
+        per_frame = det.run(None, frames_dev=(dev_ptr, n))          # [n][5] float32: x1 y1 x2 y2 score
+        streamer.release()
         for rows in per_frame:
             ids, _, info = tracker.step(rows[:, :4].astype(np.float64), rows[:, 4].astype(np.float64))
             track_results = [np.concatenate([[np.float32(i)], rows[j]]).astype(np.float32) for i, j in zip(ids, info[:, 1])]
@@ -67,6 +71,6 @@ def mmtrack_bounding_boxes(file_path, method="tracktor"):
                     for x in track_results
                 ]
             )
-        done += frames.shape[0]
+    streamer.close()
     cap.release()
     return tracks
