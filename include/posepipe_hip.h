@@ -104,6 +104,7 @@ typedef enum {
 #define PP_ACT_LEAKY 3   /* LeakyReLU(alpha = 0.1f) */
 #define PP_ACT_MISH 4    /* x * tanh(softplus(x)) */
 #define PP_ACT_ELU 5     /* x > 0 ? x : exp(x) - 1 */
+#define PP_ACT_SWISH 6   /* x * sigmoid(x)  (mmcv Swish: YOLOX of the ByteTrack config, _base_/models/yolox_x_8x8.py) */
 
 typedef struct pp_op {
     int32_t type;
@@ -279,6 +280,14 @@ int pp_linear_sum_assignment(const double* cost, int n_rows, int n_cols, int32_t
 typedef struct pp_detector pp_detector;
 /* mmcv rescale_size for img_scale (1088,1088) + Pad(size_divisor=32): resized and padded input dims */
 int pp_detector_input_size(int src_h, int src_w, int32_t* nh, int32_t* nw, int32_t* hp, int32_t* wp);
+/* The same mmcv test pipeline on its own (Resize keep_ratio -> Normalize -> Pad(size_divisor, pad_val)), used by the
+ * YOLOX detector of the ByteTrack config (mot/bytetrack/*.py: img_scale (800, 1440), mean 0 / std 1, pad 114):
+ * pp_rescale_size = mmcv.rescale_size + the padded dims; pp_resize_pad_normalize writes device [n][hp][wp][4] fp32
+ * (lut[c][v] applied to channel c of the BGR frame, 4th channel 0, padding = pad_val). */
+int pp_rescale_size(int src_h, int src_w, int max_long, int max_short, int divisor, int32_t* nh, int32_t* nw,
+                    int32_t* hp, int32_t* wp);
+int pp_resize_pad_normalize(pp_ctx* ctx, const uint8_t* frames, int n, int src_h, int src_w, int frames_mem, int nh,
+                            int nw, int hp, int wp, const float* lut, float pad_val, float* out_device);
 int pp_detector_create(pp_net* net_a, pp_net* net_b, const int32_t* bufs_a, const int32_t* bufs_b, int src_h,
                        int src_w, const float* lut, const float* base_anchors, pp_detector** out);
 void pp_detector_destroy(pp_detector* d);

@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("POSEPIPE_LIB", os.path.join(_HERE, "libposepipe_hip.s
 PP_MEM_HOST, PP_MEM_DEVICE = 0, 1
 PP_OP_CONV, PP_OP_MAXPOOL, PP_OP_ROIALIGN, PP_OP_COPY = 1, 2, 3, 4
 PP_RELU_NONE, PP_RELU_LAST, PP_RELU_FIRST = 0, 1, 2
-PP_ACT_LEAKY, PP_ACT_MISH, PP_ACT_ELU = 3, 4, 5
+PP_ACT_LEAKY, PP_ACT_MISH, PP_ACT_ELU, PP_ACT_SWISH = 3, 4, 5, 6
 
 
 class PosePipeHipError(RuntimeError):
@@ -97,6 +97,8 @@ SIGNATURES = {
     "pp_topdown_run_precropped": (_i, [_vp, _vp, _i, _vp, _i, _vp, _i]),
     "pp_topdown_timing": (_i, [_vp, _vp]),
     "pp_detector_input_size": (_i, [_i, _i] + [C.POINTER(C.c_int32)] * 4),
+    "pp_rescale_size": (_i, [_i, _i, _i, _i, _i] + [C.POINTER(C.c_int32)] * 4),
+    "pp_resize_pad_normalize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp]),
     "pp_detector_create": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(_vp)]),
     "pp_detector_destroy": (None, [_vp]),
     "pp_detector_run": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),

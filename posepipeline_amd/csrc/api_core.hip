@@ -271,7 +271,7 @@ static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
                    "op %d: channels [%d, %d) do not fit the out buffer (%d channels)", idx, op.out_c_off,
                    op.out_c_off + op.cout, bo.c);
         PP_REQUIRE(bo.c == op.cout || ((bo.c & 3) == 0 && !op.out_nchw), "op %d: a sliced out buffer needs c %% 4 == 0", idx);
-        PP_REQUIRE(op.relu >= PP_RELU_NONE && op.relu <= PP_ACT_ELU, "op %d: unknown activation %d", idx, op.relu);
+        PP_REQUIRE(op.relu >= PP_RELU_NONE && op.relu <= PP_ACT_SWISH, "op %d: unknown activation %d", idx, op.relu);
         const int ho = pp_conv_out_dim(bi.h + eh, op.kh, op.stride, op.pad_h, op.dil_h);
         const int wo = pp_conv_out_dim(bi.w + ew, op.kw, op.stride, op.pad_w, op.dil_w);
         PP_REQUIRE((ho << op.up_log2) == bo.h && (wo << op.up_log2) == bo.w,

@@ -63,6 +63,10 @@ __device__ __forceinline__ float activate(float x, int act) {
         return x * th;
     }
     if (act == PP_ACT_ELU) return x > 0.f ? x : (float)expm1((double)x);
+    if (act == PP_ACT_SWISH) {   // mmcv Swish: x * torch.sigmoid(x) -- sigmoid in fp64 rounded once, then a float product
+        const float s = (float)(1.0 / (1.0 + exp(-(double)x)));
+        return x * s;
+    }
     return x;
 }
 

@@ -62,7 +62,7 @@ __device__ __forceinline__ void delta2bbox(const float roi[4], const float d_in[
 __global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __restrict__ frames, int H, int W, int nh,
                                                              int nw, int Hp, int Wp, const int32_t* __restrict__ xtab,
                                                              const int32_t* __restrict__ ytab, const float* __restrict__ lut,
-                                                             float* __restrict__ out) {
+                                                             float pad_val, float* __restrict__ out) {
     // xtab: [nw][3] = (sx, a0, a1);  ytab: [nh][3] = (sy, b0, b1)   (cv::resize 8-bit linear tables, *2048)
     __shared__ float s_lut[768];
     for (int i = threadIdx.x; i < 768; i += blockDim.x) s_lut[i] = lut[i];
@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __re
     const int total = Hp * Wp;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) {
         const int y = p / Wp, x = p - y * Wp;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = make_float4(pad_val, pad_val, pad_val, 0.f);       // mmdet Pad(pad_val): 0 for Faster-RCNN, 114 for YOLOX
         if (y < nh && x < nw) {
             const int sx = xtab[3 * x], a0 = xtab[3 * x + 1], a1 = xtab[3 * x + 2];
             const int sy = ytab[3 * y], b0 = ytab[3 * y + 1], b1 = ytab[3 * y + 2];
@@ -487,9 +487,9 @@ __global__ __launch_bounds__(1024) void final_decode_kernel(const float* __restr
 
 // ---- launchers ------------------------------------------------------------------------------------------------------
 int det_enqueue_preprocess(hipStream_t s, const uint8_t* frames, int n_frames, int H, int W, int nh, int nw, int Hp,
-                           int Wp, const int32_t* xtab, const int32_t* ytab, const float* lut, float* out) {
+                           int Wp, const int32_t* xtab, const int32_t* ytab, const float* lut, float pad_val, float* out) {
     dim3 grid(std::min((Hp * Wp + 255) / 256, 512), n_frames);
-    hipLaunchKernelGGL(det_preprocess_kernel, grid, dim3(256), 0, s, frames, H, W, nh, nw, Hp, Wp, xtab, ytab, lut, out);
+    hipLaunchKernelGGL(det_preprocess_kernel, grid, dim3(256), 0, s, frames, H, W, nh, nw, Hp, Wp, xtab, ytab, lut, pad_val, out);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }

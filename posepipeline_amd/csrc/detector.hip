@@ -76,6 +76,50 @@ int pp_detector_input_size(int src_h, int src_w, int32_t* nh, int32_t* nw, int32
     return PP_OK;
 }
 
+int pp_rescale_size(int src_h, int src_w, int max_long, int max_short, int divisor, int32_t* nh, int32_t* nw, int32_t* hp,
+                    int32_t* wp) {
+    PP_REQUIRE(src_h > 0 && src_w > 0 && max_long > 0 && max_short > 0 && divisor > 0 && nh && nw && hp && wp,
+               "pp_rescale_size: bad argument");
+    int a, b;
+    rescale_size(src_w, src_h, max_long, max_short, &a, &b);
+    *nw = a; *nh = b;
+    *wp = (a + divisor - 1) / divisor * divisor;
+    *hp = (b + divisor - 1) / divisor * divisor;
+    return PP_OK;
+}
+
+int pp_resize_pad_normalize(pp_ctx* ctx, const uint8_t* frames, int n, int src_h, int src_w, int frames_mem, int nh, int nw,
+                            int hp, int wp, const float* lut, float pad_val, float* out_device) {
+    PP_REQUIRE(ctx && frames && lut && out_device, "pp_resize_pad_normalize: NULL argument");
+    PP_REQUIRE(n > 0 && src_h > 0 && src_w > 0 && nh > 0 && nw > 0 && hp >= nh && wp >= nw, "pp_resize_pad_normalize: bad dims");
+    std::vector<int32_t> xt, yt;
+    resize_table(src_w, nw, xt);
+    resize_table(src_h, nh, yt);
+    const size_t frame_bytes = (size_t)n * src_h * src_w * 3;
+    size_t need = ScratchCursor::align(xt.size() * 4) + ScratchCursor::align(yt.size() * 4) + ScratchCursor::align(768 * 4);
+    if (frames_mem == PP_MEM_HOST) need += ScratchCursor::align(frame_bytes);
+    int rc = ctx->ensure_scratch(need);
+    if (rc != PP_OK) return rc;
+    ScratchCursor cur(ctx);
+    int32_t* d_xt = cur.take<int32_t>(xt.size());
+    int32_t* d_yt = cur.take<int32_t>(yt.size());
+    float* d_lut = cur.take<float>(768);
+    hipStream_t s = ctx->stream;
+    const uint8_t* df = frames;
+    if (frames_mem == PP_MEM_HOST) {
+        uint8_t* st = cur.take<uint8_t>(frame_bytes);
+        PP_HIP_CHECK(hipMemcpyAsync(st, frames, frame_bytes, hipMemcpyHostToDevice, s));
+        df = st;
+    }
+    PP_HIP_CHECK(hipMemcpyAsync(d_xt, xt.data(), xt.size() * 4, hipMemcpyHostToDevice, s));
+    PP_HIP_CHECK(hipMemcpyAsync(d_yt, yt.data(), yt.size() * 4, hipMemcpyHostToDevice, s));
+    PP_HIP_CHECK(hipMemcpyAsync(d_lut, lut, 768 * 4, hipMemcpyHostToDevice, s));
+    rc = det_enqueue_preprocess(s, df, n, src_h, src_w, nh, nw, hp, wp, d_xt, d_yt, d_lut, pad_val, out_device);
+    if (rc != PP_OK) return rc;
+    PP_HIP_CHECK(hipStreamSynchronize(s));    // the host tables must outlive the copies
+    return PP_OK;
+}
+
 int pp_detector_create(pp_net* netA, pp_net* netB, const int32_t* bufs_a, const int32_t* bufs_b, int src_h, int src_w,
                        const float* lut, const float* base_anchors, pp_detector** out) {
     PP_REQUIRE(netA && netB && bufs_a && bufs_b && lut && base_anchors && out, "pp_detector_create: NULL argument");
@@ -195,7 +239,7 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
             PP_HIP_CHECK(hipMemcpyAsync(d->d_frames, frames, bytes, hipMemcpyHostToDevice, s));
             df = d->d_frames;
         }
-        rc = det_enqueue_preprocess(s, df, F, d->H, d->W, d->nh, d->nw, d->Hp, d->Wp, d->d_xtab, d->d_ytab, d->d_lut,
+        rc = det_enqueue_preprocess(s, df, F, d->H, d->W, d->nh, d->nw, d->Hp, d->Wp, d->d_xtab, d->d_ytab, d->d_lut, 0.f,
                                     static_cast<float*>(in_ptr));
         if (rc != PP_OK) return rc;
     }

@@ -20,6 +20,9 @@ def main():
         from posepipeline_amd.models import faster_rcnn as fr
         sd = synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2)
         prog = fr.build_image_program(sd, 640, 1088) if which == "det" else fr.build_roi_program(sd)
+    elif which == "yolox":
+        from posepipeline_amd.models import yolox
+        prog = yolox.build_yolox_program(synth.synth_state_dict(yolox.yolox_param_shapes(), seed=6), 800, 1344)
     elif which in ("yolo", "mars"):
         from posepipeline_amd.models import mars, yolov4
         if which == "yolo":
