@@ -50,6 +50,7 @@ class FrameStreamer:
         for i in range(self.N_PIN):
             self.free_q.put(i)
         self.error = None
+        self._stop = False
         self.thread = threading.Thread(target=self._read_loop, name="posepipe-frame-reader", daemon=True)
         self.thread.start()
 
@@ -61,7 +62,7 @@ class FrameStreamer:
                 if want <= 0:
                     break
                 i = self.free_q.get()
-                if i is None:
+                if i is None or self._stop:
                     return
                 a = self.video.read_batch(want)
                 n = int(a.shape[0])
@@ -105,8 +106,11 @@ class FrameStreamer:
         L.check(self.ctx.lib.pp_upload_release(self.ctx.handle), "pp_upload_release")
 
     def close(self):
+        self._stop = True
         self.free_q.put(None)
-        self.thread.join(timeout=5)
+        self.thread.join(timeout=30)
+        if self.thread.is_alive():      # never free staging memory under a reader that is still copying into it
+            raise RuntimeError("frame reader thread did not stop")
         if getattr(self.ctx, "handle", None):
             self.ctx.synchronize()
             for p in self.pin_ptr:
