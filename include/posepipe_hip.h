@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 2   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations */
+#define PP_ABI_VERSION 3   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
+                              3: PP_OP_VIT_ENCODER / PP_OP_DEPTH_TO_SPACE, bf16 building blocks, UDP top-down (post 2) */
 
 typedef enum {
     PP_OK = 0,
@@ -92,7 +93,10 @@ typedef enum {
     PP_OP_CONV = 1,      /* conv2d (conv1d when H == 1), see pp_op fields */
     PP_OP_MAXPOOL = 2,   /* kh x kw max pool, -inf padding (ResNet stem 3x3 s2 p1; FPN P6 1x1 s2) */
     PP_OP_ROIALIGN = 3,  /* reserved for the detector program */
-    PP_OP_COPY = 4       /* buffer copy (same dims) */
+    PP_OP_COPY = 4,      /* buffer copy (same dims) */
+    PP_OP_VIT_ENCODER = 5,   /* ViT encoder on the bf16 matrix cores, see "ViT encoder" below */
+    PP_OP_DEPTH_TO_SPACE = 6 /* in [h][w][4*cout] (channel groups g = 2*dy + dx) -> out [2h][2w][cout]; with four 2x2
+                                convolutions writing the groups this is ConvTranspose2d(k=4, s=2, p=1) */
 } pp_op_type;
 
 #define PP_RELU_NONE 0
@@ -119,7 +123,9 @@ typedef struct pp_op {
     int32_t res1_off_w;       /* read res1 at w + off (VideoPose3D centre-cropped residual) */
     int32_t out_c_off;        /* write channels [out_c_off, out_c_off + cout) of a wider `out` buffer (Concatenate) */
     int32_t in_c_off;         /* max pool only: read channels [in_c_off, in_c_off + cin) of `in` */
-    int32_t pad_end;          /* bit 0 / 1: one extra zero row at the bottom / column at the right (TensorFlow SAME) */
+    int32_t pad_end;          /* bit 0 / 1: one extra zero row at the bottom / column at the right (TensorFlow SAME);
+                                 bit 2 / 3: pad_h / pad_w apply in front only: the last output row / column of the
+                                 symmetric-padding result is not computed (the 2x2 sub-convolutions of a deconvolution) */
     int64_t w_off, b_off;     /* float offsets into the weight blob: W (layout below), bias[cout_pad16] */
 } pp_op;
 
@@ -155,6 +161,41 @@ int pp_net_profile(pp_net* net, int batch, float* ms_per_op);
 int pp_conv2d(pp_ctx* ctx, const pp_op* op, int n, int hin, int win, const float* x,
               const float* w, const float* bias, const float* res1, const float* res2, float* y,
               int res1_h, int res1_w, int mem);
+
+/* ---- ViT encoder (bf16 MFMA path) -----------------------------------------------------------
+ * BASELINE.json configs[4] "ViTPose-H backbone (bf16 MFMA path)".  ViTPose is NOT in the reference tree; it fills the
+ * same slot as the HRNet programs (the model `init_pose_model` builds at wrappers/mmpose.py:57 and
+ * `inference_top_down_pose_model` runs at :75).  Architecture as published for ViTPose (mmpose 0.x fork): ViT with
+ * patch 16 / padding 2, learned position embedding (cls slot folded in), pre-norm blocks (LayerNorm eps 1e-6, qkv bias,
+ * erf GELU), final LayerNorm; head: two ConvTranspose2d(k4, s2, p1) + BN + ReLU and a 1x1 conv.
+ *
+ * PP_OP_VIT_ENCODER: `in`  [h][w][dim] fp32 = patch embeddings (a PP_OP_CONV with kh = kw = stride = 16, pad 2),
+ *                    `out` [h][w][dim] fp32 = tokens after the final LayerNorm;  h * w = tokens (192 = 16 x 12).
+ *   cin = cout = dim, kh = depth, kw = heads, stride = hidden / dim (MLP ratio); dim / heads in {64, 80}.
+ *   w_off: fp32 parameter block  pos[tokens][dim],
+ *          depth x { ln1_g[dim], ln1_b[dim], Wqkv[3 dim][dim], bqkv[3 dim], Wproj[dim][dim], bproj[dim],
+ *                    ln2_g[dim], ln2_b[dim], W1[hidden][dim], b1[hidden], W2[dim][hidden], b2[dim] },
+ *          lnf_g[dim], lnf_b[dim]          (matrices in nn.Linear layout [out][in]; qkv rows = (q|k|v, head, head_dim)).
+ *   The matrices are converted to bf16 (RNE) once at pp_net_create.  Numerics: fp32 residual stream; LayerNorm
+ *   output, qkv, softmax numerators exp(s - max), attention output and GELU output are rounded to bf16; every
+ *   contraction accumulates in fp32 (v_mfma_f32_16x16x32_bf16).  Not bit-reproducible against a CPU restatement
+ *   (the MFMA's internal summation order is not architected): parity tolerance is stated in tests/test_gpu_vit.py.
+ *
+ * The building blocks are exported on their own (tests, other callers); ALL pointers are device pointers:
+ *   pp_gemm_bf16      C[m][n] = act(A[m][k] . W[n][k]^T + bias[n]) + res[row][n];  A, W bf16; bias / res fp32 or NULL;
+ *                     act 0 none / 1 GELU(erf); res row = m % res_mod when res_mod > 0; C fp32 or bf16 (out_bf16);
+ *                     k % 64 == 0, n % 128 == 0.
+ *   pp_layernorm      y = (x - mean) * rsqrt(var + eps) * gamma + beta over the last dim (biased variance), x fp32
+ *   pp_attention_bf16 qkv [batch * tokens][3][heads][head_dim] bf16 -> out [batch * tokens][heads * head_dim] bf16,
+ *                     softmax(q k^T / sqrt(head_dim)) v;  (tokens, head_dim) in {(192, 80), (192, 64)}
+ *   pp_f32_to_bf16    round-to-nearest-even conversion
+ */
+int pp_f32_to_bf16(pp_ctx* ctx, const float* x, uint16_t* y, size_t n);
+int pp_gemm_bf16(pp_ctx* ctx, const uint16_t* a, const uint16_t* w, const float* bias, const float* res, int res_mod,
+                 void* c, int m, int n, int k, int act, int out_bf16);
+int pp_layernorm(pp_ctx* ctx, const float* x, const float* gamma, const float* beta, int rows, int dim, float eps,
+                 void* y, int out_bf16);
+int pp_attention_bf16(pp_ctx* ctx, const uint16_t* qkv, int batch, int tokens, int heads, int head_dim, uint16_t* out);
 
 /* ---- top-down pre-processing --------------------------------------------------------------
  * Replaces mmpose `_box2cs` + `TopDownAffine` (cv2.warpAffine INTER_LINEAR, border 0) + ToTensor +

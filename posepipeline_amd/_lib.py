@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("POSEPIPE_LIB", os.path.join(_HERE, "libposepipe_hip.so"))   # override: kernel A/B builds
 
 PP_MEM_HOST, PP_MEM_DEVICE = 0, 1
-PP_OP_CONV, PP_OP_MAXPOOL, PP_OP_ROIALIGN, PP_OP_COPY = 1, 2, 3, 4
+PP_OP_CONV, PP_OP_MAXPOOL, PP_OP_ROIALIGN, PP_OP_COPY, PP_OP_VIT_ENCODER, PP_OP_DEPTH_TO_SPACE = 1, 2, 3, 4, 5, 6
 PP_RELU_NONE, PP_RELU_LAST, PP_RELU_FIRST = 0, 1, 2
 PP_ACT_LEAKY, PP_ACT_MISH, PP_ACT_ELU, PP_ACT_SWISH = 3, 4, 5, 6
 
@@ -118,6 +118,10 @@ SIGNATURES = {
     "pp_kalman_gating_distance": (_i, [_vp, _vp, _vp, _i, _vp]),
     "pp_linear_sum_assignment": (_i, [_vp, _i, _i, _vp, _vp, C.POINTER(C.c_int32)]),
     "pp_flip_merge_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i]),
+    "pp_f32_to_bf16": (_i, [_vp, _vp, _vp, _sz]),
+    "pp_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i]),
+    "pp_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _i]),
+    "pp_attention_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
 _lib = None

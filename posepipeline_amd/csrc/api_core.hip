@@ -208,6 +208,7 @@ struct pp_net {
     std::vector<hipEvent_t> op_done;
     hipEvent_t fork_ev = nullptr;
     std::vector<hipEvent_t> join_ev;
+    std::vector<pp_vit_encoder*> vits;   // per op: the encoder of a PP_OP_VIT_ENCODER, else null
 
     float* buf_ptr(int b) const { return arena + buf_off[b]; }
 };
@@ -272,8 +273,9 @@ static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
                    op.out_c_off + op.cout, bo.c);
         PP_REQUIRE(bo.c == op.cout || ((bo.c & 3) == 0 && !op.out_nchw), "op %d: a sliced out buffer needs c %% 4 == 0", idx);
         PP_REQUIRE(op.relu >= PP_RELU_NONE && op.relu <= PP_ACT_SWISH, "op %d: unknown activation %d", idx, op.relu);
-        const int ho = pp_conv_out_dim(bi.h + eh, op.kh, op.stride, op.pad_h, op.dil_h);
-        const int wo = pp_conv_out_dim(bi.w + ew, op.kw, op.stride, op.pad_w, op.dil_w);
+        // bits 2 / 3: padding in front only -- the last output row / column of the symmetric-padding result is not computed
+        const int ho = pp_conv_out_dim(bi.h + eh, op.kh, op.stride, op.pad_h, op.dil_h) - ((op.pad_end >> 2) & 1);
+        const int wo = pp_conv_out_dim(bi.w + ew, op.kw, op.stride, op.pad_w, op.dil_w) - ((op.pad_end >> 3) & 1);
         PP_REQUIRE((ho << op.up_log2) == bo.h && (wo << op.up_log2) == bo.w,
                    "op %d: conv output %dx%d (<<%d) does not match out buffer %dx%d", idx, ho, wo, op.up_log2,
                    bo.h, bo.w);
@@ -295,6 +297,16 @@ static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
                    "op %d: maxpool output dims mismatch", idx);
     } else if (op.type == PP_OP_COPY) {
         PP_REQUIRE(bi.c == bo.c && bi.h == bo.h && bi.w == bo.w, "op %d: copy shape mismatch", idx);
+    } else if (op.type == PP_OP_DEPTH_TO_SPACE) {
+        PP_REQUIRE(op.cout > 0 && (op.cout & 3) == 0 && bi.c == 4 * op.cout && bo.c == op.cout && bo.h == 2 * bi.h && bo.w == 2 * bi.w,
+                   "op %d: depth_to_space needs in [h][w][4*cout] and out [2h][2w][cout]", idx);
+    } else if (op.type == PP_OP_VIT_ENCODER) {
+        PP_REQUIRE(op.cin == op.cout && bi.c == op.cin && bo.c == op.cin && bi.h == bo.h && bi.w == bo.w && op.in != op.out,
+                   "op %d: vit encoder needs distinct in / out buffers of [h][w][dim]", idx);
+        PP_REQUIRE(op.kh > 0 && op.kw > 0 && op.stride > 0, "op %d: vit encoder needs depth (kh), heads (kw), mlp ratio (stride)", idx);
+        PP_REQUIRE(op.w_off >= 0 && (op.w_off % 4) == 0 &&
+                       (size_t)op.w_off + pp_vit_param_floats(bi.h * bi.w, op.cin, op.kh, op.cin * op.stride) <= net.n_weights,
+                   "op %d: vit encoder parameters out of blob", idx);
     } else {
         pp_set_error("op %d: unsupported op type %d", idx, op.type);
         return PP_ERR_UNSUPPORTED;
@@ -338,6 +350,11 @@ static int net_launch_op(pp_net* net, const pp_op& op, int batch, hipStream_t s)
                                     (size_t)batch * net->buf_elems[op.in] * sizeof(float),
                                     hipMemcpyDeviceToDevice, s));
         return PP_OK;
+    } else if (op.type == PP_OP_DEPTH_TO_SPACE) {
+        return pp_launch_depth_to_space(net->buf_ptr(op.in), net->buf_ptr(op.out), batch, bi.h, bi.w, op.cout, s);
+    } else if (op.type == PP_OP_VIT_ENCODER) {
+        pp_vit_encoder* enc = net->vits[&op - net->ops.data()];
+        return pp_vit_encoder_run(enc, net->buf_ptr(op.in), net->buf_ptr(op.out), batch, s);
     }
     return PP_ERR_UNSUPPORTED;
 }
@@ -381,6 +398,18 @@ int pp_net_create(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, 
     PP_HIP_CHECK(hipMemcpyAsync(net->weights, weights, n_weights * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     PP_HIP_CHECK(hipMalloc((void**)&net->arena, net->arena_floats * sizeof(float)));
     PP_HIP_CHECK(hipMemsetAsync(net->arena, 0, net->arena_floats * sizeof(float), ctx->stream));
+    net->vits.assign(n_ops, nullptr);
+    for (int i = 0; i < n_ops; ++i) {
+        const pp_op& op = net->ops[i];
+        if (op.type != PP_OP_VIT_ENCODER) continue;
+        const pp_buf& bi = net->bufs[op.in];
+        int rc = pp_vit_encoder_create(net->weights + op.w_off, bi.h * bi.w, op.cin, op.kh, op.kw, op.cin * op.stride,
+                                       max_batch, ctx->stream, &net->vits[i]);
+        if (rc != PP_OK) {
+            pp_net_destroy(net.release());
+            return rc;
+        }
+    }
     PP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const char* env_lanes = getenv("POSEPIPE_NET_LANES");
     const int n_lanes = env_lanes ? atoi(env_lanes) : 4;
@@ -412,6 +441,7 @@ void pp_net_destroy(pp_net* net) {
         if (e) (void)hipEventDestroy(e);
     if (net->fork_ev) (void)hipEventDestroy(net->fork_ev);
     if (net->graph_exec) (void)hipGraphExecDestroy(net->graph_exec);
+    for (auto* v : net->vits) pp_vit_encoder_destroy(v);
     if (net->weights) (void)hipFree(net->weights);
     if (net->arena) (void)hipFree(net->arena);
     delete net;
@@ -541,8 +571,8 @@ int pp_conv2d(pp_ctx* ctx, const pp_op* op, int n, int hin, int win, const float
     PP_REQUIRE(n > 0 && hin > 0 && win > 0, "pp_conv2d: empty input");
     ConvArgs a{};
     a.N = n; a.Hin = hin; a.Win = win; a.Cin = op->cin;
-    a.Hout = pp_conv_out_dim(hin + (op->pad_end & 1), op->kh, op->stride, op->pad_h, op->dil_h);
-    a.Wout = pp_conv_out_dim(win + ((op->pad_end >> 1) & 1), op->kw, op->stride, op->pad_w, op->dil_w);
+    a.Hout = pp_conv_out_dim(hin + (op->pad_end & 1), op->kh, op->stride, op->pad_h, op->dil_h) - ((op->pad_end >> 2) & 1);
+    a.Wout = pp_conv_out_dim(win + ((op->pad_end >> 1) & 1), op->kw, op->stride, op->pad_w, op->dil_w) - ((op->pad_end >> 3) & 1);
     PP_REQUIRE(a.Hout > 0 && a.Wout > 0, "pp_conv2d: empty output");
     a.Cout = op->cout; a.CoutPad = (op->cout + 15) / 16 * 16;
     a.KH = op->kh; a.KW = op->kw; a.stride = op->stride; a.pad_h = op->pad_h; a.pad_w = op->pad_w;

@@ -89,6 +89,35 @@ struct PoolArgs {
 };
 int pp_launch_maxpool(const PoolArgs& a, hipStream_t stream);
 
+// ---- ViT encoder pieces, bf16 MFMA path (gemm_bf16.hip, vit_encoder.hip) ---------------------------
+struct GemmArgs {
+    const void* A;       // [M][K] bf16 activations
+    const void* B;       // [N][K] bf16 weights (nn.Linear layout)
+    const float* bias;   // [N] or null
+    const float* res;    // fp32 [M or res_mod][N] or null
+    void* C;             // [M][N] fp32 or bf16
+    int M, N, K;
+    int act;             // 0 none, 1 GELU (erf)
+    int out_bf16;
+    int res_mod;         // > 0: residual row = m % res_mod (position embedding)
+};
+int pp_launch_gemm_bf16(const GemmArgs& a, hipStream_t stream);
+int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream);
+// y = LayerNorm(x [+ pos[row % pos_mod]]) over the last dim; x_out (optional) receives x + pos in fp32
+int pp_launch_layernorm(const float* x, const float* pos, int pos_mod, float* x_out, const float* gamma,
+                        const float* beta, int rows, int dim, float eps, void* y, int out_bf16, hipStream_t stream);
+// multi-head self-attention on a packed qkv tensor [batch * tokens][3][heads][head_dim] bf16 -> [batch * tokens][heads * head_dim]
+int pp_launch_attention(const void* qkv, int batch, int tokens, int heads, int head_dim, void* out, hipStream_t stream);
+// [n][h][w][4 * c] (parity-major channel groups g = 2 * dy + dx) -> [n][2h][2w][c]
+int pp_launch_depth_to_space(const float* x, float* y, int n, int h, int w, int c, hipStream_t stream);
+// encoder behind PP_OP_VIT_ENCODER; `params` is a DEVICE pointer into the program's fp32 weight blob
+struct pp_vit_encoder;
+size_t pp_vit_param_floats(int tokens, int dim, int depth, int hidden);
+int pp_vit_encoder_create(const float* params, int tokens, int dim, int depth, int heads, int hidden, int max_batch,
+                          hipStream_t stream, pp_vit_encoder** out);
+void pp_vit_encoder_destroy(pp_vit_encoder* e);
+int pp_vit_encoder_run(pp_vit_encoder* e, const float* in, float* out, int batch, hipStream_t stream);
+
 // ---- top-down pre/post (crop_affine.hip, dark_decode.hip) ----------------------------------------
 struct PersonXform {
     double a00, a01, b0, a10, a11, b1;  // inverse map dst -> src (OpenCV warpAffine, after inversion)

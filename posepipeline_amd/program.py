@@ -103,10 +103,11 @@ class ProgramBuilder:
     # ---- ops ---------------------------------------------------------------------------------
     def conv(self, x, weight, bias, *, stride=1, pad=(0, 0), dil=(1, 1), relu=L.PP_RELU_NONE, res1=-1, res2=-1,
              up_log2=0, out=None, out_nchw=False, res1_shift=0, res1_off_w=0, out_c_off=0, pad_end=(0, 0),
-             name="conv") -> int:
+             front_only=(0, 0), name="conv") -> int:
         """weight: torch layout, BN already folded.  Returns the (virtual) output buffer.
         out / out_c_off: write channels [out_c_off, out_c_off + cout) of an existing wider buffer (Concatenate).
-        pad_end: (rows, cols) in {0, 1}: one extra zero row / column at the bottom / right (TensorFlow SAME)."""
+        pad_end: (rows, cols) in {0, 1}: one extra zero row / column at the bottom / right (TensorFlow SAME).
+        front_only: (rows, cols) in {0, 1}: `pad` applies in front only (the last output row / column is dropped)."""
         if isinstance(pad, int):
             pad = (pad, pad)
         if isinstance(dil, int):
@@ -118,8 +119,8 @@ class ProgramBuilder:
         cout, cin, kh, kw = wt.shape
         assert cin <= cin_buf and cin_buf % 4 == 0, (cin, cin_buf)
         W, b = pack_conv(wt, bias, cin_pad=cin_buf)
-        ho = (h + pad_end[0] + 2 * pad[0] - dil[0] * (kh - 1) - 1) // stride + 1
-        wo = (w + pad_end[1] + 2 * pad[1] - dil[1] * (kw - 1) - 1) // stride + 1
+        ho = (h + pad_end[0] + 2 * pad[0] - dil[0] * (kh - 1) - 1) // stride + 1 - front_only[0]
+        wo = (w + pad_end[1] + 2 * pad[1] - dil[1] * (kw - 1) - 1) // stride + 1 - front_only[1]
         if out is None:
             assert out_c_off == 0
             out = self.buf(ho << up_log2, wo << up_log2, cout)
@@ -132,7 +133,8 @@ class ProgramBuilder:
         self.vops.append(dict(type=L.PP_OP_CONV, in_=x, out=out, res1=res1, res2=res2, cin=cin_buf, cout=cout, kh=kh,
                               kw=kw, stride=stride, pad_h=pad[0], pad_w=pad[1], dil_h=dil[0], dil_w=dil[1], relu=relu,
                               up_log2=up_log2, out_nchw=int(out_nchw), res1_shift=res1_shift, res1_off_w=res1_off_w,
-                              out_c_off=out_c_off, in_c_off=0, pad_end=pad_end[0] | (pad_end[1] << 1),
+                              out_c_off=out_c_off, in_c_off=0,
+                              pad_end=pad_end[0] | (pad_end[1] << 1) | (front_only[0] << 2) | (front_only[1] << 3),
                               w_off=w_off, b_off=b_off, name=name,
                               flops=2.0 * ho * wo * cout * cin * kh * kw))
         return out
@@ -155,6 +157,53 @@ class ProgramBuilder:
                               res1_shift=0, res1_off_w=0, out_c_off=out_c_off, in_c_off=in_c_off, pad_end=0,
                               w_off=0, b_off=0, name=name, flops=0.0))
         return out
+
+    def _plain_op(self, type_, x, out, *, cin, cout, kh=1, kw=1, stride=1, w_off=0, name="op", flops=0.0):
+        self.vops.append(dict(type=type_, in_=x, out=out, res1=-1, res2=-1, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride,
+                              pad_h=0, pad_w=0, dil_h=1, dil_w=1, relu=0, up_log2=0, out_nchw=0, res1_shift=0,
+                              res1_off_w=0, out_c_off=0, in_c_off=0, pad_end=0, w_off=w_off, b_off=0, name=name,
+                              flops=flops))
+        return out
+
+    def vit_encoder(self, x, params, *, depth, heads, mlp_ratio, name="vit_encoder") -> int:
+        """PP_OP_VIT_ENCODER on a [h][w][dim] fp32 token map.  params: flat fp32 block in the layout of
+        include/posepipe_hip.h (pos, depth x block, final LayerNorm)."""
+        h, w, dim = self.dims(x)
+        t, hid = h * w, dim * mlp_ratio
+        per_block = 2 * dim + 3 * dim * dim + 3 * dim + dim * dim + dim + 2 * dim + hid * dim + hid + dim * hid + dim
+        params = np.asarray(params, dtype=np.float32).reshape(-1)
+        assert params.size == t * dim + per_block * depth + 2 * dim, (params.size, t, dim, depth)
+        out = self.buf(h, w, dim)
+        macs = depth * (t * (4 * dim * dim + 2 * dim * hid) + 2 * t * t * dim)
+        return self._plain_op(L.PP_OP_VIT_ENCODER, x, out, cin=dim, cout=dim, kh=depth, kw=heads, stride=mlp_ratio,
+                              w_off=self._add_blob(params), name=name, flops=2.0 * macs)
+
+    def depth_to_space(self, x, name="depth_to_space") -> int:
+        """[h][w][4c] (channel groups g = 2*dy + dx) -> [2h][2w][c]"""
+        h, w, c4 = self.dims(x)
+        assert c4 % 16 == 0
+        out = self.buf(2 * h, 2 * w, c4 // 4)
+        return self._plain_op(L.PP_OP_DEPTH_TO_SPACE, x, out, cin=c4, cout=c4 // 4, name=name)
+
+    def deconv4x4s2(self, x, weight, bias, *, relu=L.PP_RELU_NONE, name="deconv") -> int:
+        """ConvTranspose2d(kernel 4, stride 2, padding 1) (+ folded BN, ReLU) as four 2x2 convolutions, one per output
+        parity, written to the channel groups of a [h][w][4*cout] buffer, then depth_to_space.
+        weight: torch ConvTranspose2d layout [cin][cout][4][4].  out[2j + a] = sum_i in[i] w[2j + a + 1 - 2i]:
+        a = 0 -> taps (in[j-1], in[j]) x (w[3], w[1]), one zero row in front; a = 1 -> (in[j], in[j+1]) x (w[2], w[0]),
+        one zero row behind."""
+        h, w, cin_buf = self.dims(x)
+        wt = np.asarray(weight, dtype=np.float32)
+        cin, cout = wt.shape[:2]
+        assert wt.shape[2:] == (4, 4) and cout % 4 == 0
+        wide = self.buf(h, w, 4 * cout)
+        taps = {0: (3, 1), 1: (2, 0)}
+        for a in (0, 1):
+            for b in (0, 1):
+                sub = wt[:, :, list(taps[a]), :][:, :, :, list(taps[b])]          # [cin][cout][2][2]
+                self.conv(x, np.transpose(sub, (1, 0, 2, 3)), bias, pad=(1 - a, 1 - b), pad_end=(a, b),
+                          front_only=(1 - a, 1 - b), relu=relu, out=wide, out_c_off=(2 * a + b) * cout,
+                          name=f"{name}.p{a}{b}")
+        return self.depth_to_space(wide, name=name + ".d2s")
 
     # ---- finalize ----------------------------------------------------------------------------
     def build(self) -> Program:
