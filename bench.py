@@ -9,11 +9,13 @@ Workloads (--workload, named in config.workload):
           so the boxes fed to the tracker / 2D stage are replayed synthetic ground truth (+jitter), as
           SURVEY.md 8(d) prescribes.
   c2      BASELINE.json configs[1]: HRNet-W32 256x192 on 64 pre-cropped persons per step (flip_test, decode).
+  c5      BASELINE.json configs[4] on one GPU: ViTPose-H 256x192 (bf16 MFMA encoder) on 64 pre-cropped persons per step.
 One process per GPU (torchrun); ranks work on independent frame shards (weak scaling, no data-path
 collective); weights are broadcast from rank 0 over RCCL.  `value` = frames of all ranks / max-over-ranks
 wall time of exactly K steps bracketed by barrier + synchronize.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -34,10 +36,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cascade", choices=["cascade", "c2", "track0", "cascade0"])
+    ap.add_argument("--workload", default="cascade", choices=["cascade", "c2", "c5", "track0", "cascade0"])
     ap.add_argument("--chunk", type=int, default=32, help="cascade: frames per step per GPU")
     ap.add_argument("--persons", type=int, default=1, help="cascade: tracked persons per frame")
-    ap.add_argument("--batch", type=int, default=64, help="c2: person-frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="c2 / c5: person-frames per step per GPU")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the CPU-baseline sample (0 = skip)")
     return ap.parse_args()
 
@@ -363,6 +365,104 @@ def cpu_baseline_c2(sd, x, cs, kp_gpu):
             "max_abs_diff_px_vs_gpu": float(np.abs(np.array(kps) - kp_gpu[:m]).max())}
 
 
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def run_c5(args, D):
+    """BASELINE.json configs[4] on one GPU per rank: ViTPose-H 256x192 top-down 2D (bf16 MFMA encoder, flip test, UDP
+    decode) on pre-cropped persons.  ViTPose is not in the reference tree: a parity-test configuration
+    with its own bench line, not the headline metric."""
+    from posepipeline_amd import _lib, ops
+    from posepipeline_amd.models import hrnet, vitpose
+    from posepipeline_amd.program import Net
+
+    ctx = _lib.Context(D.local_rank)
+    spec = vitpose.vitpose_huge()
+    p = vitpose.synth_params(spec, seed=5)
+    prog = vitpose.build_vitpose_program(spec, p)
+    prog.blob = D.bcast_blob(prog.blob)
+    n = args.batch
+    net = Net(ctx, prog, max_batch=2 * n)
+    td = ops.TopDown(net, num_joints=17, flip_perm=hrnet.flip_perm(17), shift_heatmap=False, post="udp", blur_kernel=11)
+    rng = np.random.default_rng(5000 + D.rank)
+    x = np.zeros((n, spec.in_h, spec.in_w, 4), np.float32)
+    x[..., :3] = rng.standard_normal((n, spec.in_h, spec.in_w, 3)).astype(np.float32)
+    cs = np.tile(np.array([[96.0, 128.0, 192 / 200 * 1.25, 256 / 200 * 1.25]], np.float32), (n, 1))
+    dptr, _, _ = net.buffer("input")
+    ctx.h2d(dptr, x)
+    for _ in range(args.warmup):
+        kp = td.run_precropped(dptr, cs, n=n)
+    D.barrier(ctx)
+    t0 = time.perf_counter()
+    t_net = t_pre = t_dec = 0.0
+    for _ in range(args.steps):
+        kp = td.run_precropped(dptr, cs, n=n)
+        a, b, c = td.timing()
+        t_pre, t_net, t_dec = t_pre + a, t_net + b, t_dec + c
+    D.barrier(ctx)
+    dt = D.max_time(time.perf_counter() - t0)
+    if D.rank != 0:
+        return
+    # roofline leg (outside the timed region): HIP events after every encoder launch, summed per kernel family
+    ms3 = np.zeros(3, np.float32)
+    n_gemm = ctypes.c_int(0)
+    _lib.check(ctx.lib.pp_net_vit_timing(net.handle, 1, None, None))
+    td.run_precropped(dptr, cs, n=n)
+    _lib.check(ctx.lib.pp_net_vit_timing(net.handle, 0, _lib.ptr(ms3), ctypes.byref(n_gemm)))
+    m_rows, d, hid = 2 * n * spec.tokens, spec.dim, spec.dim * spec.mlp_ratio
+    gemm_flops = 2.0 * m_rows * (4 * d * d + 2 * d * hid) * spec.depth
+    achieved = gemm_flops / (float(ms3[0]) * 1e-3) / 1e12
+    net_ms = t_net / args.steps
+    out = {
+        "metric": METRIC, "value": D.world * n * args.steps / dt, "unit": "frames/s", "n_gpus": D.world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "configs[4] on one GPU per rank: ViTPose-H 256x192 top-down 2D, pre-cropped persons, flip_test, "
+                               "UDP decode (bf16 MFMA encoder, fp32 patch embedding and deconvolution head)",
+                   "frames_per_step_per_gpu": n, "backbone_samples_per_step": 2 * n,
+                   "gflop_per_frame": prog.flops * 2 / 1e9,
+                   "not_in_this_line": "detector, tracker, 3D lifting (see --workload cascade); ViTPose is not in the reference tree"},
+        "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (%d launches per step: qkv / proj / fc1 / fc2 of %d blocks)" % (n_gemm.value, spec.depth),
+                     "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
+                     "traffic": pmc_traffic("c5_batch%d" % n), "flops_per_launch": gemm_flops / max(n_gemm.value, 1),
+                     "avg_launch_ms": float(ms3[0]) / max(n_gemm.value, 1),
+                     "encoder_ms": {"gemm": float(ms3[0]), "layernorm": float(ms3[1]), "attention": float(ms3[2])},
+                     "program_tflops": prog.flops * 2 * n / (net_ms * 1e-3) / 1e12,
+                     "stage_ms": {"pre": t_pre / args.steps, "backbone": net_ms, "decode": t_dec / args.steps}},
+    }
+    n_cpu = 1 if args.cpu_frames is None else args.cpu_frames
+    if n_cpu > 0 and D.world == 1:
+        hm_gpu = net.read("output", 2 * n).reshape(2 * n, 17, *spec.heatmap_hw)
+        out["cpu_baseline"] = cpu_baseline_c5(p, spec, x[:n_cpu], cs[:n_cpu], kp[:n_cpu], hm_gpu[:n_cpu], hm_gpu[n:n + n_cpu])
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_c5(p, spec, x, cs, kp_gpu, hm_gpu, hmf_gpu):
+    """batch-1 loop on the CPU oracle (numpy float64 contractions of the bf16-rounded operands).  The bf16 network is
+    compared on its heatmaps (a randomly initialised net has no stable argmax); the decode is compared on the GPU's own
+    heatmaps."""
+    from oracle import decode as odec
+    from oracle import vit as ovit
+    from posepipeline_amd.models import hrnet
+    t0 = time.perf_counter()
+    m, err = 0, 0.0
+    for i in range(x.shape[0]):
+        hm = ovit.forward(x[i:i + 1], p, spec, emulate_bf16=True)
+        hmf = ovit.forward(np.ascontiguousarray(x[i:i + 1, :, ::-1]), p, spec, emulate_bf16=True)
+        odec.decode_topdown_udp(hm, hmf, hrnet.COCO_FLIP_PAIRS, cs[i:i + 1, :2], cs[i:i + 1, 2:], kernel=11)
+        m += 1
+        err = max(err, float(np.abs(hm[0] - hm_gpu[i]).max() / np.abs(hm[0]).max()),
+                  float(np.abs(hmf[0] - hmf_gpu[i]).max() / np.abs(hmf[0]).max()))
+        if time.perf_counter() - t0 > 20.0:
+            break
+    dt = time.perf_counter() - t0
+    k_ref, _ = odec.decode_topdown_udp(hm_gpu[:m], hmf_gpu[:m], hrnet.COCO_FLIP_PAIRS, cs[:m, :2], cs[:m, 2:], kernel=11)
+    return {"value": m / dt, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d of the same pre-cropped frames, batch-1 loop, numpy/BLAS float64 contractions + numpy decode (%.1f s)" % (m, dt),
+            "heatmap_max_rel_diff_vs_gpu": err,
+            "decode_max_abs_diff_px_on_gpu_heatmaps": float(np.abs(k_ref - kp_gpu[:m]).max())}
+
+
 def run_track0(args, D):
     """tracking_method 0 (DeepSortYOLOv4): YOLOv4 person detector + mars-small128 features +
     DeepSORT on 1080p frames resident in HBM.  Not the headline metric; same JSON shape for comparison."""
@@ -497,7 +597,7 @@ def main():
     args = parse()
     D = Dist()
     try:
-        {"cascade": run_cascade, "c2": run_c2, "track0": run_track0, "cascade0": run_cascade0}[args.workload](args, D)
+        {"cascade": run_cascade, "c2": run_c2, "c5": run_c5, "track0": run_track0, "cascade0": run_cascade0}[args.workload](args, D)
     finally:
         D.close()
 

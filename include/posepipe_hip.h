@@ -190,6 +190,10 @@ int pp_conv2d(pp_ctx* ctx, const pp_op* op, int n, int hin, int win, const float
  *                     softmax(q k^T / sqrt(head_dim)) v;  (tokens, head_dim) in {(192, 80), (192, 64)}
  *   pp_f32_to_bf16    round-to-nearest-even conversion
  */
+/* HIP-event timing of the encoder's kernel families (bench.py's roofline leg).  enable != 0: record one event after
+ * every launch of later runs.  ms3 (may be NULL): {bf16 GEMMs, LayerNorms, attention} milliseconds of the last recorded
+ * run, n_gemm its GEMM launch count; synchronises the ctx stream. */
+int pp_net_vit_timing(pp_net* net, int enable, float* ms3, int* n_gemm);
 int pp_f32_to_bf16(pp_ctx* ctx, const float* x, uint16_t* y, size_t n);
 int pp_gemm_bf16(pp_ctx* ctx, const uint16_t* a, const uint16_t* w, const float* bias, const float* res, int res_mod,
                  void* c, int m, int n, int k, int act, int out_bf16);
@@ -223,7 +227,11 @@ int pp_crop_affine_normalize(pp_ctx* ctx, const uint8_t* frames, int n_frames, i
  * wrappers/mmpose.py:75; in-tree statement of the DARK maths: utils/inference.py:27-114.
  * hm: [n][k][h][w] fp32; hm_flip: same for the mirrored input or NULL (no flip test).
  * flip_perm: [k] channel permutation applied to hm_flip (COCO left/right pairs).
- * post: 0 = 'default' (+-0.25 px), 1 = 'unbiased' (DARK, blur_kernel e.g. 17).
+ * post: 0 = 'default' (+-0.25 px), 1 = 'unbiased' (DARK, blur_kernel e.g. 17),
+ *       2 = UDP (`use_udp=True`, ViTPose configs; not in the reference tree): post_dark_udp (cv2.GaussianBlur with
+ *       modulate kernel e.g. 11 and reflect-101 borders, clip [0.001, 50], log, edge-replicated stencil, Newton step
+ *       with inv(Hessian + eps I)) and the UDP back-mapping x * scale * 200 / (w - 1).  In pp_topdown_* post 2 also
+ *       selects the UDP crop (TopDownAffine(use_udp=True)); pp_crop_affine_normalize takes it as bit 1 of `flip`.
  * center_scale: [n][4] as above.  kpts: [n][k][3] fp32 = (x_px, y_px, maxval).
  * merged (optional): [n][k][h][w] the averaged heatmap (parity tests).
  */

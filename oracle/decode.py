@@ -160,3 +160,79 @@ def decode_topdown(hm, hm_flipped, flip_pairs, center, scale, post_process="unbi
     out[:, :, 0:2] = preds
     out[:, :, 2:3] = maxvals
     return out, merged
+
+
+# ---- UDP variant (ViTPose configs: test_cfg use_udp=True, post_process='default', modulate_kernel=11, shift_heatmap=False)
+# NOT in the reference tree; restated from mmpose 0.x `post_dark_udp` / `transform_preds(use_udp=True)`: parity unpinned.
+def gaussian_blur_reflect_f32(hm2d, ksize):
+    """cv2.GaussianBlur(hm, (ksize, ksize), 0) in place on the map itself: BORDER_REFLECT_101, float32, no FMA;
+    same summation orders as gaussian_blur_f32."""
+    h, w = hm2d.shape
+    r = ksize // 2
+    k = gaussian_kernel1d(ksize)
+    pad = np.pad(hm2d.astype(f32), ((0, 0), (r, r)), mode="reflect")
+    row = (k[0] * pad[:, 0:w]).astype(f32)
+    for j in range(1, ksize):
+        row = (row + (k[j] * pad[:, j:j + w]).astype(f32)).astype(f32)
+    padv = np.pad(row, ((r, r), (0, 0)), mode="reflect")
+    out = (k[r] * padv[r:r + h]).astype(f32)
+    for j in range(1, r + 1):
+        pair = (padv[r + j:r + j + h] + padv[r - j:r - j + h]).astype(f32)
+        out = (out + (k[r + j] * pair).astype(f32)).astype(f32)
+    return out
+
+
+def post_dark_udp(coords, heatmaps, kernel=11):
+    """coords [N][K][2] float32 (argmax), heatmaps [N][K][H][W] float32 -> refined coords (float32).
+    Deviation, stated: joints without a peak (maxval <= 0, coords -1) are left alone -- mmpose indexes the flattened,
+    padded batch with -1 there and reads an unrelated map."""
+    n, kk, h, w = heatmaps.shape
+    out = coords.astype(f32).copy()
+    for i in range(n):
+        for j in range(kk):
+            px, py = int(coords[i, j, 0]), int(coords[i, j, 1])
+            if px < 0:
+                continue
+            hm = gaussian_blur_reflect_f32(heatmaps[i, j], kernel)
+            hm = np.log(np.clip(hm, f32(0.001), f32(50.0)).astype(f64)).astype(f32)
+            p = np.pad(hm, 1, mode="edge")
+            x, y = px + 1, py + 1
+            i_, ix1, iy1, ix1y1 = p[y, x], p[y, x + 1], p[y + 1, x], p[y + 1, x + 1]
+            ix1_y1_, ix1_, iy1_ = p[y - 1, x - 1], p[y, x - 1], p[y - 1, x]
+            dx = f32(0.5) * f32(ix1 - ix1_)
+            dy = f32(0.5) * f32(iy1 - iy1_)
+            dxx = f32(f32(ix1 - f32(f32(2.0) * i_)) + ix1_)
+            dyy = f32(f32(iy1 - f32(f32(2.0) * i_)) + iy1_)
+            t = f32(ix1y1 - ix1)
+            for v, sgn in ((iy1, -1), (i_, 1), (i_, 1), (ix1_, -1), (iy1_, -1), (ix1_y1_, 1)):
+                t = f32(t + v) if sgn > 0 else f32(t - v)
+            dxy = f32(0.5) * t
+            hess = np.array([[dxx, dxy], [dxy, dyy]], f64) + f64(np.finfo(f32).eps) * np.eye(2)
+            off = np.linalg.inv(hess) @ np.array([dx, dy], f64)
+            out[i, j, 0] = f32(f64(out[i, j, 0]) - off[0])
+            out[i, j, 1] = f32(f64(out[i, j, 1]) - off[1])
+    return out
+
+
+def transform_preds_udp(coords, center, scale, output_size):
+    scale = (np.asarray(scale, f32) * f32(200.0)).astype(f32)
+    scale_x = f32(f64(scale[0]) / (output_size[0] - 1.0))
+    scale_y = f32(f64(scale[1]) / (output_size[1] - 1.0))
+    out = np.ones_like(coords, dtype=f32)
+    out[:, 0] = ((coords[:, 0] * scale_x).astype(f32) + f32(center[0])).astype(f32) - f32(f64(scale[0]) * 0.5)
+    out[:, 1] = ((coords[:, 1] * scale_y).astype(f32) + f32(center[1])).astype(f32) - f32(f64(scale[1]) * 0.5)
+    return out.astype(f32)
+
+
+def decode_topdown_udp(hm, hm_flipped, flip_pairs, center, scale, kernel=11):
+    """flip-merge (no shift) + DARK-UDP + UDP back-mapping -> (keypoints [N][K][3], merged heatmap)"""
+    merged = flip_merge(hm, hm_flipped, flip_pairs, False) if hm_flipped is not None else np.asarray(hm, f32)
+    n, k, h, w = merged.shape
+    preds, maxvals = get_max_preds(merged)
+    preds = post_dark_udp(preds, merged, kernel)
+    for i in range(n):
+        preds[i] = transform_preds_udp(preds[i], center[i], scale[i], [w, h])
+    out = np.zeros((n, k, 3), dtype=f32)
+    out[:, :, 0:2] = preds
+    out[:, :, 2:3] = maxvals
+    return out, merged

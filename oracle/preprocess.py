@@ -140,3 +140,33 @@ def top_down_input(frame_wrapper_rgb, bbox, image_size=(288, 384)):
     lut = normalize_lut()
     t = np.stack([lut[c][crop[:, :, c]] for c in range(3)], axis=0)
     return t.astype(np.float32), center, scale, crop
+
+
+# ---- UDP variant (ViTPose configs, `use_udp=True`; NOT in the reference tree: parity unpinned) -------------------
+def get_warp_matrix_udp(center, scale, image_size):
+    """mmpose `get_warp_matrix(theta=0, size_input=c * 2.0, size_dst=image_size - 1.0, size_target=s * 200.0)`:
+    scalars in float64, the returned 2x3 matrix float32 (as mmpose builds it)."""
+    size_input = (np.asarray(center, np.float32) * np.float32(2.0)).astype(np.float32)
+    size_target = (np.asarray(scale, np.float32) * np.float32(200.0)).astype(np.float32)
+    size_dst = np.asarray(image_size, np.float64) - 1.0
+    m = np.zeros((2, 3), dtype=np.float32)
+    sx = size_dst[0] / float(size_target[0])
+    sy = size_dst[1] / float(size_target[1])
+    m[0, 0] = 1.0 * sx
+    m[0, 1] = -0.0 * sx
+    m[0, 2] = sx * (-0.5 * float(size_input[0]) * 1.0 + 0.5 * float(size_input[1]) * 0.0 + 0.5 * float(size_target[0]))
+    m[1, 0] = 0.0 * sy
+    m[1, 1] = 1.0 * sy
+    m[1, 2] = sy * (-0.5 * float(size_input[0]) * 0.0 - 0.5 * float(size_input[1]) * 1.0 + 0.5 * float(size_target[1]))
+    return m
+
+
+def top_down_input_udp(frame_wrapper_rgb, bbox, image_size=(192, 256)):
+    """`top_down_input` with TopDownAffine(use_udp=True).  Same channel quirk as the non-UDP path."""
+    center, scale = box2cs(bbox, image_size)
+    m = get_warp_matrix_udp(center, scale, image_size)
+    img_bgr_view = frame_wrapper_rgb[:, :, ::-1]
+    crop = warp_affine_u8(np.ascontiguousarray(img_bgr_view), m.astype(np.float64), image_size)
+    lut = normalize_lut()
+    t = np.stack([lut[c][crop[:, :, c]] for c in range(3)], axis=0).astype(np.float32)
+    return t, center, scale, crop

@@ -112,10 +112,11 @@ def conv_transpose_4s2p1(x_nhwc, w):
     b, h, ww, cin = x_nhwc.shape
     cout = w.shape[1]
     full = np.zeros((b, 2 * h + 2, 2 * ww + 2, cout), np.float64)
-    x64, w64 = x_nhwc.astype(np.float64), w.astype(np.float64)
+    x64 = x_nhwc.astype(np.float64).reshape(b * h * ww, cin)
+    w64 = np.ascontiguousarray(np.transpose(w.astype(np.float64), (2, 3, 0, 1)))      # [kh][kw][cin][cout]
     for kh in range(4):
         for kw in range(4):
-            full[:, kh:kh + 2 * h:2, kw:kw + 2 * ww:2] += x64 @ w64[:, :, kh, kw]
+            full[:, kh:kh + 2 * h:2, kw:kw + 2 * ww:2] += (x64 @ w64[kh, kw]).reshape(b, h, ww, cout)
     return full[:, 1:1 + 2 * h, 1:1 + 2 * ww]
 
 

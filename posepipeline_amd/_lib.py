@@ -118,6 +118,7 @@ SIGNATURES = {
     "pp_kalman_gating_distance": (_i, [_vp, _vp, _vp, _i, _vp]),
     "pp_linear_sum_assignment": (_i, [_vp, _i, _i, _vp, _vp, C.POINTER(C.c_int32)]),
     "pp_flip_merge_decode": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i]),
+    "pp_net_vit_timing": (_i, [_vp, _i, _vp, _vp]),
     "pp_f32_to_bf16": (_i, [_vp, _vp, _vp, _sz]),
     "pp_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i]),
     "pp_layernorm": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_float, _vp, _i]),

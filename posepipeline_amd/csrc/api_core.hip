@@ -490,6 +490,22 @@ int pp_net_run(pp_net* net, int batch, int first_op, int last_op) {
     return PP_OK;
 }
 
+int pp_net_vit_timing(pp_net* net, int enable, float* ms3, int* n_gemm) {
+    PP_REQUIRE(net, "pp_net_vit_timing: net is NULL");
+    for (auto* v : net->vits) {
+        if (!v) continue;
+        if (ms3) {
+            PP_HIP_CHECK(hipStreamSynchronize(net->ctx->stream));
+            int rc = pp_vit_encoder_get_timing(v, ms3, n_gemm);
+            if (rc != PP_OK) return rc;
+        }
+        pp_vit_encoder_set_timing(v, enable);
+        return PP_OK;
+    }
+    pp_set_error("pp_net_vit_timing: the program has no PP_OP_VIT_ENCODER");
+    return PP_ERR_STATE;
+}
+
 int pp_net_set_lanes(pp_net* net, int enable) {
     PP_REQUIRE(net, "pp_net_set_lanes: net is NULL");
     PP_HIP_CHECK(hipStreamSynchronize(net->ctx->stream));

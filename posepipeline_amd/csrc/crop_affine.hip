@@ -127,7 +127,7 @@ bool solve6(double A[6][6], double b[6], double x[6]) {
 }  // namespace
 
 // mmpose `_box2cs` + `get_affine_transform(rot=0)` + OpenCV's inversion.  Returns false for NaN boxes.
-bool pp_person_transform(const double* bb, int out_w, int out_h, float cs[4], PersonXform* t) {
+bool pp_person_transform(const double* bb, int out_w, int out_h, float cs[4], PersonXform* t, int udp) {
     t->valid = 0;
     cs[0] = cs[1] = cs[2] = cs[3] = 0.f;
     if (std::isnan(bb[0]) || std::isnan(bb[1]) || std::isnan(bb[2]) || std::isnan(bb[3])) return false;
@@ -140,6 +140,21 @@ bool pp_person_transform(const double* bb, int out_w, int out_h, float cs[4], Pe
     sx = sx * 1.25f;   // float32 array * python float stays float32
     sy = sy * 1.25f;
     cs[0] = cx; cs[1] = cy; cs[2] = sx; cs[3] = sy;
+    double M[6];
+    if (udp) {
+        // mmpose TopDownAffine(use_udp=True): get_warp_matrix(theta = 0, size_input = c * 2.0, size_dst = image_size - 1.0,
+        // size_target = s * 200.0): scalars in float64, the 2x3 matrix itself is float32
+        const float in_x = cx * 2.0f, in_y = cy * 2.0f, tg_x = sx * 200.0f, tg_y = sy * 200.0f;
+        const double scale_x = ((double)out_w - 1.0) / (double)tg_x, scale_y = ((double)out_h - 1.0) / (double)tg_y;
+        M[0] = (double)(float)(1.0 * scale_x);
+        M[1] = (double)(float)(-0.0 * scale_x);
+        M[2] = (double)(float)(scale_x * (-0.5 * (double)in_x * 1.0 + 0.5 * (double)in_y * 0.0 + 0.5 * (double)tg_x));
+        M[3] = (double)(float)(0.0 * scale_y);
+        M[4] = (double)(float)(1.0 * scale_y);
+        M[5] = (double)(float)(scale_y * (-0.5 * (double)in_x * 0.0 - 0.5 * (double)in_y * 1.0 + 0.5 * (double)tg_y));
+        if (!(std::isfinite(M[0]) && std::isfinite(M[4]) && std::isfinite(M[2]) && std::isfinite(M[5])))
+            for (double& m : M) m = 0.0;   // zero-size box
+    } else {
     // get_affine_transform: points are float32, the intermediate sums float64
     const float src_w = sx * 200.0f;
     const float s0x = cx, s0y = cy;
@@ -154,7 +169,7 @@ bool pp_person_transform(const double* bb, int out_w, int out_h, float cs[4], Pe
     const float t2x = t1x + (-e1), t2y = t1y + e0;
     const float sp[3][2] = {{s0x, s0y}, {s1x, s1y}, {s2x, s2y}};
     const float dp[3][2] = {{t0x, t0y}, {t1x, t1y}, {t2x, t2y}};
-    double A[6][6] = {}, b[6], M[6];
+    double A[6][6] = {}, b[6];
     for (int i = 0; i < 3; ++i) {
         A[2 * i][0] = sp[i][0]; A[2 * i][1] = sp[i][1]; A[2 * i][2] = 1.0;
         A[2 * i + 1][3] = sp[i][0]; A[2 * i + 1][4] = sp[i][1]; A[2 * i + 1][5] = 1.0;
@@ -163,6 +178,7 @@ bool pp_person_transform(const double* bb, int out_w, int out_h, float cs[4], Pe
     if (!solve6(A, b, M)) {
         // singular (zero-size box): OpenCV returns zeros -> D == 0 -> all-zero inverse map
         for (double& m : M) m = 0.0;
+    }
     }
     double D = M[0] * M[4] - M[1] * M[3];
     D = D != 0 ? 1.0 / D : 0;
@@ -208,10 +224,12 @@ extern "C" int pp_crop_affine_normalize(pp_ctx* ctx, const uint8_t* frames, int 
     if (n_person <= 0) return PP_OK;
     for (int c = 0; c < 3; ++c) PP_REQUIRE(chan_map[c] >= 0 && chan_map[c] < 3, "chan_map[%d] out of range", c);
     std::vector<PersonXform> xf(n_person);
+    const int udp = (flip >> 1) & 1;   // bit 1 of `flip`: UDP transform
+    flip &= 1;
     for (int i = 0; i < n_person; ++i) {
         PP_REQUIRE(frame_idx[i] >= 0 && frame_idx[i] < n_frames, "frame_idx[%d]=%d out of range", i, frame_idx[i]);
         float cs[4];
-        pp_person_transform(bbox_tlwh + 4 * i, out_w, out_h, cs, &xf[i]);
+        pp_person_transform(bbox_tlwh + 4 * i, out_w, out_h, cs, &xf[i], udp);
         xf[i].frame = frame_idx[i];
         if (center_scale) memcpy(center_scale + 4 * i, cs, sizeof(cs));
         if (valid) valid[i] = xf[i].valid;

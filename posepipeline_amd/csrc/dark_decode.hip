@@ -103,10 +103,13 @@ __global__ __launch_bounds__(256) void flip_merge_decode_kernel(DecodeArgs a) {
         py = -1;
     }
 
-    if (a.post == 1) {
-        // ---- 2. zero-padded separable Gaussian blur (row pass k = 0..ks-1 sequential, column pass
-        //         centre + symmetric pairs), float32 without contraction -----------------------------
+    if (a.post == 1 || a.post == 2) {
+        // ---- 2. separable Gaussian blur (row pass k = 0..ks-1 sequential, column pass centre + symmetric pairs),
+        //         float32 without contraction.  post 1: mmpose pads with zeros before cv2.GaussianBlur; post 2
+        //         (post_dark_udp) calls cv2.GaussianBlur on the map itself: default border BORDER_REFLECT_101 ------
         const int ks = a.blur_kernel, r = ks >> 1;
+        const bool reflect = a.post == 2;
+        auto mirror = [](int p, int n) { p = p < 0 ? -p : p; p = p >= n ? 2 * (n - 1) - p : p; return min(max(p, 0), n - 1); };
         __syncthreads();
         for (int i = threadIdx.x; i < HW; i += blockDim.x) {
             const int y = i / a.w, x = i - y * a.w;
@@ -115,7 +118,7 @@ __global__ __launch_bounds__(256) void flip_merge_decode_kernel(DecodeArgs a) {
             bool first = true;
             for (int j = 0; j < ks; ++j) {
                 const int xx = x + j - r;
-                const float sv = ((unsigned)xx < (unsigned)a.w) ? row[xx] : 0.f;
+                const float sv = ((unsigned)xx < (unsigned)a.w) ? row[xx] : (reflect ? row[mirror(xx, a.w)] : 0.f);
                 const float t = __fmul_rn(a.gk[j], sv);
                 s = first ? t : __fadd_rn(s, t);
                 first = false;
@@ -129,15 +132,42 @@ __global__ __launch_bounds__(256) void flip_merge_decode_kernel(DecodeArgs a) {
             const int y = i / a.w, x = i - y * a.w;
             float s = __fmul_rn(a.gk[r], B[i]);
             for (int j = 1; j <= r; ++j) {
-                const float up = (y - j >= 0) ? B[i - j * a.w] : 0.f;
-                const float dn = (y + j < a.h) ? B[i + j * a.w] : 0.f;
+                const float up = (y - j >= 0) ? B[i - j * a.w] : (reflect ? B[mirror(y - j, a.h) * a.w + x] : 0.f);
+                const float dn = (y + j < a.h) ? B[i + j * a.w] : (reflect ? B[mirror(y + j, a.h) * a.w + x] : 0.f);
                 s = __fadd_rn(s, __fmul_rn(a.gk[r + j], __fadd_rn(dn, up)));
             }
             A[i] = s;
             argmax_combine(bmax, bidx, s, i);
-            (void)x;
         }
         block_argmax(bmax, bidx, s_v, s_i);   // also orders the A[] writes before the reads below
+        if (a.post == 2) {
+            // ---- post_dark_udp: clip to [0.001, 50], log, edge-replicated 3x3 stencil, Newton step with the
+            //      float64 inverse of (Hessian + float32 eps * I); applied wherever there is a peak ----------------
+            if (threadIdx.x == 0 && has_peak) {
+                auto L = [&](int yy, int xx) -> float {
+                    yy = min(max(yy, 0), a.h - 1);
+                    xx = min(max(xx, 0), a.w - 1);
+                    const float v = fminf(fmaxf(A[yy * a.w + xx], 0.001f), 50.0f);
+                    return (float)log((double)v);
+                };
+                const float i_ = L(py, px), ix1 = L(py, px + 1), iy1 = L(py + 1, px), ix1y1 = L(py + 1, px + 1);
+                const float ix1_y1_ = L(py - 1, px - 1), ix1_ = L(py, px - 1), iy1_ = L(py - 1, px);
+                const float dx = __fmul_rn(0.5f, __fsub_rn(ix1, ix1_)), dy = __fmul_rn(0.5f, __fsub_rn(iy1, iy1_));
+                const float dxx = __fadd_rn(__fsub_rn(ix1, __fmul_rn(2.0f, i_)), ix1_);
+                const float dyy = __fadd_rn(__fsub_rn(iy1, __fmul_rn(2.0f, i_)), iy1_);
+                float t = __fsub_rn(ix1y1, ix1);
+                t = __fsub_rn(t, iy1); t = __fadd_rn(t, i_); t = __fadd_rn(t, i_);
+                t = __fsub_rn(t, ix1_); t = __fsub_rn(t, iy1_); t = __fadd_rn(t, ix1_y1_);
+                const float dxy = __fmul_rn(0.5f, t);
+                const double eps = 1.1920928955078125e-07;
+                const double h00 = (double)dxx + eps, h01 = (double)dxy, h11 = (double)dyy + eps;
+                const double det = h00 * h11 - h01 * h01;
+                const double ox = (h11 * (double)dx - h01 * (double)dy) / det;
+                const double oy = (h00 * (double)dy - h01 * (double)dx) / det;
+                cxp = (float)((double)cxp - ox);
+                cyp = (float)((double)cyp - oy);
+            }
+        } else
         // ---- 3. rescale, clamp, log at the Taylor stencil; 4. Taylor step in float64 ------------
         if (threadIdx.x == 0 && 1 < px && px < a.w - 2 && 1 < py && py < a.h - 2) {
             const float scale = maxval / bmax;     // float32 / float32
@@ -182,8 +212,9 @@ __global__ __launch_bounds__(256) void flip_merge_decode_kernel(DecodeArgs a) {
     if (threadIdx.x == 0) {
         const float* cs = a.center_scale + 4 * n;
         const float s200x = __fmul_rn(cs[2], 200.0f), s200y = __fmul_rn(cs[3], 200.0f);
-        const float scale_x = (float)((double)s200x / (double)a.w);
-        const float scale_y = (float)((double)s200y / (double)a.h);
+        // use_udp (post 2): the grid spans output_size - 1
+        const float scale_x = (float)((double)s200x / (a.post == 2 ? (double)a.w - 1.0 : (double)a.w));
+        const float scale_y = (float)((double)s200y / (a.post == 2 ? (double)a.h - 1.0 : (double)a.h));
         const float hx = (float)((double)s200x * 0.5), hy = (float)((double)s200y * 0.5);
         float* o = a.kpts + ((size_t)n * a.k + k) * 3;
         o[0] = __fsub_rn(__fadd_rn(__fmul_rn(cxp, scale_x), cs[0]), hx);
@@ -214,8 +245,8 @@ int pp_enqueue_decode(hipStream_t s, const DecodeParams& p, const float* hm, con
                       const int32_t* flip_perm, const float* center_scale, float* kpts, float* merged) {
     PP_REQUIRE(p.n >= 0 && p.k > 0 && p.h > 0 && p.w > 0, "decode: bad dims");
     PP_REQUIRE(!hm_flip || flip_perm, "decode: hm_flip given without flip_perm");
-    PP_REQUIRE(p.post == 0 || p.post == 1 || p.post == -1, "decode: post must be -1 (none), 0 (default) or 1 (unbiased)");
-    PP_REQUIRE(p.post != 1 || ((p.blur_kernel & 1) && p.blur_kernel >= 3 && p.blur_kernel <= MAX_BLUR),
+    PP_REQUIRE(p.post >= -1 && p.post <= 2, "decode: post must be -1 (none), 0 (default), 1 (unbiased) or 2 (UDP)");
+    PP_REQUIRE(p.post < 1 || ((p.blur_kernel & 1) && p.blur_kernel >= 3 && p.blur_kernel <= MAX_BLUR),
                "decode: blur_kernel must be odd in [3,%d]", MAX_BLUR);
     const size_t lds = (size_t)2 * p.h * p.w * sizeof(float);
     PP_REQUIRE(lds <= 160 * 1024 - 64, "decode: heatmap %dx%d does not fit LDS", p.h, p.w);
@@ -223,7 +254,7 @@ int pp_enqueue_decode(hipStream_t s, const DecodeParams& p, const float* hm, con
     DecodeArgs a{};
     a.n = p.n; a.k = p.k; a.h = p.h; a.w = p.w;
     a.shift_heatmap = p.shift_heatmap; a.post = p.post; a.blur_kernel = p.blur_kernel;
-    if (p.post == 1) fill_gaussian_taps(a);
+    if (p.post >= 1) fill_gaussian_taps(a);
     a.hm = hm; a.hm_flip = hm_flip; a.flip_perm = flip_perm; a.center_scale = center_scale;
     a.kpts = kpts; a.merged = merged;
     static bool attr_set = false;

@@ -4,13 +4,14 @@
 //   C[M][N] = epilogue( A[M][K] . W[N][K]^T )        A, W bf16 row-major (torch nn.Linear weight layout), fp32 accumulate
 //   epilogue: + bias[N] -> GELU (erf form, optional) -> + res[m % res_mod][N] (fp32, optional) -> fp32 or bf16 store
 //
-// Structure: 256 threads = 2 x 2 waves, block tile (32 WM) x (32 WN), K step 64.  Both operand tiles go global -> LDS
-// with global_load_lds_dwordx4 (no staging registers); the LDS image is lane-linear, so the bank-conflict swizzle
-// (16-byte chunk index ^ ((row >> 1) & 7) inside each 128-byte row) is applied to the per-lane SOURCE address and
-// again when the fragments are read back with ds_read_b128.  The weights are the MFMA "A" operand and the activations
-// the "B" operand, so a lane ends up with 4 consecutive n of one row m: bias / residual / store are 16-byte (8-byte
-// for bf16) vector accesses.  Tiles are ordered in groups of 8 tile rows x all tile columns per sweep so that the
-// blocks resident on one XCD share operand tiles in its L2.
+// Structure: WAVES_M x WAVES_N waves per block, each owning a (16 WM) x (16 WN) sub-tile of the block tile, K step 64.
+// Both operand tiles go global -> LDS with global_load_lds_dwordx4 (no staging registers); the LDS image is
+// lane-linear, so the bank-conflict swizzle (16-byte chunk index ^ ((row >> 1) & 7) inside each 128-byte row) is
+// applied to the per-lane SOURCE address and again when the fragments are read back with ds_read_b128 (measured: 0
+// bank-conflict cycles).  The weights are the MFMA "A" operand and the activations the "B" operand, so a lane ends up
+// with 4 consecutive n of one row m: bias / residual / store are 16-byte (8-byte for bf16) vector accesses.  Tiles are
+// ordered in groups of 8 tile rows x all tile columns per sweep so that the blocks resident on one XCD share operand
+// tiles in its L2.
 #include "pp_internal.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -25,17 +26,37 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
     return (unsigned short)(u >> 16);
 }
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+// GELU(v) = 0.5 v (1 + erf(v / sqrt 2)); erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding
+// of the result): 1 rcp + 1 exp + 8 VALU instead of libm's branchy erff -- the epilogue of the fc1 GEMM applies it to
+// 64 values per lane.
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float x = v * 0.70710678118654752440f, ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __expf(-ax * ax);
+    const float erf_ax = fmaf(-p * t, e, 1.0f);
+    return 0.5f * v * (1.0f + copysignf(erf_ax, x));
+}
 
-template <int WM, int WN>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
-    constexpr int BM = WM * 32, BN = WN * 32;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[(BM + BN) * 128];
+// blocks the register allocator must leave room for on one CU (without it the 256-thread variants spread into AGPRs and
+// lose occupancy, which is what hides the load latency here)
+constexpr int min_blocks(int nw, int wm, int nstage) { return nw >= 16 ? 1 : nw >= 8 ? 2 : (wm > 4 || nstage > 1) ? 2 : 4; }
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, int NSTAGE>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, min_blocks(WAVES_M * WAVES_N, WM, NSTAGE)) void gemm_bf16_kernel(GemmArgs a) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
+    constexpr int NLA = BM / (8 * NW), NLB = BN / (8 * NW);   // global_load_lds per thread and tile (1 KiB = 8 rows each)
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // NSTAGE x (BM + BN) x 128 bytes
     unsigned char* ldsA = lds;              // activations tile [BM][64] bf16 (swizzled)
     unsigned char* ldsB = lds + BM * 128;   // weights tile     [BN][64] bf16 (swizzled)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
 
     // tile order: XCD-contiguous ranges (blocks are dealt round-robin to the 8 XCDs), inside a range groups of 8 tile
     // rows sweep the tile columns
@@ -52,19 +73,19 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
     const int tn = in_grp / rows_here, tm = grp * GM + (in_grp - tn * rows_here);
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // global_load_lds sources: instruction i of wave w fills the 1 KiB slab (i * 4 + w) = 8 tile rows
+    // global_load_lds sources: instruction i of wave w fills the 1 KiB slab (i * NW + w) = 8 tile rows
     const int lrow = lane >> 3, slot = lane & 7;
-    const __bf16* gA[BM / 32];
-    const __bf16* gB[BN / 32];
+    const __bf16* gA[NLA];
+    const __bf16* gB[NLB];
 #pragma unroll
-    for (int i = 0; i < BM / 32; ++i) {
-        const int row = (i * 4 + wave) * 8 + lrow;
+    for (int i = 0; i < NLA; ++i) {
+        const int row = (i * NW + wave) * 8 + lrow;
         const int chunk = slot ^ ((row >> 1) & 7);
         gA[i] = reinterpret_cast<const __bf16*>(a.A) + (size_t)min(m0 + row, a.M - 1) * a.K + chunk * 8;
     }
 #pragma unroll
-    for (int i = 0; i < BN / 32; ++i) {
-        const int row = (i * 4 + wave) * 8 + lrow;
+    for (int i = 0; i < NLB; ++i) {
+        const int row = (i * NW + wave) * 8 + lrow;
         const int chunk = slot ^ ((row >> 1) & 7);
         gB[i] = reinterpret_cast<const __bf16*>(a.B) + (size_t)(n0 + row) * a.K + chunk * 8;
     }
@@ -80,25 +101,45 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
     const unsigned char* rdB = ldsB + (wn * WN * 16 + r16) * 128;
     const int c0 = ((0 + kg) ^ sw) << 4, c1 = ((4 + kg) ^ sw) << 4;
 
-    const int nk = a.K >> 6;
-    for (int kt = 0; kt < nk; ++kt) {
+    // K loop.  NSTAGE 1: load, wait, multiply -- latency is hidden by the other blocks resident on the CU.
+    // NSTAGE 2: the global_load_lds of tile kt + 1 are in flight while tile kt is multiplied (raw s_barrier + counted
+    // vmcnt: a __syncthreads() would make the compiler drain the loads first).
+    constexpr int STAGE = (BM + BN) * 128;
+    auto issue = [&](int stage) {
 #pragma unroll
-        for (int i = 0; i < BM / 32; ++i) {
+        for (int i = 0; i < NLA; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gA[i],
-                                             (__attribute__((address_space(3))) void*)(ldsA + (i * 4 + wave) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(ldsA + stage * STAGE + (i * NW + wave) * 1024),
+                                             16, 0, 0);
             gA[i] += 64;
         }
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) {
+        for (int i = 0; i < NLB; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gB[i],
-                                             (__attribute__((address_space(3))) void*)(ldsB + (i * 4 + wave) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(ldsB + stage * STAGE + (i * NW + wave) * 1024),
+                                             16, 0, 0);
             gB[i] += 64;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    };
+    const int nk = a.K >> 6;
+    if constexpr (NSTAGE == 2) issue(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = NSTAGE == 2 ? (kt & 1) : 0;
+        if constexpr (NSTAGE == 2) {
+            if (kt + 1 < nk) {
+                issue(cur ^ 1);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + NLB) : "memory");   // tile kt landed, kt + 1 in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+            issue(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();          // every wave's part of tile kt has landed
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const int co = kk ? c1 : c0;
+            const int co = (kk ? c1 : c0) + cur * STAGE;
             bf16x8_t fa[WM], fb[WN];
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8_t*>(rdA + mi * 2048 + co);
@@ -110,7 +151,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
                 for (int ni = 0; ni < WN; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // the stage just read may be overwritten
     }
 
     // epilogue: lane holds C[m][n .. n + 3], m = row16 index (lane & 15), n = 4 * (lane >> 4)
@@ -153,6 +195,22 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
     for (; i < n; i += stride) y[i] = f32_to_bf16_rne(x[i]);
 }
 
+template <int WAVES_M, int WAVES_N, int WM, int WN, int NSTAGE>
+int launch_cfg(const GemmArgs& a, hipStream_t stream) {
+    constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
+    constexpr int lds = NSTAGE * (BM + BN) * 128;
+    auto* kern = &gemm_bf16_kernel<WAVES_M, WAVES_N, WM, WN, NSTAGE>;
+    static bool configured = false;
+    if (!configured && lds > 64 * 1024) {
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured = true;
+    }
+    const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, stream, a);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}
+
 }  // namespace
 
 int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream) {
@@ -163,22 +221,27 @@ int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream)
     return PP_OK;
 }
 
+// Tile configurations (POSEPIPE_GEMM_CFG forces one; tests run all of them):
+//   0  128 x 128, 4 waves (64 x 64 each), 1 stage,  32 KiB LDS -> 4 blocks / CU
+//   1  256 x 128, 8 waves (64 x 64 each), 1 stage,  48 KiB LDS -> 2 blocks / CU, 3/4 of the L2 -> LDS bytes per FLOP
+//   2  256 x 256, 16 waves (64 x 64 each), 2 stages, 128 KiB LDS -> 1 block / CU, 1/2 of the bytes, in-block prefetch
+//   3  256 x 128, 4 waves (128 x 64 each), 1 stage,  48 KiB LDS -> 2 blocks / CU, 3/4 of the LDS reads per FLOP
+//   4  128 x 128, 4 waves, 2 stages, 64 KiB LDS
 int pp_launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
     PP_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm_bf16: empty problem");
     PP_REQUIRE(a.K % 64 == 0, "gemm_bf16: K = %d must be a multiple of 64", a.K);
     PP_REQUIRE(a.N % 128 == 0, "gemm_bf16: N = %d must be a multiple of 128", a.N);
-    const int tiles_n = a.N / 128;
-    const char* env_tile = getenv("POSEPIPE_GEMM_TILE");   // tests / A-B runs: force the 128- or 256-row tile
-    const int variant = env_tile ? atoi(env_tile) : 0;
-    // 256-row tiles when they still fill the chip twice over
-    const bool big = variant == 256 || (variant == 0 && (long)((a.M + 255) / 256) * tiles_n >= 1024);
-    if (big) {
-        const int tiles_m = (a.M + 255) / 256;
-        hipLaunchKernelGGL((gemm_bf16_kernel<8, 4>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, a);
-    } else {
-        const int tiles_m = (a.M + 127) / 128;
-        hipLaunchKernelGGL((gemm_bf16_kernel<4, 4>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, a);
+    const char* env_cfg = getenv("POSEPIPE_GEMM_CFG");
+    // default: 256 x 128 tiles once they give every CU a block (measured on the ViT-H shapes at M = 12288: 831 / 721 /
+    // 720 / 931 TFLOP/s for qkv / proj / fc1 / fc2 vs 785 / 673 / 716 / 844 with 128 x 128 tiles); small problems keep
+    // the 128 x 128 tile for the larger grid
+    int cfg = env_cfg ? atoi(env_cfg) : ((long)((a.M + 255) / 256) * (a.N / 128) >= 256 ? 1 : 0);
+    if (cfg == 2 && a.N % 256 != 0) cfg = 1;
+    switch (cfg) {
+        case 1: return launch_cfg<4, 2, 4, 4, 1>(a, stream);
+        case 2: return launch_cfg<4, 4, 4, 4, 2>(a, stream);
+        case 3: return launch_cfg<2, 2, 8, 4, 1>(a, stream);
+        case 4: return launch_cfg<2, 2, 4, 4, 2>(a, stream);
+        default: return launch_cfg<2, 2, 4, 4, 1>(a, stream);
     }
-    PP_HIP_CHECK(hipGetLastError());
-    return PP_OK;
 }

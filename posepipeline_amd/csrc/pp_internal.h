@@ -117,6 +117,8 @@ int pp_vit_encoder_create(const float* params, int tokens, int dim, int depth, i
                           hipStream_t stream, pp_vit_encoder** out);
 void pp_vit_encoder_destroy(pp_vit_encoder* e);
 int pp_vit_encoder_run(pp_vit_encoder* e, const float* in, float* out, int batch, hipStream_t stream);
+void pp_vit_encoder_set_timing(pp_vit_encoder* e, int enable);
+int pp_vit_encoder_get_timing(pp_vit_encoder* e, float ms3[3], int* n_gemm);
 
 // ---- top-down pre/post (crop_affine.hip, dark_decode.hip) ----------------------------------------
 struct PersonXform {
@@ -125,7 +127,8 @@ struct PersonXform {
     int valid;
 };
 // mmpose `_box2cs` + `get_affine_transform(rot=0)` + OpenCV's inversion; false for NaN boxes
-bool pp_person_transform(const double* bbox_tlwh, int out_w, int out_h, float center_scale[4], PersonXform* t);
+// udp != 0: mmpose `TopDownAffine(use_udp=True)` (get_warp_matrix on image_size - 1) instead of the 3-point affine
+bool pp_person_transform(const double* bbox_tlwh, int out_w, int out_h, float center_scale[4], PersonXform* t, int udp = 0);
 // all pointers are device pointers; nothing is synchronised
 int pp_enqueue_crop(hipStream_t s, const uint8_t* frames, int h, int w, const PersonXform* xf, int n_person,
                     int out_w, int out_h, const float* lut, const int32_t chan_map[3], int flip, float* out,

@@ -128,7 +128,7 @@ int pp_topdown_run(pp_topdown* t, const uint8_t* frames, int n_frames, int h, in
     hipStream_t s = t->ctx->stream;
     for (int i = 0; i < n_person; ++i) {
         PP_REQUIRE(frame_idx[i] >= 0 && frame_idx[i] < n_frames, "frame_idx[%d]=%d out of range", i, frame_idx[i]);
-        pp_person_transform(bbox_tlwh + 4 * i, t->in_w, t->in_h, t->h_cs + 4 * i, &t->h_xf[i]);
+        pp_person_transform(bbox_tlwh + 4 * i, t->in_w, t->in_h, t->h_cs + 4 * i, &t->h_xf[i], t->post == 2);
         t->h_xf[i].frame = frame_idx[i];
         if (valid) valid[i] = t->h_xf[i].valid;
     }

@@ -282,11 +282,43 @@ struct pp_vit_encoder {
     void* scratch = nullptr;           // X fp32 | h bf16 | qkv bf16 | att bf16 | mlp bf16
     float* X = nullptr;
     unsigned short *hbuf = nullptr, *qkv = nullptr, *att = nullptr, *mlp = nullptr;
+    // optional per-kernel-family timing (bench.py's roofline leg): one event after every launch
+    bool timing = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> ev_kind;          // family of the launch that ENDS at event i: 0 gemm, 1 layernorm, 2 attention
+    size_t ev_used = 0;
+    int n_gemm = 0;
+    void mark(int kind, hipStream_t s) {
+        if (!timing) return;
+        if (ev_used == ev.size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            ev.push_back(e);
+            ev_kind.push_back(kind);
+        }
+        ev_kind[ev_used] = kind;
+        (void)hipEventRecord(ev[ev_used++], s);
+    }
     ~pp_vit_encoder() {
+        for (auto e : ev) (void)hipEventDestroy(e);
         if (wbf16) (void)hipFree(wbf16);
         if (scratch) (void)hipFree(scratch);
     }
 };
+
+void pp_vit_encoder_set_timing(pp_vit_encoder* e, int enable) { e->timing = enable != 0; }
+
+// {gemm, layernorm, attention} milliseconds and the GEMM launch count of the last run (the stream must be idle)
+int pp_vit_encoder_get_timing(pp_vit_encoder* e, float ms3[3], int* n_gemm) {
+    ms3[0] = ms3[1] = ms3[2] = 0.f;
+    for (size_t i = 1; i < e->ev_used; ++i) {
+        float ms = 0.f;
+        PP_HIP_CHECK(hipEventElapsedTime(&ms, e->ev[i - 1], e->ev[i]));
+        ms3[e->ev_kind[i]] += ms;
+    }
+    if (n_gemm) *n_gemm = e->n_gemm;
+    return PP_OK;
+}
 
 void pp_vit_encoder_destroy(pp_vit_encoder* e) { delete e; }
 
@@ -343,26 +375,36 @@ int pp_vit_encoder_run(pp_vit_encoder* e, const float* in, float* out, int batch
     const int M = batch * e->tokens, D = e->dim, H = e->hidden;
     const float eps = 1e-6f;
     int rc;
+    e->ev_used = 0;
+    e->n_gemm = 0;
+    e->mark(1, stream);   // start of the first interval
     auto gemm = [&](const void* A, const void* W, const float* bias, const float* res, void* C, int N, int K, int act, int obf) {
         GemmArgs g{};
         g.A = A; g.B = W; g.bias = bias; g.res = res; g.C = C; g.M = M; g.N = N; g.K = K; g.act = act; g.out_bf16 = obf;
-        return pp_launch_gemm_bf16(g, stream);
+        const int r = pp_launch_gemm_bf16(g, stream);
+        e->mark(0, stream);
+        ++e->n_gemm;
+        return r;
+    };
+    auto ln = [&](const float* x, const float* pos, float* x_out, const float* g, const float* b, void* y, int obf) {
+        const int r = pp_launch_layernorm(x, pos, pos ? e->tokens : 0, x_out, g, b, M, D, eps, y, obf, stream);
+        e->mark(1, stream);
+        return r;
     };
     for (int i = 0; i < e->depth; ++i) {
         const VitBlock& b = e->blocks[i];
-        if (i == 0)   // x = patch_embed + pos, h = LN1(x)
-            rc = pp_launch_layernorm(in, e->pos, e->tokens, e->X, b.ln1_g, b.ln1_b, M, D, eps, e->hbuf, 1, stream);
-        else
-            rc = pp_launch_layernorm(e->X, nullptr, 0, nullptr, b.ln1_g, b.ln1_b, M, D, eps, e->hbuf, 1, stream);
+        if (i == 0) rc = ln(in, e->pos, e->X, b.ln1_g, b.ln1_b, e->hbuf, 1);   // x = patch_embed + pos, h = LN1(x)
+        else rc = ln(e->X, nullptr, nullptr, b.ln1_g, b.ln1_b, e->hbuf, 1);
         if (rc != PP_OK) return rc;
         if ((rc = gemm(e->hbuf, b.wqkv, b.bqkv, nullptr, e->qkv, 3 * D, D, 0, 1)) != PP_OK) return rc;
         if ((rc = pp_launch_attention(e->qkv, batch, e->tokens, e->heads, D / e->heads, e->att, stream)) != PP_OK) return rc;
+        e->mark(2, stream);
         if ((rc = gemm(e->att, b.wproj, b.bproj, e->X, e->X, D, D, 0, 0)) != PP_OK) return rc;
-        if ((rc = pp_launch_layernorm(e->X, nullptr, 0, nullptr, b.ln2_g, b.ln2_b, M, D, eps, e->hbuf, 1, stream)) != PP_OK) return rc;
+        if ((rc = ln(e->X, nullptr, nullptr, b.ln2_g, b.ln2_b, e->hbuf, 1)) != PP_OK) return rc;
         if ((rc = gemm(e->hbuf, b.w1, b.b1, nullptr, e->mlp, H, D, 1, 1)) != PP_OK) return rc;
         if ((rc = gemm(e->mlp, b.w2, b.b2, e->X, e->X, D, H, 0, 0)) != PP_OK) return rc;
     }
-    return pp_launch_layernorm(e->X, nullptr, 0, nullptr, e->lnf_g, e->lnf_b, M, D, eps, out, 0, stream);
+    return ln(e->X, nullptr, nullptr, e->lnf_g, e->lnf_b, out, 0);
 }
 
 // ---- C ABI: the building blocks on their own (device pointers) ------------------------------------------------

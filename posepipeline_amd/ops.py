@@ -22,8 +22,9 @@ def normalize_lut(mean=TOPDOWN_MEAN, std=TOPDOWN_STD) -> np.ndarray:
 
 
 def crop_affine_normalize(ctx: L.Context, frames: np.ndarray, frame_idx, bboxes, out_wh=(288, 384), lut=None,
-                          chan_map=(0, 1, 2), flip=True, want_crop_u8=False):
+                          chan_map=(0, 1, 2), flip=True, want_crop_u8=False, udp=False):
     """frames [F][H][W][3] u8; bboxes [P][4] float64 TLWH (NaN row = absent).
+    udp: TopDownAffine(use_udp=True) transform (ViTPose configs) instead of the 3-point affine.
     Returns dict(out=[P or 2P][out_h][out_w][4] fp32, center_scale=[P][4], valid=[P], crop_u8=...)."""
     frames = np.ascontiguousarray(frames, dtype=np.uint8)
     f, h, w, c = frames.shape
@@ -40,7 +41,7 @@ def crop_affine_normalize(ctx: L.Context, frames: np.ndarray, frame_idx, bboxes,
     valid = np.zeros((p,), dtype=np.int32)
     crop = np.empty((p, oh, ow, 3), dtype=np.uint8) if want_crop_u8 else None
     L.check(ctx.lib.pp_crop_affine_normalize(ctx.handle, L.ptr(frames), f, h, w, L.ptr(frame_idx), L.ptr(bboxes), p, ow, oh,
-                                             L.ptr(lut), L.ptr(cm), int(flip), L.ptr(out), L.ptr(cs), L.ptr(crop),
+                                             L.ptr(lut), L.ptr(cm), int(bool(flip)) | (2 if udp else 0), L.ptr(out), L.ptr(cs), L.ptr(crop),
                                              L.ptr(valid), L.PP_MEM_HOST), "pp_crop_affine_normalize")
     return dict(out=out, center_scale=cs, valid=valid, crop_u8=crop)
 
@@ -55,7 +56,7 @@ def flip_merge_decode(ctx: L.Context, hm: np.ndarray, hm_flip, center_scale, fli
     cs = np.ascontiguousarray(center_scale, np.float32).reshape(n, 4)
     kp = np.empty((n, k, 3), dtype=np.float32)
     merged = np.empty_like(hm) if want_merged else None
-    post_i = {"unbiased": 1, "default": 0, None: -1}[post]
+    post_i = {"unbiased": 1, "default": 0, "udp": 2, None: -1}[post]   # "udp": UDP crop + DARK-UDP decode (ViTPose)
     L.check(ctx.lib.pp_flip_merge_decode(ctx.handle, L.ptr(hm), L.ptr(hf), n, k, h, w, L.ptr(perm), int(shift_heatmap),
                                          post_i, int(blur_kernel), L.ptr(cs), L.ptr(kp), L.ptr(merged), L.PP_MEM_HOST),
             "pp_flip_merge_decode")
@@ -87,7 +88,7 @@ class TopDown:
         lut = normalize_lut() if lut is None else np.ascontiguousarray(lut, np.float32)
         cm = np.asarray(chan_map, np.int32)
         perm = None if flip_perm is None else np.ascontiguousarray(flip_perm, np.int32)
-        post_i = {"unbiased": 1, "default": 0, None: -1}[post]
+        post_i = {"unbiased": 1, "default": 0, "udp": 2, None: -1}[post]   # "udp": UDP crop + DARK-UDP decode (ViTPose)
         h = C.c_void_p()
         L.check(self.ctx.lib.pp_topdown_create(net.handle, net.prog.named[in_name], net.prog.named[out_name], self.k,
                                                L.ptr(perm), int(shift_heatmap), post_i, int(blur_kernel), L.ptr(lut),

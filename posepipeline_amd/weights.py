@@ -31,7 +31,7 @@ def load_state_dict(path: str, key_candidates=("state_dict", "model_pos")) -> di
     return {k: v.detach().cpu().numpy() for k, v in sd.items() if hasattr(v, "detach")}
 
 
-def get_state_dict(relpath: str, shapes: dict, seed: int) -> dict:
+def get_state_dict(relpath: str, shapes: dict, seed: int, synth=None) -> dict:
     path = os.path.join(model_data_dir(), relpath)
     if os.path.exists(path):
         sd = load_state_dict(path)
@@ -40,6 +40,8 @@ def get_state_dict(relpath: str, shapes: dict, seed: int) -> dict:
             raise KeyError(f"{path}: missing parameters {missing[:5]}{'...' if len(missing) > 5 else ''}")
         return {k: np.asarray(sd[k], np.float32) for k in shapes}
     if os.environ.get("POSEPIPE_SYNTHETIC_WEIGHTS") == "1":
+        if synth is not None:                      # model-specific generator (ViT: 1/fan_in linear layers)
+            return synth(shapes, seed)
         from .models.synth import synth_state_dict
         return synth_state_dict(shapes, seed)
     raise FileNotFoundError(f"{path} (set POSEPIPE_SYNTHETIC_WEIGHTS=1 to run with seeded synthetic weights)")

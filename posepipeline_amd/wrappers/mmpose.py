@@ -16,7 +16,7 @@ from __future__ import annotations
 import numpy as np
 
 from .. import _lib, ops, weights
-from ..models import hrnet
+from ..models import hrnet, vitpose
 from ..program import Net
 from ..video import open_video
 
@@ -48,6 +48,11 @@ _METHODS = {
     # BASELINE.json configs[0-1] name the W32 256x192 member of the family (mmpose's plain W32 config decodes 'default')
     "HRNet_W32_COCO": (hrnet.hrnet_w32_256x192, "mmpose/checkpoints/hrnet_w32_coco_256x192-c78dce93_20200708.pth",
                        17, hrnet.COCO_FLIP_PAIRS, "default", 11),
+    # BASELINE.json configs[4]; NOT a method of the reference wrapper (ViTPose is absent from /root/reference): the
+    # published ViTPose COCO configs (UDP crop / DARK-UDP decode, modulate kernel 11, no heatmap shift), bf16 MFMA encoder
+    "ViTPose_H_COCO": (vitpose.vitpose_huge, "mmpose/checkpoints/vitpose-h.pth", 17, hrnet.COCO_FLIP_PAIRS, "udp", 11),
+    "ViTPose_L_COCO": (vitpose.vitpose_large, "mmpose/checkpoints/vitpose-l.pth", 17, hrnet.COCO_FLIP_PAIRS, "udp", 11),
+    "ViTPose_B_COCO": (vitpose.vitpose_base, "mmpose/checkpoints/vitpose-b.pth", 17, hrnet.COCO_FLIP_PAIRS, "udp", 11),
 }
 
 BATCH = 32
@@ -62,10 +67,16 @@ def _model(method, device=0):
             raise UnboundLocalError(f"local variable 'pose_cfg' referenced before assignment (unknown method {method!r})")
         spec_fn, ckpt, k, pairs, post, blur = _METHODS[method]
         spec = spec_fn(k)
-        sd = weights.get_state_dict(ckpt, hrnet.hrnet_param_shapes(spec), seed=1)
         ctx = _lib.Context(device)
-        net = Net(ctx, hrnet.build_hrnet_program(spec, sd), max_batch=2 * BATCH)
-        td = ops.TopDown(net, num_joints=k, flip_perm=hrnet.flip_perm(k, pairs), shift_heatmap=True, post=post,
+        if isinstance(spec, vitpose.VitPoseSpec):
+            sd = weights.get_state_dict(ckpt, vitpose.vitpose_param_shapes(spec), seed=1,
+                                        synth=lambda shapes, seed: vitpose.synth_params(spec, seed))
+            prog = vitpose.build_vitpose_program(spec, sd)
+        else:
+            sd = weights.get_state_dict(ckpt, hrnet.hrnet_param_shapes(spec), seed=1)
+            prog = hrnet.build_hrnet_program(spec, sd)
+        net = Net(ctx, prog, max_batch=2 * BATCH)
+        td = ops.TopDown(net, num_joints=k, flip_perm=hrnet.flip_perm(k, pairs), shift_heatmap=post != "udp", post=post,
                          blur_kernel=blur, chan_map=(0, 1, 2))
         _cache[(method, device)] = (ctx, net, td, k)
     return _cache[(method, device)]

@@ -1,0 +1,122 @@
+"""ViTPose top-down stage (UDP crop -> ViT program -> flip-merge + DARK-UDP decode) vs the CPU oracle.
+
+The UDP crop is integer / lookup arithmetic: bit-exact.  The decode is float arithmetic on given heatmaps: 1e-3 px
+(north_star tolerance).  The fused stage is checked by composition: its input tensor and its keypoints are compared
+with the oracle applied to the SAME frames / the SAME (GPU) heatmaps; the bf16 network itself is covered by
+tests/test_gpu_vit.py with its own tolerance, because argmax over heatmaps of a randomly initialised network is not
+stable under 1e-3 perturbations.
+"""
+import numpy as np
+import pytest
+
+from oracle import decode as odec
+from oracle import preprocess as opre
+from posepipeline_amd import ops
+from posepipeline_amd.models import hrnet
+from posepipeline_amd.models import vitpose as MV
+from posepipeline_amd.program import Net
+from tests.test_gpu_stages import synth_frames
+
+pytestmark = pytest.mark.gpu
+
+BBOXES = np.array([
+    [100.3, 40.7, 80.2, 190.9],
+    [-30.5, -20.25, 200.0, 150.0],     # over the top-left corner
+    [400.0, 200.0, 120.0, 100.0],      # over the bottom-right corner, wide box
+    [np.nan, np.nan, np.nan, np.nan],  # absent person
+    [10.0, 10.0, 30.0, 60.0],
+    [0.0, 0.0, 480.0, 270.0],
+], dtype=np.float64)
+FIDX = np.array([0, 1, 2, 0, 1, 2], dtype=np.int32)
+
+
+def test_udp_crop_bit_exact(ctx):
+    rng = np.random.default_rng(21)
+    frames = synth_frames(rng, 3, 270, 480)
+    res = ops.crop_affine_normalize(ctx, frames, FIDX, BBOXES, out_wh=(192, 256), flip=True, want_crop_u8=True, udp=True)
+    out = res["out"]
+    for i, bb in enumerate(BBOXES):
+        if np.isnan(bb).any():
+            assert res["valid"][i] == 0 and not out[i].any()
+            continue
+        t, c, s, crop = opre.top_down_input_udp(frames[FIDX[i]][:, :, ::-1], bb, (192, 256))
+        assert np.array_equal(res["center_scale"][i], np.concatenate([c, s]))
+        assert np.array_equal(res["crop_u8"][i], crop), f"person {i}: {np.abs(res['crop_u8'][i].astype(int) - crop).max()}"
+        assert np.array_equal(np.transpose(out[i][:, :, :3], (2, 0, 1)), t)
+        assert np.array_equal(out[len(BBOXES) + i], out[i][:, ::-1])
+    # the UDP transform is not the 3-point one: a half-pixel-order shift must be visible against the plain crop
+    plain = ops.crop_affine_normalize(ctx, frames, FIDX, BBOXES, out_wh=(192, 256), flip=False, want_crop_u8=True)
+    assert not np.array_equal(plain["crop_u8"][0], res["crop_u8"][0])
+
+
+def _gaussian_maps(rng, n, k, h, w, perm):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    hm = np.zeros((n, k, h, w), np.float32)
+    hmf = np.zeros_like(hm)
+    for i in range(n):
+        for j in range(k):
+            cx, cy = rng.uniform(0, w - 1), rng.uniform(0, h - 1)
+            if j == 3:
+                cx, cy = 0.2, 0.4              # corner: edge-replicated stencil
+            if j == 4:
+                cx, cy = w - 1.3, h - 1.2
+            g = np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * 2.0 ** 2)).astype(np.float32)
+            hm[i, j] = g * rng.uniform(0.3, 1.0) + rng.normal(0, 0.005, (h, w))
+            gf = np.exp(-((xx - (w - 1 - cx)) ** 2 + (yy - cy) ** 2) / (2 * 2.0 ** 2)).astype(np.float32)
+            hmf[i, perm[j]] = gf * rng.uniform(0.3, 1.0) + rng.normal(0, 0.005, (h, w))
+    return hm, hmf
+
+
+def test_dark_udp_decode(ctx):
+    rng = np.random.default_rng(8)
+    n, k, h, w = 3, 17, 64, 48
+    perm = hrnet.flip_perm(k)
+    hm, hmf = _gaussian_maps(rng, n, k, h, w, perm)
+    hm[1, 7] = -np.abs(hm[1, 7]) - 1e-3         # no positive peak: coordinates stay at -1 (stated deviation)
+    hmf[1, perm[7]] = -np.abs(hmf[1, perm[7]]) - 1e-3
+    center = rng.uniform(100, 900, (n, 2)).astype(np.float32)
+    scale = rng.uniform(0.5, 4.0, (n, 2)).astype(np.float32)
+    ref, ref_merged = odec.decode_topdown_udp(hm, hmf, hrnet.COCO_FLIP_PAIRS, center, scale, kernel=11)
+    got, merged = ops.flip_merge_decode(ctx, hm, hmf, np.concatenate([center, scale], 1), flip_perm=perm, shift_heatmap=False,
+                                        post="udp", blur_kernel=11, want_merged=True)
+    assert np.array_equal(merged, ref_merged)
+    assert np.array_equal(got[:, :, 2], ref[:, :, 2])
+    err = np.abs(got[:, :, :2] - ref[:, :, :2]).max()
+    assert err <= 1e-3, err
+    # sub-pixel refinement actually happened: decoded != plain argmax back-mapping
+    plain, _ = ops.flip_merge_decode(ctx, hm, hmf, np.concatenate([center, scale], 1), flip_perm=perm, shift_heatmap=False,
+                                     post=None)
+    assert np.abs(got[:, :, :2] - plain[:, :, :2]).max() > 0.05
+
+
+def test_vitpose_topdown_composition(ctx):
+    spec = MV.VitPoseSpec(dim=640, depth=2, heads=8, mlp_ratio=4, num_joints=17, deconv=(64, 64))
+    p = MV.synth_params(spec, seed=4)
+    n = len(BBOXES)
+    net = Net(ctx, MV.build_vitpose_program(spec, p), max_batch=2 * n)
+    perm = hrnet.flip_perm(17)
+    td = ops.TopDown(net, num_joints=17, flip_perm=perm, shift_heatmap=False, post="udp", blur_kernel=11)
+    rng = np.random.default_rng(31)
+    frames = synth_frames(rng, 3, 270, 480)
+    kp, valid = td.run(frames, FIDX, BBOXES)
+    assert list(valid) == [1, 1, 1, 0, 1, 1]
+    x = net.read("input", 2 * n)
+    hm = net.read("output", 2 * n).reshape(2 * n, 17, *spec.heatmap_hw)
+    cs = []
+    for i, bb in enumerate(BBOXES):
+        if np.isnan(bb).any():
+            assert not x[i].any() and not kp[i].any()
+            cs.append(np.zeros(4, np.float32))
+            continue
+        t, c, s, _ = opre.top_down_input_udp(frames[FIDX[i]][:, :, ::-1], bb, (192, 256))
+        assert np.array_equal(np.transpose(x[i][:, :, :3], (2, 0, 1)), t)
+        assert np.array_equal(x[n + i], x[i][:, ::-1])
+        cs.append(np.concatenate([c, s]))
+    cs = np.stack(cs)
+    ref, _ = odec.decode_topdown_udp(hm[:n], hm[n:], hrnet.COCO_FLIP_PAIRS, cs[:, :2], cs[:, 2:], kernel=11)
+    ok = valid.astype(bool)
+    assert np.array_equal(kp[ok][:, :, 2], ref[ok][:, :, 2])
+    err = np.abs(kp[ok][:, :, :2] - ref[ok][:, :, :2]).max()
+    assert err <= 1e-3, err
+    td.close()
+    net.close()
