@@ -43,7 +43,9 @@ __device__ __forceinline__ float gelu_erf(float v) {
 
 // blocks the register allocator must leave room for on one CU (without it the 256-thread variants spread into AGPRs and
 // lose occupancy, which is what hides the load latency here)
-constexpr int min_blocks(int nw, int wm, int nstage) { return nw >= 16 ? 1 : nw >= 8 ? 2 : (wm > 4 || nstage > 1) ? 2 : 4; }
+constexpr int min_blocks(int nw, int wm, int nstage) {
+    return nw >= 16 ? 1 : nw >= 8 ? (wm > 4 ? 1 : 2) : (wm > 4 || nstage > 1) ? 2 : 4;
+}
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int NSTAGE>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, min_blocks(WAVES_M * WAVES_N, WM, NSTAGE)) void gemm_bf16_kernel(GemmArgs a) {
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, min_blocks(WAVES_M * WAVES_
         const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = pid & 7, loc = pid >> 3;
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
-    constexpr int GM = 8;
+    const int GM = a.group_m;
     const int per_group = GM * tiles_n;
     const int grp = pid / per_group, in_grp = pid - grp * per_group;
     const int rows_here = min(GM, tiles_m - grp * GM);
@@ -227,7 +229,13 @@ int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream)
 //   2  256 x 256, 16 waves (64 x 64 each), 2 stages, 128 KiB LDS -> 1 block / CU, 1/2 of the bytes, in-block prefetch
 //   3  256 x 128, 4 waves (128 x 64 each), 1 stage,  48 KiB LDS -> 2 blocks / CU, 3/4 of the LDS reads per FLOP
 //   4  128 x 128, 4 waves, 2 stages, 64 KiB LDS
-int pp_launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
+//   5  256 x 256, 8 waves (128 x 64 each), 2 stages, 128 KiB LDS -> 1 block / CU
+int pp_launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    if (a.group_m <= 0) {
+        const char* env_gm = getenv("POSEPIPE_GEMM_GROUP_M");
+        a.group_m = env_gm ? std::max(1, atoi(env_gm)) : 4;   // measured best of {1, 2, 4, 8, 16, 48} on the ViT-H shapes
+    }
     PP_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm_bf16: empty problem");
     PP_REQUIRE(a.K % 64 == 0, "gemm_bf16: K = %d must be a multiple of 64", a.K);
     PP_REQUIRE(a.N % 128 == 0, "gemm_bf16: N = %d must be a multiple of 128", a.N);
@@ -242,6 +250,7 @@ int pp_launch_gemm_bf16(const GemmArgs& a, hipStream_t stream) {
         case 2: return launch_cfg<4, 4, 4, 4, 2>(a, stream);
         case 3: return launch_cfg<2, 2, 8, 4, 1>(a, stream);
         case 4: return launch_cfg<2, 2, 4, 4, 2>(a, stream);
+        case 5: return launch_cfg<2, 4, 8, 4, 2>(a, stream);
         default: return launch_cfg<2, 2, 4, 4, 1>(a, stream);
     }
 }

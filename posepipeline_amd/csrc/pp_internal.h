@@ -100,6 +100,7 @@ struct GemmArgs {
     int act;             // 0 none, 1 GELU (erf)
     int out_bf16;
     int res_mod;         // > 0: residual row = m % res_mod (position embedding)
+    int group_m;         // tile rows per L2 sweep group (0: default)
 };
 int pp_launch_gemm_bf16(const GemmArgs& a, hipStream_t stream);
 int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream);

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // S^T = K . Q^T puts, in each lane, 4 consecutive keys of one query per 16x16 tile -- exactly the k-slots of the next
 // MFMA's B operand when V^T's k-slots are read with the same key permutation, so P never leaves the registers.
 template <int T, int HD>
-__global__ __launch_bounds__(256) void attention_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
+__global__ __launch_bounds__(256, 2) void attention_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
                                                         int heads, float scale) {
     constexpr int HDP = (HD + 31) / 32 * 32;   // head dim padded to the MFMA K step (zeros)
     constexpr int KSTR = HDP * 2 + 16;         // bytes per K row; rows 0..15 land in 16 distinct 16-byte bank groups
@@ -135,6 +135,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const unsigned short* __
         f32x4_t s[T / 16];
 #pragma unroll
         for (int f = 0; f < T / 16; ++f) {
+            // keep the scheduler from hoisting all 36 K-fragment reads (378 registers, 1 block / CU without the fences;
+            // 95 registers and 2 blocks / CU with them)
+            if ((f & 3) == 0) __builtin_amdgcn_sched_barrier(0);
             s[f] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < HDP / 32; ++kk) {
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const unsigned short* __
         for (int df = 0; df < HD / 16; ++df) o[df] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < T / 32; ++kb) {
+            __builtin_amdgcn_sched_barrier(0);
             uint4 pp;
             pp.x = pack_bf16(s[2 * kb][0], s[2 * kb][1]);
             pp.y = pack_bf16(s[2 * kb][2], s[2 * kb][3]);
