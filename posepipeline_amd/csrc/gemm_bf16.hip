@@ -47,21 +47,26 @@ constexpr int min_blocks(int nw, int wm, int nstage) {
     return nw >= 16 ? 1 : nw >= 8 ? (wm > 4 ? 1 : 2) : (wm > 4 || nstage > 1) ? 2 : 4;
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int NSTAGE>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, min_blocks(WAVES_M * WAVES_N, WM, NSTAGE)) void gemm_bf16_kernel(GemmArgs a) {
+template <int WAVES_M, int WAVES_N, int WM, int WN, int NSTAGE, int BK>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, min_blocks(WAVES_M * WAVES_N, WM, NSTAGE * BK / 64)) void gemm_bf16_kernel(GemmArgs a) {
     constexpr int NW = WAVES_M * WAVES_N;
     constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
-    constexpr int NLA = BM / (8 * NW), NLB = BN / (8 * NW);   // global_load_lds per thread and tile (1 KiB = 8 rows each)
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split evenly over the waves");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // NSTAGE x (BM + BN) x 128 bytes
-    unsigned char* ldsA = lds;              // activations tile [BM][64] bf16 (swizzled)
-    unsigned char* ldsB = lds + BM * 128;   // weights tile     [BN][64] bf16 (swizzled)
+    constexpr int ROWB = BK * 2;             // bytes per tile row in LDS (128 / 64)
+    constexpr int CH = BK / 8;               // 16-byte chunks per row (8 / 4)
+    constexpr int RS = 1024 / ROWB;          // tile rows per 1 KiB global_load_lds slab (8 / 16)
+    constexpr int SH = BK == 64 ? 1 : 2;     // swizzle: chunk ^ ((row >> SH) & (CH - 1)) -> 16 rows x 16 B hit 16 distinct bank groups
+    constexpr int NLA = BM / (RS * NW), NLB = BN / (RS * NW);   // global_load_lds per thread and tile
+    static_assert(BK == 64 || BK == 32, "K step");
+    static_assert(BM % (RS * NW) == 0 && BN % (RS * NW) == 0, "tile rows must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // NSTAGE x (BM + BN) x ROWB bytes
+    unsigned char* ldsA = lds;               // activations tile [BM][BK] bf16 (swizzled)
+    unsigned char* ldsB = lds + BM * ROWB;   // weights tile     [BN][BK] bf16 (swizzled)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
 
-    // tile order: XCD-contiguous ranges (blocks are dealt round-robin to the 8 XCDs), inside a range groups of 8 tile
-    // rows sweep the tile columns
+    // tile order: XCD-contiguous ranges (blocks are dealt round-robin to the 8 XCDs), inside a range groups of group_m
+    // tile rows sweep the tile columns
     const int tiles_n = a.N / BN, tiles_m = (a.M + BM - 1) / BM;
     int pid = blockIdx.x;
     {
@@ -75,20 +80,20 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, min_blocks(WAVES_M * WAVES_
     const int tn = in_grp / rows_here, tm = grp * GM + (in_grp - tn * rows_here);
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // global_load_lds sources: instruction i of wave w fills the 1 KiB slab (i * NW + w) = 8 tile rows
-    const int lrow = lane >> 3, slot = lane & 7;
+    // global_load_lds sources: instruction i of wave w fills the 1 KiB slab (i * NW + w) = RS tile rows
+    const int lrow = lane / CH, slot = lane & (CH - 1);
     const __bf16* gA[NLA];
     const __bf16* gB[NLB];
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
-        const int row = (i * NW + wave) * 8 + lrow;
-        const int chunk = slot ^ ((row >> 1) & 7);
+        const int row = (i * NW + wave) * RS + lrow;
+        const int chunk = slot ^ ((row >> SH) & (CH - 1));
         gA[i] = reinterpret_cast<const __bf16*>(a.A) + (size_t)min(m0 + row, a.M - 1) * a.K + chunk * 8;
     }
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
-        const int row = (i * NW + wave) * 8 + lrow;
-        const int chunk = slot ^ ((row >> 1) & 7);
+        const int row = (i * NW + wave) * RS + lrow;
+        const int chunk = slot ^ ((row >> SH) & (CH - 1));
         gB[i] = reinterpret_cast<const __bf16*>(a.B) + (size_t)(n0 + row) * a.K + chunk * 8;
     }
 
@@ -98,63 +103,61 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, min_blocks(WAVES_M * WAVES_
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int r16 = lane & 15, kg = lane >> 4, sw = (r16 >> 1) & 7;
-    const unsigned char* rdA = ldsA + (wm * WM * 16 + r16) * 128;
-    const unsigned char* rdB = ldsB + (wn * WN * 16 + r16) * 128;
-    const int c0 = ((0 + kg) ^ sw) << 4, c1 = ((4 + kg) ^ sw) << 4;
+    const int r16 = lane & 15, kg = lane >> 4, sw = (r16 >> SH) & (CH - 1);
+    const unsigned char* rdA = ldsA + (wm * WM * 16 + r16) * ROWB;
+    const unsigned char* rdB = ldsB + (wn * WN * 16 + r16) * ROWB;
+    const int c0 = ((0 + kg) ^ sw) << 4, c1 = (((4 + kg) & (CH - 1)) ^ sw) << 4;
 
-    // K loop.  NSTAGE 1: load, wait, multiply -- latency is hidden by the other blocks resident on the CU.
-    // NSTAGE 2: the global_load_lds of tile kt + 1 are in flight while tile kt is multiplied (raw s_barrier + counted
-    // vmcnt: a __syncthreads() would make the compiler drain the loads first).
-    constexpr int STAGE = (BM + BN) * 128;
+    // K loop.
+    // NSTAGE 1: load, wait, barrier, multiply, barrier -- the load latency is hidden by the other block(s) on the CU.
+    // NSTAGE 2: wait for tile kt, ONE barrier (it also says every wave is done reading the other stage), start the loads
+    //           of tile kt + 1 into that stage, multiply tile kt while they fly.  Raw s_barrier + explicit s_waitcnt: a
+    //           __syncthreads() would make the compiler drain the loads first.
+    constexpr int STAGE = (BM + BN) * ROWB;
     auto issue = [&](int stage) {
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gA[i],
                                              (__attribute__((address_space(3))) void*)(ldsA + stage * STAGE + (i * NW + wave) * 1024),
                                              16, 0, 0);
-            gA[i] += 64;
+            gA[i] += BK;
         }
 #pragma unroll
         for (int i = 0; i < NLB; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gB[i],
                                              (__attribute__((address_space(3))) void*)(ldsB + stage * STAGE + (i * NW + wave) * 1024),
                                              16, 0, 0);
-            gB[i] += 64;
+            gB[i] += BK;
         }
     };
-    const int nk = a.K >> 6;
+    const int nk = a.K / BK;
     if constexpr (NSTAGE == 2) issue(0);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = NSTAGE == 2 ? (kt & 1) : 0;
-        if constexpr (NSTAGE == 2) {
-            if (kt + 1 < nk) {
-                issue(cur ^ 1);
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + NLB) : "memory");   // tile kt landed, kt + 1 in flight
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-        } else {
-            issue(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if constexpr (NSTAGE == 1) issue(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();          // every wave's part of tile kt has landed
+        if constexpr (NSTAGE == 2) {
+            if (kt + 1 < nk) issue(cur ^ 1);
+        }
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 32; ++kk) {
             const int co = (kk ? c1 : c0) + cur * STAGE;
             bf16x8_t fa[WM], fb[WN];
 #pragma unroll
-            for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8_t*>(rdA + mi * 2048 + co);
+            for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8_t*>(rdA + mi * 16 * ROWB + co);
 #pragma unroll
-            for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const bf16x8_t*>(rdB + ni * 2048 + co);
+            for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const bf16x8_t*>(rdB + ni * 16 * ROWB + co);
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < WN; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();          // the stage just read may be overwritten
+        if constexpr (NSTAGE == 1) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // the tile may be overwritten
+        }
     }
 
     // epilogue: lane holds C[m][n .. n + 3], m = row16 index (lane & 15), n = 4 * (lane >> 4)
@@ -197,11 +200,11 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
     for (; i < n; i += stride) y[i] = f32_to_bf16_rne(x[i]);
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int NSTAGE>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int NSTAGE, int BK = 64>
 int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
-    constexpr int lds = NSTAGE * (BM + BN) * 128;
-    auto* kern = &gemm_bf16_kernel<WAVES_M, WAVES_N, WM, WN, NSTAGE>;
+    constexpr int lds = NSTAGE * (BM + BN) * BK * 2;
+    auto* kern = &gemm_bf16_kernel<WAVES_M, WAVES_N, WM, WN, NSTAGE, BK>;
     static bool configured = false;
     if (!configured && lds > 64 * 1024) {
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -230,6 +233,8 @@ int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream)
 //   3  256 x 128, 4 waves (128 x 64 each), 1 stage,  48 KiB LDS -> 2 blocks / CU, 3/4 of the LDS reads per FLOP
 //   4  128 x 128, 4 waves, 2 stages, 64 KiB LDS
 //   5  256 x 256, 8 waves (128 x 64 each), 2 stages, 128 KiB LDS -> 1 block / CU
+//   6  256 x 128, 8 waves, 2 stages of K step 32, 48 KiB LDS -> 2 blocks / CU with the in-block prefetch
+//   7  128 x 128, 4 waves, 2 stages of K step 32, 32 KiB LDS -> 4 blocks / CU
 int pp_launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
     if (a.group_m <= 0) {
@@ -240,17 +245,21 @@ int pp_launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
     PP_REQUIRE(a.K % 64 == 0, "gemm_bf16: K = %d must be a multiple of 64", a.K);
     PP_REQUIRE(a.N % 128 == 0, "gemm_bf16: N = %d must be a multiple of 128", a.N);
     const char* env_cfg = getenv("POSEPIPE_GEMM_CFG");
-    // default: 256 x 128 tiles once they give every CU a block (measured on the ViT-H shapes at M = 12288: 831 / 721 /
-    // 720 / 931 TFLOP/s for qkv / proj / fc1 / fc2 vs 785 / 673 / 716 / 844 with 128 x 128 tiles); small problems keep
-    // the 128 x 128 tile for the larger grid
-    int cfg = env_cfg ? atoi(env_cfg) : ((long)((a.M + 255) / 256) * (a.N / 128) >= 256 ? 1 : 0);
-    if (cfg == 2 && a.N % 256 != 0) cfg = 1;
+    // default (measured on the ViT-H shapes at M = 12288, qkv / proj / fc1 / fc2 in TFLOP/s): 256 x 256 two-stage tiles
+    // 867 / 743 / 730 / 997, 256 x 128 tiles 831 / 721 / 720 / 931, 128 x 128 tiles 785 / 673 / 716 / 844; small problems
+    // keep the smaller tiles for the larger grid
+    const long rows256 = (a.M + 255) / 256;
+    int cfg = env_cfg ? atoi(env_cfg)
+                      : (a.N % 256 == 0 && rows256 * (a.N / 256) >= 128) ? 2 : (rows256 * (a.N / 128) >= 256 ? 1 : 0);
+    if ((cfg == 2 || cfg == 5) && a.N % 256 != 0) cfg = 1;
     switch (cfg) {
         case 1: return launch_cfg<4, 2, 4, 4, 1>(a, stream);
         case 2: return launch_cfg<4, 4, 4, 4, 2>(a, stream);
         case 3: return launch_cfg<2, 2, 8, 4, 1>(a, stream);
         case 4: return launch_cfg<2, 2, 4, 4, 2>(a, stream);
         case 5: return launch_cfg<2, 4, 8, 4, 2>(a, stream);
+        case 6: return launch_cfg<4, 2, 4, 4, 2, 32>(a, stream);
+        case 7: return launch_cfg<2, 2, 4, 4, 2, 32>(a, stream);
         default: return launch_cfg<2, 2, 4, 4, 1>(a, stream);
     }
 }
