@@ -108,8 +108,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const unsigned short*
         if (c < HD / 8) v = *reinterpret_cast<const uint4*>(base + (size_t)t * ld + D + h * HD + c * 8);
         *reinterpret_cast<uint4*>(sK + t * KSTR + c * 16) = v;
     }
-    for (int idx = tid; idx < T * (HD / 8); idx += 256) {
-        const int c = idx / T, t = idx - c * T;     // consecutive threads -> consecutive tokens: conflict-free LDS columns
+    // V^T: lane = token (consecutive 2-byte LDS columns: conflict-free transposed writes); each wave owns T / 4 tokens and
+    // walks the HD / 8 chunks of their rows back to back, so the 2 cache lines of a row are fetched once and hit in L1
+    // for the other chunks (a token-major sweep over all 192 tokens re-fetched every line HD / 8 times)
+    for (int c = 0; c < HD / 8; ++c) {
+        const int t = wave * (T / 4) + lane;
+        if (lane >= T / 4) continue;
         const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)t * ld + 2 * D + h * HD + c * 8);
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -369,6 +373,11 @@ int pp_vit_encoder_create(const float* params, int tokens, int dim, int depth, i
     e->qkv = reinterpret_cast<unsigned short*>(s); s += M * 3 * D * 2;
     e->att = reinterpret_cast<unsigned short*>(s); s += M * D * 2;
     e->mlp = reinterpret_cast<unsigned short*>(s);
+    // one throw-away pass on the scratch buffers: sets the kernels' dynamic-LDS attributes now, so that a later first
+    // launch inside a hipGraph capture (pp_net_capture) does not have to
+    PP_HIP_CHECK(hipMemsetAsync(e->scratch, 0, bytes, stream));
+    int rc = pp_vit_encoder_run(e.get(), e->X, e->X, 1, stream);
+    if (rc != PP_OK) return rc;
     *out = e.release();
     return PP_OK;
 }

@@ -237,6 +237,10 @@ class TopDownMethodLookup(dj.Lookup):  # pipeline.py:979-998
         {"top_down_method": 12, "top_down_method_name": "Bridging_bml_movi_87"},
         {"top_down_method": 13, "top_down_method_name": "Bridging_smpl+head_30"},
         {"top_down_method": 14, "top_down_method_name": "Bridging_smplx_42"},
+        # NOT a row of the reference (ViTPose is absent from it): BASELINE.json configs[4], ids above the reference's range
+        {"top_down_method": 100, "top_down_method_name": "ViTPoseB"},
+        {"top_down_method": 101, "top_down_method_name": "ViTPoseL"},
+        {"top_down_method": 102, "top_down_method_name": "ViTPoseH"},
     ]
 
 
@@ -265,6 +269,8 @@ class TopDownPerson(dj.Computed):  # pipeline.py:1011-1015
             key["keypoints"] = mmpose_top_down_person(key, "HRNet_W48_COCOWholeBody")
         elif method_name == "MMPoseHalpe":
             key["keypoints"] = mmpose_top_down_person(key, "HRNet_W48_HALPE")
+        elif method_name in ("ViTPoseB", "ViTPoseL", "ViTPoseH"):      # extension, see TopDownMethodLookup
+            key["keypoints"] = mmpose_top_down_person(key, "ViTPose_%s_COCO" % method_name[-1])
         else:
             raise Exception("Method not implemented")
         self.insert1(key)

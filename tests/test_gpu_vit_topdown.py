@@ -89,6 +89,57 @@ def test_dark_udp_decode(ctx):
     assert np.abs(got[:, :, :2] - plain[:, :, :2]).max() > 0.05
 
 
+def test_vitpose_method_through_the_wrapper(ctx, tmp_path, monkeypatch):
+    """`mmpose_top_down_person(key, method="ViTPose_B_COCO")` on the table shim: same table reads, same return contract
+    (zero rows for absent frames -> float64 stack) as the HRNet methods; a 2-block encoder keeps it quick."""
+    import datetime
+    monkeypatch.setenv("POSEPIPE_SYNTHETIC_WEIGHTS", "1")
+    from posepipeline_amd import djshim, pipeline as pl, video
+    from posepipeline_amd.wrappers import mmpose as wmm
+    from tests.test_gpu_pipeline import synth_clip
+    djshim.reset()
+    rng = np.random.default_rng(2)
+    frames, boxes = synth_clip(rng, 10, 240, 320)
+    path = str(tmp_path / "clip.ppvid")
+    video.write_ppvid(path, frames, fps=30.0)
+    vkey = {"video_project": "test", "filename": "clip"}
+    pl.Video().insert1({**vkey, "video": path, "start_time": datetime.datetime(2024, 1, 1)})
+    tracks = [[{"track_id": 1, "tlbr": np.r_[b[:2], b[:2] + b[2:]], "tlhw": b, "confidence": 0.9}] for b in boxes]
+    for t in (3, 4, 5, 6, 7):
+        tracks[t] = []
+    tkey = {**vkey, "tracking_method": 5}
+    pl.TrackingBboxMethod().insert1(tkey)
+    pl.TrackingBbox().insert1({**tkey, "tracks": tracks, "num_tracks": 1})
+    pl.PersonBboxValid().insert1({**tkey, "video_subject_id": 0, "keep_tracks": [1]})
+    pl.PersonBbox().populate(tkey)
+    bbox = (pl.PersonBbox & tkey).fetch1("bbox")
+    small = lambda k: MV.VitPoseSpec(dim=768, depth=2, heads=12, num_joints=k, deconv=(64, 64))   # noqa: E731
+    monkeypatch.setitem(wmm._METHODS, "ViTPose_B_COCO", (small,) + wmm._METHODS["ViTPose_B_COCO"][1:])
+    wmm._cache.clear()
+    pkey = {**tkey, "video_subject_id": 0}
+    kp = wmm.mmpose_top_down_person(pkey, method="ViTPose_B_COCO")
+    assert kp.shape == (10, 17, 3) and kp.dtype == np.float64
+    absent = np.isnan(bbox).any(axis=1)
+    assert absent.sum() == 1 and not kp[absent].any() and all(kp[i].any() for i in np.flatnonzero(~absent))
+    # the stage really ran the UDP decode on this model's maps: recompute from the program's own buffers
+    _, net, td, _ = wmm._cache[("ViTPose_B_COCO", 0)]
+    n = 10
+    hm = net.read("output", 2 * n).reshape(2 * n, 17, 64, 48)
+    cs = np.stack([np.concatenate(opre.box2cs(b, (192, 256))) if not np.isnan(b).any() else np.zeros(4, np.float32) for b in bbox])
+    ref, _ = odec.decode_topdown_udp(hm[:n], hm[n:], hrnet.COCO_FLIP_PAIRS, cs[:, :2], cs[:, 2:], kernel=11)
+    ok = ~absent
+    assert np.abs(kp[ok][:, :, :2] - ref[ok][:, :, :2]).max() <= 1e-3
+    with pytest.raises(UnboundLocalError):
+        wmm.mmpose_top_down_person(pkey, method="ViTPose_XXL")
+    # the same through the table layer: lookup row 100 ("ViTPoseB", an extension of TopDownMethodLookup) -> TopDownPerson
+    tdkey = {**pkey, "top_down_method": 100}
+    assert (pl.TopDownMethodLookup & {"top_down_method": 100}).fetch1("top_down_method_name") == "ViTPoseB"
+    pl.TopDownMethod().insert1(tdkey)
+    pl.TopDownPerson().populate(tdkey)
+    assert np.array_equal((pl.TopDownPerson & tdkey).fetch1("keypoints"), kp)
+    wmm._cache.clear()
+
+
 def test_vitpose_topdown_composition(ctx):
     spec = MV.VitPoseSpec(dim=640, depth=2, heads=8, mlp_ratio=4, num_joints=17, deconv=(64, 64))
     p = MV.synth_params(spec, seed=4)

@@ -22,7 +22,11 @@ def test_lookup_tables_match_reference_rows():
     assert (pl.TopDownMethodLookup & {"top_down_method": 0}).fetch1("top_down_method_name") == "MMPose"
     assert (pl.TopDownMethodLookup & {"top_down_method": 2}).fetch1("top_down_method_name") == "MMPoseHalpe"
     assert (pl.LiftingMethodLookup & {"lifting_method": 1}).fetch1("lifting_method_name") == "VideoPose3D"
-    assert len(pl.TrackingBboxMethodLookup()) == 8 and len(pl.TopDownMethodLookup()) == 13 and len(pl.LiftingMethodLookup()) == 7
+    assert len(pl.TrackingBboxMethodLookup()) == 8 and len(pl.LiftingMethodLookup()) == 7
+    # the reference's 13 rows keep their ids; ids >= 100 are this package's ViTPose extension (BASELINE.json configs[4])
+    ref_rows = [r for r in pl.TopDownMethodLookup().fetch(as_dict=True) if r["top_down_method"] < 100]
+    ext_rows = [r["top_down_method_name"] for r in pl.TopDownMethodLookup().fetch(as_dict=True) if r["top_down_method"] >= 100]
+    assert len(ref_rows) == 13 and ext_rows == ["ViTPoseB", "ViTPoseL", "ViTPoseH"]
 
 
 def test_primary_keys_follow_the_definitions():
