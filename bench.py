@@ -10,6 +10,7 @@ Workloads (--workload, named in config.workload):
           SURVEY.md 8(d) prescribes.
   c2      BASELINE.json configs[1]: HRNet-W32 256x192 on 64 pre-cropped persons per step (flip_test, decode).
   c5      BASELINE.json configs[4] on one GPU: ViTPose-H 256x192 (bf16 MFMA encoder) on 64 pre-cropped persons per step.
+  cascade5  the cascade of the default workload with ViTPose-H as its 2D stage (configs[4]'s full pipeline).
 One process per GPU (torchrun); ranks work on independent frame shards (weak scaling, no data-path
 collective); weights are broadcast from rank 0 over RCCL.  `value` = frames of all ranks / max-over-ranks
 wall time of exactly K steps bracketed by barrier + synchronize.
@@ -36,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cascade", choices=["cascade", "c2", "c5", "track0", "cascade0"])
+    ap.add_argument("--workload", default="cascade", choices=["cascade", "c2", "c5", "cascade5", "track0", "cascade0"])
     ap.add_argument("--chunk", type=int, default=32, help="cascade: frames per step per GPU")
     ap.add_argument("--persons", type=int, default=1, help="cascade: tracked persons per frame")
     ap.add_argument("--batch", type=int, default=64, help="c2 / c5: person-frames per step per GPU")
@@ -129,11 +130,17 @@ def run_cascade(args, D):
 
     ctx = _lib.Context(D.local_rank)
     det_sd = synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2)
-    pose_spec = hrnet.hrnet_w48_384x288()
-    pose_sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(pose_spec), seed=1)
+    vit = args.workload == "cascade5"      # configs[4]-style cascade: ViTPose-H (bf16 MFMA) as the 2D stage
+    if vit:
+        from posepipeline_amd.models import vitpose
+        pose_spec = vitpose.vitpose_huge()
+        pose_sd = vitpose.synth_params(pose_spec, seed=5)
+    else:
+        pose_spec = hrnet.hrnet_w48_384x288()
+        pose_sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(pose_spec), seed=1)
     lift_sd = synth.synth_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3)
     B, P = args.chunk, args.persons
-    cas = Cascade(ctx, det_sd, pose_sd, lift_sd, 1080, 1920, chunk=B, max_persons=P)
+    cas = Cascade(ctx, det_sd, pose_sd, lift_sd, 1080, 1920, chunk=B, max_persons=P, pose_spec=pose_spec)
     if D.world > 1:
         # the resident blobs were uploaded from locally generated (identical, seeded) weights; exercise the
         # RCCL weight broadcast the multi-GPU deployment uses and check that it delivers the same bytes
@@ -199,13 +206,25 @@ def run_cascade(args, D):
         nt.set_lanes(True)
     n_launch = len(cas.detector.prog_a.ops) + len(cas.detector.prog_b.ops) + len(cas.pose_net.prog.ops)
     flops_step = B * (cas.detector.flops_per_frame + 2 * P * cas.pose_net.prog.flops)
-    achieved = flops_step / (conv_ms * 1e-3) / 1e12
+    if vit:
+        # the fp32 conv roofline covers the detector programs only; the ViT stage is reported beside it (its own roofline
+        # line is --workload c5)
+        pose_flops = B * 2 * P * cas.pose_net.prog.flops
+        conv_ms -= stage["pose_backbone"]
+        serial_conv_ms -= serial["pose_backbone"] / 2
+        n_launch -= len(cas.pose_net.prog.ops)
+        flops_conv = flops_step - pose_flops
+    else:
+        flops_conv = flops_step
+    achieved = flops_conv / (conv_ms * 1e-3) / 1e12
     out = {
         "metric": METRIC, "value": D.world * B * K / dt, "unit": "frames/s", "n_gpus": D.world, "steps": K,
         "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[3] on one GPU per rank: 1080p detect (Faster-RCNN R50-FPN) -> SORT -> HRNet-W48 "
-                               "384x288 flip_test + DARK decode -> VideoPose3D 243-frame lifting",
+        "vs_baseline": None, "dtype": "f32 (detector, lifting) + bf16 (ViT encoder)" if vit else "f32", "data": "synthetic",
+        "config": {"workload": ("configs[4]-style cascade on one GPU per rank: 1080p detect (Faster-RCNN R50-FPN) -> SORT -> "
+                                "ViTPose-H 256x192 (bf16 MFMA encoder) flip_test + UDP decode -> VideoPose3D 243-frame lifting") if vit else
+                               ("configs[3] on one GPU per rank: 1080p detect (Faster-RCNN R50-FPN) -> SORT -> HRNet-W48 "
+                                "384x288 flip_test + DARK decode -> VideoPose3D 243-frame lifting"),
                    "frames_per_step_per_gpu": B, "persons_per_frame": P,
                    "gflop_per_frame": flops_step / B / 1e9,
                    "detector_boxes": "detector runs on every frame; downstream boxes are replayed synthetic GT (random-weight detector)"},
@@ -213,11 +232,11 @@ def run_cascade(args, D):
                      "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
                      "traffic": pmc_traffic("cascade_chunk%d_persons%d" % (B, P)),
-                     "flops_per_launch": flops_step / n_launch, "avg_launch_ms": conv_ms / n_launch, "stage_ms": stage,
+                     "flops_per_launch": flops_conv / n_launch, "avg_launch_ms": conv_ms / n_launch, "stage_ms": stage,
                      "launch_overlap": "programs run on 4 HIP streams; avg_launch_ms = wall time of the conv programs / launches "
                                        "(rocprof per-kernel durations overlap and sum to more)",
                      "serial": {"avg_launch_ms": serial_conv_ms / n_launch,
-                                "achieved": flops_step / (serial_conv_ms * 1e-3) / 1e12,
+                                "achieved": flops_conv / (serial_conv_ms * 1e-3) / 1e12,
                                 "note": "same step, one stream (pp_net_set_lanes 0): comparable with rocprofv3 --stats AverageNs "
                                         "of profiles/*_serial_kernel_stats.csv"}},
     }
@@ -242,8 +261,12 @@ def run_cascade(args, D):
                                  "note": "steady state over %d frames read once from host memory, copied into page-locked "
                                          "staging buffers by a reader thread and uploaded on a copy stream while the previous "
                                          "chunk computes (posepipeline_amd/streaming.py)" % n_seen}
+    if vit:
+        out["roofline"]["kernel"] = out["roofline"]["kernel"].replace(", HRNet-W48", "")
+        out["roofline"]["vit_stage"] = {"backbone_ms": stage["pose_backbone"], "program_tflops": pose_flops / (stage["pose_backbone"] * 1e-3) / 1e12,
+                                        "note": "ViTPose-H program (bf16 GEMMs + fp32 patch embedding / head); roofline line: --workload c5"}
     n_cpu = 1 if args.cpu_frames is None else args.cpu_frames
-    if n_cpu > 0 and D.world == 1:          # the CPU baseline is a rank-0, N=1 leg
+    if n_cpu > 0 and D.world == 1 and not vit:          # the CPU baseline is a rank-0, N=1 leg (c5 carries the ViT one)
         out["cpu_baseline"] = cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames[0], gt[0][0], cas, ctx)
     print(json.dumps(out), flush=True)
 
@@ -597,7 +620,8 @@ def main():
     args = parse()
     D = Dist()
     try:
-        {"cascade": run_cascade, "c2": run_c2, "c5": run_c5, "track0": run_track0, "cascade0": run_cascade0}[args.workload](args, D)
+        {"cascade": run_cascade, "c2": run_c2, "c5": run_c5, "cascade5": run_cascade, "track0": run_track0,
+         "cascade0": run_cascade0}[args.workload](args, D)
     finally:
         D.close()
 

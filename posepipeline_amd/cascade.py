@@ -16,6 +16,7 @@ from . import _lib as L
 from . import ops
 from .models import faster_rcnn as fr
 from .models import hrnet
+from .models import vitpose
 from .models import videopose3d as vp3d
 from .program import Net
 from .tracking import Tracker
@@ -42,8 +43,15 @@ class Cascade:
             assert tracking == "MMTrack_deepsort", tracking
             self.detector = fr.Detector(ctx, det_sd, src_h, src_w, max_frames=chunk)
         self.pose_spec = pose_spec or hrnet.hrnet_w48_384x288()
-        self.pose_net = Net(ctx, hrnet.build_hrnet_program(self.pose_spec, pose_sd), max_batch=2 * chunk * max_persons)
-        self.topdown = ops.TopDown(self.pose_net, 17, flip_perm=hrnet.flip_perm(17), post=post, blur_kernel=blur_kernel)
+        if isinstance(self.pose_spec, vitpose.VitPoseSpec):     # BASELINE.json configs[4]: ViTPose 2D stage (UDP, bf16 MFMA)
+            pose_prog = vitpose.build_vitpose_program(self.pose_spec, pose_sd)
+            post, blur_kernel, shift = "udp", 11, False
+        else:
+            pose_prog = hrnet.build_hrnet_program(self.pose_spec, pose_sd)
+            shift = True
+        self.pose_net = Net(ctx, pose_prog, max_batch=2 * chunk * max_persons)
+        self.topdown = ops.TopDown(self.pose_net, 17, flip_perm=hrnet.flip_perm(17), shift_heatmap=shift, post=post,
+                                   blur_kernel=blur_kernel)
         self.lift_spec = vp3d.VideoPose3DSpec()
         self.lift_net = Net(ctx, vp3d.build_videopose3d_program(self.lift_spec, lift_sd), max_batch=max(1, max_persons))
         self.reset()

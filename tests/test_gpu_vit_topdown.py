@@ -140,6 +140,41 @@ def test_vitpose_method_through_the_wrapper(ctx, tmp_path, monkeypatch):
     wmm._cache.clear()
 
 
+def test_cascade_with_vitpose_2d_stage(ctx):
+    """bench.py --workload cascade5 in miniature: detector -> tracker -> ViTPose (UDP) -> VideoPose3D; the 2D stage of
+    the cascade equals the stand-alone top-down stage on the same frames and boxes, the 3D stage the oracle on those."""
+    from oracle import nets as onets
+    from posepipeline_amd.cascade import Cascade
+    from posepipeline_amd.models import faster_rcnn as fr, synth
+    from posepipeline_amd.models import videopose3d as vp3d
+    from posepipeline_amd.wrappers.videopose3d import normalize_screen_coordinates
+    from tests.test_gpu_detector import synth_frame
+    rng = np.random.default_rng(13)
+    h, w = 135, 240
+    frames = np.stack([synth_frame(rng, h, w) for _ in range(4)])
+    det_sd = synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2)
+    spec = MV.VitPoseSpec(dim=640, depth=2, heads=8, deconv=(64, 64))
+    p = MV.synth_params(spec, seed=6)
+    lift_sd = synth.synth_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3)
+    cas = Cascade(ctx, det_sd, p, lift_sd, h, w, chunk=2, max_persons=1, pose_spec=spec)
+    gt = [np.array([[60 + 4 * t, 20, 130 + 4 * t, 120, 0.9]], np.float32) for t in range(4)]
+    out = [cas.step(frames[0:2], replay=gt[0:2]), cas.step(frames[2:4], replay=gt[2:4])]
+    tid = out[0]["tracks"][0][0][0]
+    k2 = np.concatenate([o["keypoints"][tid] for o in out])
+    assert k2.shape == (4, 17, 3)
+    boxes = np.array([[g[0, 0], g[0, 1], g[0, 2] - g[0, 0], g[0, 3] - g[0, 1]] for g in gt], np.float64)
+    net = Net(ctx, MV.build_vitpose_program(spec, p), max_batch=8)
+    td = ops.TopDown(net, num_joints=17, flip_perm=hrnet.flip_perm(17), shift_heatmap=False, post="udp", blur_kernel=11)
+    ref, _ = td.run(frames, np.arange(4, dtype=np.int32), boxes)
+    # same kernels, same inputs, other batch size (2 + 2 vs 4): the tile schedule does not depend on the batch, so equal
+    assert np.array_equal(k2, ref)
+    kn = normalize_screen_coordinates(k2[:, :, :2].astype(np.float64), w, h).astype(np.float32)
+    ref3 = onets.VideoPose3DRef(lift_sd).forward(onets.videopose3d_windows(kn, 121))
+    assert np.array_equal(out[1]["keypoints_3d"][tid], ref3[2:4])
+    td.close()
+    net.close()
+
+
 def test_vitpose_topdown_composition(ctx):
     spec = MV.VitPoseSpec(dim=640, depth=2, heads=8, mlp_ratio=4, num_joints=17, deconv=(64, 64))
     p = MV.synth_params(spec, seed=4)
