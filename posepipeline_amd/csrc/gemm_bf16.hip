@@ -41,6 +41,42 @@ __device__ __forceinline__ float gelu_erf(float v) {
     return 0.5f * v * (1.0f + copysignf(erf_ax, x));
 }
 
+// epilogue of one wave tile: lane holds C[m][n .. n + 3], m = mbase + 16 mi + (lane & 15), n = nbase + 16 ni + 4 (lane >> 4)
+template <int WM, int WN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[WM][WN], int mbase, int nbase, int r16, int kg) {
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) {
+        const int m = mbase + mi * 16 + r16;
+        if (m >= a.M) continue;
+        const int rrow = a.res_mod > 0 ? m % a.res_mod : m;
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            const int n = nbase + ni * 16 + kg * 4;
+            f32x4_t v = acc[mi][ni];
+            if (a.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (a.act == 1) {
+                v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
+            }
+            if (a.res) {
+                const float4 rr = *reinterpret_cast<const float4*>(a.res + (size_t)rrow * a.N + n);
+                v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+            }
+            if (a.out_bf16) {
+                ushort4 o;
+                o.x = f32_to_bf16_rne(v[0]); o.y = f32_to_bf16_rne(v[1]);
+                o.z = f32_to_bf16_rne(v[2]); o.w = f32_to_bf16_rne(v[3]);
+                *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(a.C) + (size_t)m * a.N + n) = o;
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (size_t)m * a.N + n) =
+                    make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
 // blocks the register allocator must leave room for on one CU (without it the 256-thread variants spread into AGPRs and
 // lose occupancy, which is what hides the load latency here)
 constexpr int min_blocks(int nw, int wm, int nstage) {
@@ -160,37 +196,118 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, min_blocks(WAVES_M * WAVES_
         }
     }
 
-    // epilogue: lane holds C[m][n .. n + 3], m = row16 index (lane & 15), n = 4 * (lane >> 4)
+    gemm_epilogue<WM, WN>(a, acc, m0 + wm * WM * 16, n0 + wn * WN * 16, r16, kg);
+}
+
+// Persistent form of the two-stage kernel: one block per CU walks the tile list; the first K tile of the NEXT output tile
+// is requested (global_load_lds is asynchronous and needs no registers) before the epilogue of the current one, so the
+// epilogue's loads / math / stores overlap that fetch instead of being followed by a cold pipeline start.
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void gemm_bf16_persistent_kernel(GemmArgs a) {
+    constexpr int NW = WAVES_M * WAVES_N, BK = 64, ROWB = 128, CH = 8, RS = 8;
+    constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
+    constexpr int NLA = BM / (RS * NW), NLB = BN / (RS * NW);
+    constexpr int STAGE = (BM + BN) * ROWB;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // 2 x STAGE
+    unsigned char* ldsA = lds;
+    unsigned char* ldsB = lds + BM * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int tiles_n = a.N / BN, tiles_m = (a.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    const int lrow = lane >> 3, slot = lane & 7;
+    const int r16 = lane & 15, kg = lane >> 4, sw = (r16 >> 1) & 7;
+    const unsigned char* rdA = ldsA + (wm * WM * 16 + r16) * ROWB;
+    const unsigned char* rdB = ldsB + (wn * WN * 16 + r16) * ROWB;
+    const int c0 = ((0 + kg) ^ sw) << 4, c1 = ((4 + kg) ^ sw) << 4;
+    const int nk = a.K / BK;
+
+    const __bf16* gA[NLA];
+    const __bf16* gB[NLB];
+    // virtual tile id -> (m0, n0): the XCD-aware grouped order of the non-persistent kernel over the whole tile list; a
+    // block's ids are congruent mod 8 (the grid is a multiple of 8), so it stays on its XCD's range
+    auto locate = [&](int vp, int& m0, int& n0) {
+        const int q = ntiles >> 3, r = ntiles & 7, xcd = vp & 7, loc = vp >> 3;
+        const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        const int GM = a.group_m, per_group = GM * tiles_n;
+        const int grp = pid / per_group, in_grp = pid - grp * per_group;
+        const int rows_here = min(GM, tiles_m - grp * GM);
+        const int tn = in_grp / rows_here, tm = grp * GM + (in_grp - tn * rows_here);
+        m0 = tm * BM;
+        n0 = tn * BN;
+    };
+    auto point = [&](int m0, int n0) {
 #pragma unroll
-    for (int mi = 0; mi < WM; ++mi) {
-        const int m = m0 + (wm * WM + mi) * 16 + r16;
-        if (m >= a.M) continue;
-        const int rrow = a.res_mod > 0 ? m % a.res_mod : m;
-#pragma unroll
-        for (int ni = 0; ni < WN; ++ni) {
-            const int n = n0 + (wn * WN + ni) * 16 + kg * 4;
-            f32x4_t v = acc[mi][ni];
-            if (a.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if (a.act == 1) {
-                v[0] = gelu_erf(v[0]); v[1] = gelu_erf(v[1]); v[2] = gelu_erf(v[2]); v[3] = gelu_erf(v[3]);
-            }
-            if (a.res) {
-                const float4 rr = *reinterpret_cast<const float4*>(a.res + (size_t)rrow * a.N + n);
-                v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-            }
-            if (a.out_bf16) {
-                ushort4 o;
-                o.x = f32_to_bf16_rne(v[0]); o.y = f32_to_bf16_rne(v[1]);
-                o.z = f32_to_bf16_rne(v[2]); o.w = f32_to_bf16_rne(v[3]);
-                *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(a.C) + (size_t)m * a.N + n) = o;
-            } else {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (size_t)m * a.N + n) =
-                    make_float4(v[0], v[1], v[2], v[3]);
-            }
+        for (int i = 0; i < NLA; ++i) {
+            const int row = (i * NW + wave) * RS + lrow;
+            gA[i] = reinterpret_cast<const __bf16*>(a.A) + (size_t)min(m0 + row, a.M - 1) * a.K + (slot ^ ((row >> 1) & 7)) * 8;
         }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            const int row = (i * NW + wave) * RS + lrow;
+            gB[i] = reinterpret_cast<const __bf16*>(a.B) + (size_t)(n0 + row) * a.K + (slot ^ ((row >> 1) & 7)) * 8;
+        }
+    };
+    auto issue = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gA[i],
+                                             (__attribute__((address_space(3))) void*)(ldsA + stage * STAGE + (i * NW + wave) * 1024),
+                                             16, 0, 0);
+            gA[i] += BK;
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gB[i],
+                                             (__attribute__((address_space(3))) void*)(ldsB + stage * STAGE + (i * NW + wave) * 1024),
+                                             16, 0, 0);
+            gB[i] += BK;
+        }
+    };
+
+    int vp = blockIdx.x;
+    if (vp >= ntiles) return;
+    int m0, n0, st = 0;             // st: the LDS stage that holds (or will hold) the K tile about to be multiplied
+    locate(vp, m0, n0);
+    point(m0, n0);
+    issue(st);
+    while (true) {
+        f32x4_t acc[WM][WN];
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();      // K tile kt has landed in stage st; nobody reads stage st ^ 1 any more
+            if (kt + 1 < nk) issue(st ^ 1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int co = (kk ? c1 : c0) + st * STAGE;
+                bf16x8_t fa[WM], fb[WN];
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8_t*>(rdA + mi * 16 * ROWB + co);
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const bf16x8_t*>(rdB + ni * 16 * ROWB + co);
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+            }
+            st ^= 1;
+        }
+        // here st names the stage that was read at step nk - 2: every wave has passed the barrier of step nk - 1 since,
+        // so it is free for the first K tile of the next output tile
+        const int cm0 = m0, cn0 = n0;
+        vp += gridDim.x;
+        const bool more = vp < ntiles;
+        if (more) {
+            locate(vp, m0, n0);
+            point(m0, n0);
+            issue(st);
+        }
+        gemm_epilogue<WM, WN>(a, acc, cm0 + wm * WM * 16, cn0 + wn * WN * 16, r16, kg);
+        if (!more) break;
     }
 }
 
@@ -216,6 +333,25 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return PP_OK;
 }
 
+template <int WAVES_M, int WAVES_N, int WM, int WN>
+int launch_persistent(const GemmArgs& a, hipStream_t stream) {
+    constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
+    constexpr int lds = 2 * (BM + BN) * 128;
+    auto* kern = &gemm_bf16_persistent_kernel<WAVES_M, WAVES_N, WM, WN>;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        int dev = 0;
+        PP_HIP_CHECK(hipGetDevice(&dev));
+        PP_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        n_cu = std::max(8, n_cu / 8 * 8);        // a multiple of 8 keeps a block's tile ids on one XCD
+    }
+    const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+    hipLaunchKernelGGL(kern, dim3(std::min(tiles, n_cu)), dim3(64 * WAVES_M * WAVES_N), lds, stream, a);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}
+
 }  // namespace
 
 int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream) {
@@ -235,6 +371,7 @@ int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream)
 //   5  256 x 256, 8 waves (128 x 64 each), 2 stages, 128 KiB LDS -> 1 block / CU
 //   6  256 x 128, 8 waves, 2 stages of K step 32, 48 KiB LDS -> 2 blocks / CU with the in-block prefetch
 //   7  128 x 128, 4 waves, 2 stages of K step 32, 32 KiB LDS -> 4 blocks / CU
+//   8  configuration 2 as a persistent kernel (one block per CU, next tile's first loads issued before the epilogue)
 int pp_launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
     if (a.group_m <= 0) {
@@ -251,7 +388,7 @@ int pp_launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
     const long rows256 = (a.M + 255) / 256;
     int cfg = env_cfg ? atoi(env_cfg)
                       : (a.N % 256 == 0 && rows256 * (a.N / 256) >= 128) ? 2 : (rows256 * (a.N / 128) >= 256 ? 1 : 0);
-    if ((cfg == 2 || cfg == 5) && a.N % 256 != 0) cfg = 1;
+    if ((cfg == 2 || cfg == 5 || cfg == 8) && a.N % 256 != 0) cfg = 1;
     switch (cfg) {
         case 1: return launch_cfg<4, 2, 4, 4, 1>(a, stream);
         case 2: return launch_cfg<4, 4, 4, 4, 2>(a, stream);
@@ -260,6 +397,7 @@ int pp_launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
         case 5: return launch_cfg<2, 4, 8, 4, 2>(a, stream);
         case 6: return launch_cfg<4, 2, 4, 4, 2, 32>(a, stream);
         case 7: return launch_cfg<2, 2, 4, 4, 2, 32>(a, stream);
+        case 8: return launch_persistent<4, 4, 4, 4>(a, stream);
         default: return launch_cfg<2, 2, 4, 4, 1>(a, stream);
     }
 }
