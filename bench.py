@@ -61,11 +61,18 @@ class Dist:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.dist = None
+        # POSEPIPE_DIST_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share
+        # devices, collectives on CPU tensors); the real runs use RCCL ("nccl"), one rank per GPU
+        self.backend = os.environ.get("POSEPIPE_DIST_BACKEND", "nccl")
         if self.world > 1:
             import torch
             import torch.distributed as dist
-            torch.cuda.set_device(self.local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            if self.backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                self.local_rank %= max(torch.cuda.device_count(), 1)
+                dist.init_process_group(self.backend)
             self.dist = dist
 
     def barrier(self, ctx):
@@ -78,7 +85,8 @@ class Dist:
         if self.dist is None:
             return blob
         import torch
-        t = torch.from_numpy(blob).cuda() if self.rank == 0 else torch.empty(blob.size, dtype=torch.float32, device="cuda")
+        dev = "cuda" if self.backend == "nccl" else "cpu"
+        t = torch.from_numpy(blob).to(dev) if self.rank == 0 else torch.empty(blob.size, dtype=torch.float32, device=dev)
         self.dist.broadcast(t, src=0)
         return t.cpu().numpy()
 
@@ -86,7 +94,7 @@ class Dist:
         if self.dist is None:
             return dt
         import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
         self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
         return float(tt.item())
 
