@@ -99,3 +99,31 @@ def test_conv_input_beyond_2_gib(ctx, n):
     assert np.array_equal(first, ref_a) and np.array_equal(mid, ref_a) and np.array_equal(last, ref_z)
     for p in (dx, dy, dw, db):
         ctx.free(p)
+
+
+def test_vitpose_huge_full_size(ctx):
+    """configs[4] at full size: ViTPose-H (32 blocks, dim 1280) on 256x192.  One sample against the CPU oracle that rounds
+    to bf16 at the same points (tolerance: 1e-2 of the heat-map range -- fp32 accumulation order and the occasional
+    1-ulp bf16 flip over 32 blocks; 4.5e-3 measured), and the size-independent properties: batch-position and batch-size
+    independence are EXACT (each output element is one MFMA chain over K in a fixed order, whatever the tile shape),
+    and the hipGraph replay reproduces the same bits."""
+    from oracle import vit as ovit
+    from posepipeline_amd.models import vitpose
+    spec = vitpose.vitpose_huge()
+    p = vitpose.synth_params(spec, seed=5)
+    net = Net(ctx, vitpose.build_vitpose_program(spec, p), max_batch=24)
+    rng = np.random.default_rng(4)
+    n = 24
+    x = np.zeros((n, 256, 192, 4), np.float32)
+    x[..., :3] = rng.standard_normal((n, 256, 192, 3)).astype(np.float32)
+    hm = net.forward(x).reshape(n, 17, 64, 48)
+    ref = ovit.forward(x[7:8], p, spec, emulate_bf16=True)
+    err = float(np.abs(hm[7] - ref[0]).max() / np.abs(ref[0]).max())
+    assert err < 1e-2, err
+    perm = rng.permutation(n)
+    assert np.array_equal(net.forward(x[perm]).reshape(n, 17, 64, 48), hm[perm])
+    assert np.array_equal(net.forward(x[5:8]).reshape(3, 17, 64, 48), hm[5:8])      # other GEMM tile configuration
+    assert np.array_equal(net.forward(x[20:21]).reshape(1, 17, 64, 48), hm[20:21])
+    net.capture(n)
+    assert np.array_equal(net.forward(x).reshape(n, 17, 64, 48), hm)
+    net.close()
