@@ -10,8 +10,10 @@
 // applied to the per-lane SOURCE address and again when the fragments are read back with ds_read_b128 (measured: 0
 // bank-conflict cycles).  The weights are the MFMA "A" operand and the activations the "B" operand, so a lane ends up
 // with 4 consecutive n of one row m: bias / residual / store are 16-byte (8-byte for bf16) vector accesses.  Tiles are
-// ordered in groups of 8 tile rows x all tile columns per sweep so that the blocks resident on one XCD share operand
-// tiles in its L2.
+// ordered in groups of group_m (4) tile rows x all tile columns per sweep, each XCD owning a contiguous range of that
+// order, so that the blocks resident on one XCD share operand tiles in its L2.
+// Default: 256 x 256 tiles, 16 waves, two LDS stages with one barrier per K step (launcher at the end of the file lists
+// every configuration with its measured rate; DESIGN.md 5b has the bound analysis).
 #include "pp_internal.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
