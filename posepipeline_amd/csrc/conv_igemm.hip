@@ -444,6 +444,8 @@ int launch_t(const ConvArgs& a, hipStream_t stream) {
 
 template <int CT>
 int launch_ct(const ConvArgs& a, int pt, hipStream_t stream) {
+    // PT = 4 for the narrow channel tiles (CT <= 2, same 32 accumulator registers) measured 92.5 vs 94.3 TFLOP/s on the
+    // 32 -> 32 3x3 layers of HRNet-W32: not instantiated
     return pt >= 2 ? launch_t<CT, 2>(a, stream) : launch_t<CT, 1>(a, stream);
 }
 
