@@ -95,8 +95,11 @@ typedef enum {
     PP_OP_ROIALIGN = 3,  /* reserved for the detector program */
     PP_OP_COPY = 4,      /* buffer copy (same dims) */
     PP_OP_VIT_ENCODER = 5,   /* ViT encoder on the bf16 matrix cores, see "ViT encoder" below */
-    PP_OP_DEPTH_TO_SPACE = 6 /* in [h][w][4*cout] (channel groups g = 2*dy + dx) -> out [2h][2w][cout]; with four 2x2
+    PP_OP_DEPTH_TO_SPACE = 6,/* in [h][w][4*cout] (channel groups g = 2*dy + dx) -> out [2h][2w][cout]; with four 2x2
                                 convolutions writing the groups this is ConvTranspose2d(k=4, s=2, p=1) */
+    PP_OP_UPSAMPLE_ADD = 7   /* out[y][x] = act((in[y >> up_log2][x >> up_log2] + res1[y][x]) + res2[y][x]): nearest
+                                upsample + accumulate of an HRNet fuse layer (relu: PP_RELU_NONE / PP_RELU_LAST);
+                                same additions, same order as a conv with up_log2, from a fully parallel kernel */
 } pp_op_type;
 
 #define PP_RELU_NONE 0

@@ -300,6 +300,14 @@ static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
     } else if (op.type == PP_OP_DEPTH_TO_SPACE) {
         PP_REQUIRE(op.cout > 0 && (op.cout & 3) == 0 && bi.c == 4 * op.cout && bo.c == op.cout && bo.h == 2 * bi.h && bo.w == 2 * bi.w,
                    "op %d: depth_to_space needs in [h][w][4*cout] and out [2h][2w][cout]", idx);
+    } else if (op.type == PP_OP_UPSAMPLE_ADD) {
+        PP_REQUIRE(op.cin == op.cout && (op.cout & 3) == 0 && bi.c == op.cout && bo.c == op.cout && op.up_log2 >= 0 &&
+                       (bi.h << op.up_log2) == bo.h && (bi.w << op.up_log2) == bo.w && op.in != op.out,
+                   "op %d: upsample_add needs in [h][w][c] and out [h << up][w << up][c]", idx);
+        PP_REQUIRE(op.relu == PP_RELU_NONE || op.relu == PP_RELU_LAST, "op %d: upsample_add supports PP_RELU_NONE / PP_RELU_LAST", idx);
+        for (int r : {op.res1, op.res2})
+            if (r >= 0)
+                PP_REQUIRE(net.bufs[r].c == bo.c && net.bufs[r].h == bo.h && net.bufs[r].w == bo.w, "op %d: residual shape mismatch", idx);
     } else if (op.type == PP_OP_VIT_ENCODER) {
         PP_REQUIRE(op.cin == op.cout && bi.c == op.cin && bo.c == op.cin && bi.h == bo.h && bi.w == bo.w && op.in != op.out,
                    "op %d: vit encoder needs distinct in / out buffers of [h][w][dim]", idx);
@@ -352,6 +360,10 @@ static int net_launch_op(pp_net* net, const pp_op& op, int batch, hipStream_t s)
         return PP_OK;
     } else if (op.type == PP_OP_DEPTH_TO_SPACE) {
         return pp_launch_depth_to_space(net->buf_ptr(op.in), net->buf_ptr(op.out), batch, bi.h, bi.w, op.cout, s);
+    } else if (op.type == PP_OP_UPSAMPLE_ADD) {
+        return pp_launch_upsample_add(net->buf_ptr(op.in), op.res1 >= 0 ? net->buf_ptr(op.res1) : nullptr,
+                                      op.res2 >= 0 ? net->buf_ptr(op.res2) : nullptr, net->buf_ptr(op.out), batch, bo.h, bo.w,
+                                      bo.c, op.up_log2, op.relu == PP_RELU_LAST, s);
     } else if (op.type == PP_OP_VIT_ENCODER) {
         pp_vit_encoder* enc = net->vits[&op - net->ops.data()];
         return pp_vit_encoder_run(enc, net->buf_ptr(op.in), net->buf_ptr(op.out), batch, s);

@@ -111,6 +111,9 @@ int pp_launch_layernorm(const float* x, const float* pos, int pos_mod, float* x_
 int pp_launch_attention(const void* qkv, int batch, int tokens, int heads, int head_dim, void* out, hipStream_t stream);
 // [n][h][w][4 * c] (parity-major channel groups g = 2 * dy + dx) -> [n][2h][2w][c]
 int pp_launch_depth_to_space(const float* x, float* y, int n, int h, int w, int c, hipStream_t stream);
+// y[n][H][W][c] = act((t[n][H >> u][W >> u][c] + res1) + res2)   (elementwise.hip; res1 / res2 may be null)
+int pp_launch_upsample_add(const float* t, const float* res1, const float* res2, float* y, int n, int H, int W, int c,
+                           int up_log2, int relu, hipStream_t stream);
 // encoder behind PP_OP_VIT_ENCODER; `params` is a DEVICE pointer into the program's fp32 weight blob
 struct pp_vit_encoder;
 size_t pp_vit_param_floats(int tokens, int dim, int depth, int hidden);

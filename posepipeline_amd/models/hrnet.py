@@ -23,6 +23,10 @@ import numpy as np
 from .. import _lib as L
 from ..program import ProgramBuilder, Program, fold_bn
 
+import os
+
+FUSE_UP_IN_CONV = os.environ.get("POSEPIPE_HRNET_SPLIT_UP", "0") != "1"     # A/B switch, see _HR.module
+
 COCO_FLIP_PAIRS = [(1, 2), (3, 4), (5, 6), (7, 8), (9, 10), (11, 12), (13, 14), (15, 16)]
 # Halpe-136: derived from the `swap=` fields of /root/reference/3rdparty/mmpose/config/_base_/halpe.py
 HALPE_FLIP_PAIRS = COCO_FLIP_PAIRS + [
@@ -179,9 +183,16 @@ class _HR:
                 relu = L.PP_RELU_LAST if is_last else L.PP_RELU_NONE
                 f = f"{mp}fuse_layers.{i}.{j}."
                 if j > i:
-                    h, w, c = pb.dims(xs[i])
-                    acc = self.cb(xs[j], f + "0", f + "1", pad=0, relu=relu, res1=acc, up_log2=j - i,
-                                  out=pb.buf(h, w, c))
+                    # 1x1 conv + BN on the coarse branch, then nearest upsample + accumulate.  FUSE_UP_IN_CONV = the first
+                    # form of this round (the conv epilogue scatters over the 2^u x 2^u patch); the split form gives the
+                    # same bits from a fully parallel kernel (csrc/elementwise.hip) and is what runs
+                    if FUSE_UP_IN_CONV:
+                        h, w, c = pb.dims(xs[i])
+                        acc = self.cb(xs[j], f + "0", f + "1", pad=0, relu=relu, res1=acc, up_log2=j - i,
+                                      out=pb.buf(h, w, c))
+                    else:
+                        t = self.cb(xs[j], f + "0", f + "1", pad=0)
+                        acc = pb.upsample_add(t, up_log2=j - i, res1=acc, relu=relu, name=f + "up")
                 else:
                     y = xs[j]
                     for k in range(i - j - 1):

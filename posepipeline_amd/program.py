@@ -178,6 +178,16 @@ class ProgramBuilder:
         return self._plain_op(L.PP_OP_VIT_ENCODER, x, out, cin=dim, cout=dim, kh=depth, kw=heads, stride=mlp_ratio,
                               w_off=self._add_blob(params), name=name, flops=2.0 * macs)
 
+    def upsample_add(self, t, *, up_log2, res1=-1, res2=-1, relu=L.PP_RELU_NONE, name="upsample_add") -> int:
+        """out = act((nearest-upsample(t, 2^up_log2) + res1) + res2), the accumulate step of an HRNet fuse layer."""
+        h, w, c = self.dims(t)
+        out = self.buf(h << up_log2, w << up_log2, c)
+        self.vops.append(dict(type=L.PP_OP_UPSAMPLE_ADD, in_=t, out=out, res1=res1, res2=res2, cin=c, cout=c, kh=1, kw=1,
+                              stride=1, pad_h=0, pad_w=0, dil_h=1, dil_w=1, relu=relu, up_log2=up_log2, out_nchw=0,
+                              res1_shift=0, res1_off_w=0, out_c_off=0, in_c_off=0, pad_end=0, w_off=0, b_off=0, name=name,
+                              flops=0.0))
+        return out
+
     def depth_to_space(self, x, name="depth_to_space") -> int:
         """[h][w][4c] (channel groups g = 2*dy + dx) -> [2h][2w][c]"""
         h, w, c4 = self.dims(x)
