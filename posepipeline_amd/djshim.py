@@ -14,7 +14,10 @@ Lookup `contents`, Computed `populate(*restrictions)` over `key_source` (default
 """
 from __future__ import annotations
 
+import os
 import re
+
+from . import blob as _blob
 
 config = {"custom": {}}
 
@@ -26,8 +29,9 @@ class DuplicateError(Exception):
 
 
 def _parse_definition(cls):
-    """-> (primary attribute names, parent tables, secondary attribute names)"""
+    """-> (primary attribute names, parent tables, secondary attribute names); sets cls.blob_attrs"""
     pk, parents, sec = [], [], []
+    cls.blob_attrs = set()
     section = pk
     for raw in cls.definition.splitlines():
         line = raw.split("#")[0].strip()
@@ -44,10 +48,19 @@ def _parse_definition(cls):
                 if a not in section and a not in pk:
                     section.append(a)
             continue
-        m = re.match(r"([A-Za-z_][A-Za-z0-9_]*)\s*(=[^:]*)?:", line)
+        m = re.match(r"([A-Za-z_][A-Za-z0-9_]*)\s*(=[^:]*)?:\s*([A-Za-z]+)?", line)
         if m:
             section.append(m.group(1))
+            if (m.group(3) or "").lower() in ("longblob", "blob", "mediumblob", "tinyblob"):
+                cls.blob_attrs.add(m.group(1))
     return pk, parents, sec
+
+
+class _Packed(bytes):
+    """a serialised longblob value in a row store"""
+
+
+BLOBS = os.environ.get("POSEPIPE_SHIM_BLOBS", "1") != "0"     # longblob attributes are stored as DataJoint blobs
 
 
 class _Relation:
@@ -105,8 +118,12 @@ class _Relation:
         return len(self) > 0
 
     # -- fetch --------------------------------------------------------------------------------------
+    def _rows_out(self):
+        """rows as a fetch returns them: blob attributes deserialised (a fresh object per fetch, like DataJoint)"""
+        return [{k: (_blob.unpack(v) if isinstance(v, _Packed) else v) for k, v in r.items()} for r in self._rows()]
+
     def fetch1(self, *attrs):
-        rows = self._rows()
+        rows = self._rows_out()
         if len(rows) != 1:
             raise ValueError(f"fetch1 on {self.table.__name__}: expected one row, found {len(rows)}")
         if not attrs:
@@ -117,7 +134,7 @@ class _Relation:
         return vals[0] if len(vals) == 1 else tuple(vals)
 
     def fetch(self, *attrs, as_dict=False):
-        rows = self._rows()
+        rows = self._rows_out()
         if attrs == ("KEY",):
             return [{a: r[a] for a in self.table.primary_key} for r in rows]
         if not attrs or as_dict:
@@ -207,6 +224,9 @@ class Table(metaclass=_TableMeta):
         if missing:
             raise KeyError(f"{cls.__name__}.insert1: missing primary key attribute(s) {missing}")
         row = {a: row[a] for a in cls.heading if a in row}
+        for a in getattr(cls, "blob_attrs", ()):
+            if a in row and BLOBS:
+                row[a] = _Packed(_blob.pack(row[a]))      # what DataJoint would send to MySQL (blob.py)
         for r in cls._store:
             if all(r[a] == row[a] for a in cls.primary_key):
                 if skip_duplicates:
