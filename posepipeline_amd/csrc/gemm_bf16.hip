@@ -201,6 +201,108 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, min_blocks(WAVES_M * WAVES_
     gemm_epilogue<WM, WN>(a, acc, m0 + wm * WM * 16, n0 + wn * WN * 16, r16, kg);
 }
 
+// Register-pipelined form (configuration 9): 8 waves of 128 x 64, 256 x 256 block tile, two LDS stages.  The fragments
+// of the NEXT half K step are read from LDS before the 32 MFMAs of the current one are issued, so no MFMA ever waits for
+// an LDS read; the barrier sits in the middle of a K step (after the reads of its second half), where it also frees the
+// stage for the tile after next -- global loads fly for one and a half K steps.
+template <int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void gemm_bf16_pipelined_kernel(GemmArgs a) {
+    constexpr int WM = 8, WN = 4;
+    constexpr int NW = WAVES_M * WAVES_N, BK = 64, ROWB = 128, RS = 8;
+    constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
+    constexpr int NLA = BM / (RS * NW), NLB = BN / (RS * NW);
+    constexpr int STAGE = (BM + BN) * ROWB;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    unsigned char* ldsA = lds;
+    unsigned char* ldsB = lds + BM * ROWB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
+    const int tiles_n = a.N / BN, tiles_m = (a.M + BM - 1) / BM;
+    int pid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = pid & 7, loc = pid >> 3;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int GM = a.group_m, per_group = GM * tiles_n;
+    const int grp = pid / per_group, in_grp = pid - grp * per_group;
+    const int rows_here = min(GM, tiles_m - grp * GM);
+    const int tn = in_grp / rows_here, tm = grp * GM + (in_grp - tn * rows_here);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lrow = lane >> 3, slot = lane & 7;
+    const __bf16* gA[NLA];
+    const __bf16* gB[NLB];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        const int row = (i * NW + wave) * RS + lrow;
+        gA[i] = reinterpret_cast<const __bf16*>(a.A) + (size_t)min(m0 + row, a.M - 1) * a.K + (slot ^ ((row >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        const int row = (i * NW + wave) * RS + lrow;
+        gB[i] = reinterpret_cast<const __bf16*>(a.B) + (size_t)(n0 + row) * a.K + (slot ^ ((row >> 1) & 7)) * 8;
+    }
+    auto issue = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gA[i],
+                                             (__attribute__((address_space(3))) void*)(ldsA + stage * STAGE + (i * NW + wave) * 1024),
+                                             16, 0, 0);
+            gA[i] += BK;
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gB[i],
+                                             (__attribute__((address_space(3))) void*)(ldsB + stage * STAGE + (i * NW + wave) * 1024),
+                                             16, 0, 0);
+            gB[i] += BK;
+        }
+    };
+    const int r16 = lane & 15, kg = lane >> 4, sw = (r16 >> 1) & 7;
+    const unsigned char* rdA = ldsA + (wm * WM * 16 + r16) * ROWB;
+    const unsigned char* rdB = ldsB + (wn * WN * 16 + r16) * ROWB;
+    const int c0 = ((0 + kg) ^ sw) << 4, c1 = ((4 + kg) ^ sw) << 4;
+
+    f32x4_t acc[WM][WN];
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t fa0[WM], fb0[WN], fa1[WM], fb1[WN];
+    auto read = [&](bf16x8_t (&fa)[WM], bf16x8_t (&fb)[WN], int off) {
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8_t*>(rdA + mi * 16 * ROWB + off);
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const bf16x8_t*>(rdB + ni * 16 * ROWB + off);
+    };
+    auto mma = [&](bf16x8_t (&fa)[WM], bf16x8_t (&fb)[WN]) {
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
+    };
+
+    const int nk = a.K / BK;
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (nk > 1) issue(1);
+    read(fa0, fb0, c0);                                   // (tile 0, first half)
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = (kt & 1) * STAGE, nxt = STAGE - cur;
+        read(fa1, fb1, c1 + cur);                         // second half of this K step
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa0, fb0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own part of tile kt + 1 landed; stage `cur` fully read
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nk) issue(kt & 1);                   // tile kt + 2 into the stage just freed
+        if (kt + 1 < nk) read(fa0, fb0, c0 + nxt);        // first half of the next K step
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa1, fb1);
+    }
+    gemm_epilogue<WM, WN>(a, acc, m0 + wm * WM * 16, n0 + wn * WN * 16, r16, kg);
+}
+
 // Persistent form of the two-stage kernel: one block per CU walks the tile list; the first K tile of the NEXT output tile
 // is requested (global_load_lds is asynchronous and needs no registers) before the epilogue of the current one, so the
 // epilogue's loads / math / stores overlap that fetch instead of being followed by a cold pipeline start.
@@ -335,6 +437,22 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return PP_OK;
 }
 
+template <int WAVES_M, int WAVES_N>
+int launch_pipelined(const GemmArgs& a, hipStream_t stream) {
+    constexpr int BM = WAVES_M * 128, BN = WAVES_N * 64;
+    constexpr int lds = 2 * (BM + BN) * 128;
+    auto* kern = &gemm_bf16_pipelined_kernel<WAVES_M, WAVES_N>;
+    static bool configured = false;
+    if (!configured) {
+        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        configured = true;
+    }
+    const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, stream, a);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
+}
+
 template <int WAVES_M, int WAVES_N, int WM, int WN>
 int launch_persistent(const GemmArgs& a, hipStream_t stream) {
     constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
@@ -374,6 +492,7 @@ int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream)
 //   6  256 x 128, 8 waves, 2 stages of K step 32, 48 KiB LDS -> 2 blocks / CU with the in-block prefetch
 //   7  128 x 128, 4 waves, 2 stages of K step 32, 32 KiB LDS -> 4 blocks / CU
 //   8  configuration 2 as a persistent kernel (one block per CU, next tile's first loads issued before the epilogue)
+//   9  256 x 256, 8 waves (128 x 64 each), register-pipelined fragments, barrier mid K step: 821 / 671 / 747 / 1020
 int pp_launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
     if (a.group_m <= 0) {
@@ -390,7 +509,7 @@ int pp_launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
     const long rows256 = (a.M + 255) / 256;
     int cfg = env_cfg ? atoi(env_cfg)
                       : (a.N % 256 == 0 && rows256 * (a.N / 256) >= 128) ? 2 : (rows256 * (a.N / 128) >= 256 ? 1 : 0);
-    if ((cfg == 2 || cfg == 5 || cfg == 8) && a.N % 256 != 0) cfg = 1;
+    if ((cfg == 2 || cfg == 5 || cfg == 8 || cfg == 9) && a.N % 256 != 0) cfg = 1;
     switch (cfg) {
         case 1: return launch_cfg<4, 2, 4, 4, 1>(a, stream);
         case 2: return launch_cfg<4, 4, 4, 4, 2>(a, stream);
@@ -400,6 +519,7 @@ int pp_launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
         case 6: return launch_cfg<4, 2, 4, 4, 2, 32>(a, stream);
         case 7: return launch_cfg<2, 2, 4, 4, 2, 32>(a, stream);
         case 8: return launch_persistent<4, 4, 4, 4>(a, stream);
+        case 9: return launch_pipelined<2, 4>(a, stream);
         default: return launch_cfg<2, 2, 4, 4, 1>(a, stream);
     }
 }

@@ -59,7 +59,7 @@ def _close_bf16(got_bits, ref_f32, ulps=1.0):
     (576, 1280, 640, 0, True, 192, 0),       # residual broadcast over row % 192 (position embedding form)
     (1100, 640, 2560, 0, True, 0, 0),        # in-place residual stream form, ragged 256-row tiles
 ])
-@pytest.mark.parametrize("cfg", ["0", "1", "2", "3", "4", "5", "6", "7", "8"])     # every tile configuration of gemm_bf16.hip
+@pytest.mark.parametrize("cfg", ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9"])     # every tile configuration of gemm_bf16.hip
 def test_gemm_bf16(ctx, monkeypatch, cfg, m, n, k, act, use_res, res_mod, out_bf16):
     monkeypatch.setenv("POSEPIPE_GEMM_CFG", cfg)
     rng = np.random.default_rng(m + n + k)
