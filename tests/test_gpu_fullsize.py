@@ -127,3 +127,25 @@ def test_vitpose_huge_full_size(ctx):
     net.capture(n)
     assert np.array_equal(net.forward(x).reshape(n, 17, 64, 48), hm)
     net.close()
+
+
+def test_detector_1080p_full_size(ctx):
+    """configs[2]/[3] at full size: one synthetic 1920x1080 frame through Faster-RCNN R50-FPN (640x1088 input, 174 K
+    anchors, 1000 proposals) -- detections bit-exact against the CPU oracle -- and batch-position independence: the same
+    frame at positions 0 and 2 of a 3-frame batch gives the same detections as alone."""
+    from oracle import detector as odet
+    from posepipeline_amd.models import faster_rcnn as fr
+    from tests.test_gpu_detector import synth_frame
+    rng = np.random.default_rng(3)
+    sd = synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2)
+    for k, g in (("detector.rpn_head.rpn_cls.weight", 0.5), ("detector.rpn_head.rpn_reg.weight", 0.1),
+                 ("detector.roi_head.bbox_head.fc_reg.weight", 0.2)):
+        sd[k] = (sd[k] * g).astype(np.float32)
+    f0, f1 = synth_frame(rng, 1080, 1920), synth_frame(rng, 1080, 1920)
+    det = fr.Detector(ctx, sd, 1080, 1920, max_frames=3)
+    alone = det.run(f0[None])[0]
+    ref = odet.detect(odet.FasterRCNNRef(sd), f0[:, :, ::-1])
+    assert alone.shape == ref.shape and alone.shape[0] > 0
+    assert np.array_equal(alone, ref)
+    batch = det.run(np.stack([f0, f1, f0]))
+    assert np.array_equal(batch[0], alone) and np.array_equal(batch[2], alone) and not np.array_equal(batch[1], alone)
