@@ -48,3 +48,21 @@ def test_no_gpu_means_loud_failure():
         pytest.skip("a GPU is visible here")
     with pytest.raises(_lib.PosePipeHipError, match="no HIP device|no CPU fallback"):
         _lib.Context(0)
+
+
+def test_missing_library_means_loud_failure(tmp_path):
+    """the product path has no fallback: without libposepipe_hip.so the wrappers raise instead of computing on the CPU"""
+    import os
+    import subprocess
+    import sys
+    code = ("import os\n"
+            "from posepipeline_amd import _lib\n"
+            "from posepipeline_amd.wrappers import mmpose\n"
+            "try:\n"
+            "    mmpose._model('HRNet_W32_COCO')\n"
+            "except _lib.PosePipeHipError as e:\n"
+            "    print('LOUD:', e)\n")
+    env = dict(os.environ, POSEPIPE_LIB=str(tmp_path / "absent.so"), POSEPIPE_SYNTHETIC_WEIGHTS="1")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+    assert "LOUD:" in out.stdout and "absent.so" in out.stdout, out.stdout + out.stderr
