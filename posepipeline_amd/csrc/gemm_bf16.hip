@@ -70,7 +70,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4_t (&acc)[
                 ushort4 o;
                 o.x = f32_to_bf16_rne(v[0]); o.y = f32_to_bf16_rne(v[1]);
                 o.z = f32_to_bf16_rne(v[2]); o.w = f32_to_bf16_rne(v[3]);
-                *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(a.C) + (size_t)m * a.N + n) = o;
+                size_t off = (size_t)m * a.N + n;
+                if (a.qkv_tokens > 0) {      // head-major q / k / v: [which][sample][head][token][d]; 4 | head_dim keeps the 4 values together
+                    const int dim = a.N / 3, which = n / dim, rem = n - which * dim, head = rem / a.qkv_hd, d = rem - head * a.qkv_hd;
+                    const int smp = m / a.qkv_tokens, tok = m - smp * a.qkv_tokens;
+                    off = ((((size_t)which * (a.M / a.qkv_tokens) + smp) * (dim / a.qkv_hd) + head) * a.qkv_tokens + tok) * a.qkv_hd + d;
+                }
+                *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(a.C) + off) = o;
             } else {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + (size_t)m * a.N + n) =
                     make_float4(v[0], v[1], v[2], v[3]);

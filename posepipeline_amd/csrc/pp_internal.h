@@ -101,6 +101,8 @@ struct GemmArgs {
     int out_bf16;
     int res_mod;         // > 0: residual row = m % res_mod (position embedding)
     int group_m;         // tile rows per L2 sweep group (0: default)
+    // > 0 (bf16 output, N = 3 * dim): write C as [3][M / qkv_tokens][dim / qkv_hd][qkv_tokens][qkv_hd] (head-major q, k, v)
+    int qkv_tokens, qkv_hd;
 };
 int pp_launch_gemm_bf16(const GemmArgs& a, hipStream_t stream);
 int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream);
@@ -108,7 +110,9 @@ int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream)
 int pp_launch_layernorm(const float* x, const float* pos, int pos_mod, float* x_out, const float* gamma,
                         const float* beta, int rows, int dim, float eps, void* y, int out_bf16, hipStream_t stream);
 // multi-head self-attention on a packed qkv tensor [batch * tokens][3][heads][head_dim] bf16 -> [batch * tokens][heads * head_dim]
-int pp_launch_attention(const void* qkv, int batch, int tokens, int heads, int head_dim, void* out, hipStream_t stream);
+// head_major: qkv is [3][batch][heads][tokens][head_dim] (GemmArgs::qkv_tokens) instead of packed token rows
+int pp_launch_attention(const void* qkv, int batch, int tokens, int heads, int head_dim, void* out, hipStream_t stream,
+                        int head_major = 0);
 // [n][h][w][4 * c] (parity-major channel groups g = 2 * dy + dx) -> [n][2h][2w][c]
 int pp_launch_depth_to_space(const float* x, float* y, int n, int h, int w, int c, hipStream_t stream);
 // y[n][H][W][c] = act((t[n][H >> u][W >> u][c] + res1) + res2)   (elementwise.hip; res1 / res2 may be null)

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // MFMA's B operand when V^T's k-slots are read with the same key permutation, so P never leaves the registers.
 template <int T, int HD>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const unsigned short* __restrict__ qkv, unsigned short* __restrict__ out,
-                                                        int heads, float scale) {
+                                                        int heads, float scale, int head_major) {
     constexpr int HDP = (HD + 31) / 32 * 32;   // head dim padded to the MFMA K step (zeros)
     constexpr int KSTR = HDP * 2 + 16;         // bytes per K row; rows 0..15 land in 16 distinct 16-byte bank groups
     constexpr int VSTR = T * 2 + 16;           // bytes per V^T row
@@ -99,13 +99,19 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const unsigned short*
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
-    const int D = heads * HD, ld = 3 * D;
-    const unsigned short* base = qkv + (size_t)b * T * ld;
+    const int D = heads * HD;
+    // packed: rows of [3][heads][HD] per token (the standalone ABI);  head-major: [3][batch][heads][T][HD], what the encoder's
+    // qkv GEMM writes (GemmArgs::qkv_tokens), so that every (sample, head) slice is one contiguous 30 KB slab
+    const int ld = head_major ? HD : 3 * D;
+    const size_t slab = (size_t)T * HD, nbh = (size_t)gridDim.x;
+    const unsigned short* qp = head_major ? qkv + (size_t)blockIdx.x * slab : qkv + (size_t)b * T * ld + h * HD;
+    const unsigned short* kp = head_major ? qp + nbh * slab : qp + D;
+    const unsigned short* vp = head_major ? kp + nbh * slab : kp + D;
 
     for (int idx = tid; idx < T * (HDP / 8); idx += 256) {
         const int t = idx / (HDP / 8), c = idx - t * (HDP / 8);
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (c < HD / 8) v = *reinterpret_cast<const uint4*>(base + (size_t)t * ld + D + h * HD + c * 8);
+        if (c < HD / 8) v = *reinterpret_cast<const uint4*>(kp + (size_t)t * ld + c * 8);
         *reinterpret_cast<uint4*>(sK + t * KSTR + c * 16) = v;
     }
     // V^T: lane = token (consecutive 2-byte LDS columns: conflict-free transposed writes); each wave owns T / 4 tokens and
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const unsigned short*
     for (int c = 0; c < HD / 8; ++c) {
         const int t = wave * (T / 4) + lane;
         if (lane >= T / 4) continue;
-        const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)t * ld + 2 * D + h * HD + c * 8);
+        const uint4 v = *reinterpret_cast<const uint4*>(vp + (size_t)t * ld + c * 8);
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const unsigned short*
     const int r16 = lane & 15, kg = lane >> 4;
 #pragma unroll 1
     for (int qf = wave; qf < T / 16; qf += 4) {
-        const unsigned short* qrow = base + (size_t)(qf * 16 + r16) * ld + h * HD;
+        const unsigned short* qrow = qp + (size_t)(qf * 16 + r16) * ld;
         bf16x8_t fq[HDP / 32];
 #pragma unroll
         for (int kk = 0; kk < HDP / 32; ++kk) {
@@ -236,7 +242,7 @@ int pp_launch_layernorm(const float* x, const float* pos, int pos_mod, float* x_
 }
 
 template <int T, int HD>
-static int launch_attention(const void* qkv, int batch, int heads, void* out, hipStream_t stream) {
+static int launch_attention(const void* qkv, int batch, int heads, void* out, int head_major, hipStream_t stream) {
     constexpr int HDP = (HD + 31) / 32 * 32;
     constexpr size_t lds = (size_t)T * (HDP * 2 + 16) + (size_t)HD * (T * 2 + 16);
     static bool configured = false;
@@ -247,15 +253,16 @@ static int launch_attention(const void* qkv, int batch, int heads, void* out, hi
     }
     const float scale = 1.0f / sqrtf((float)HD);
     hipLaunchKernelGGL((attention_kernel<T, HD>), dim3(batch * heads), dim3(256), lds, stream,
-                       reinterpret_cast<const unsigned short*>(qkv), reinterpret_cast<unsigned short*>(out), heads, scale);
+                       reinterpret_cast<const unsigned short*>(qkv), reinterpret_cast<unsigned short*>(out), heads, scale, head_major);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
 
-int pp_launch_attention(const void* qkv, int batch, int tokens, int heads, int head_dim, void* out, hipStream_t stream) {
+int pp_launch_attention(const void* qkv, int batch, int tokens, int heads, int head_dim, void* out, hipStream_t stream,
+                        int head_major) {
     PP_REQUIRE(batch > 0 && heads > 0, "attention: empty problem");
-    if (tokens == 192 && head_dim == 80) return launch_attention<192, 80>(qkv, batch, heads, out, stream);
-    if (tokens == 192 && head_dim == 64) return launch_attention<192, 64>(qkv, batch, heads, out, stream);
+    if (tokens == 192 && head_dim == 80) return launch_attention<192, 80>(qkv, batch, heads, out, head_major, stream);
+    if (tokens == 192 && head_dim == 64) return launch_attention<192, 64>(qkv, batch, heads, out, head_major, stream);
     pp_set_error("attention: (tokens %d, head_dim %d) is not built; available: (192, 80), (192, 64)", tokens, head_dim);
     return PP_ERR_UNSUPPORTED;
 }
@@ -283,6 +290,7 @@ struct VitBlock {
 
 struct pp_vit_encoder {
     int tokens = 0, dim = 0, depth = 0, heads = 0, hidden = 0, max_batch = 0;
+    int head_major = [] { const char* v = getenv("POSEPIPE_VIT_HEAD_MAJOR"); return v && atoi(v) != 0; }();
     const float* pos = nullptr;
     const float *lnf_g = nullptr, *lnf_b = nullptr;
     std::vector<VitBlock> blocks;
@@ -391,9 +399,11 @@ int pp_vit_encoder_run(pp_vit_encoder* e, const float* in, float* out, int batch
     e->ev_used = 0;
     e->n_gemm = 0;
     e->mark(1, stream);   // start of the first interval
-    auto gemm = [&](const void* A, const void* W, const float* bias, const float* res, void* C, int N, int K, int act, int obf) {
+    auto gemm = [&](const void* A, const void* W, const float* bias, const float* res, void* C, int N, int K, int act, int obf,
+                    int qkv_tokens = 0, int qkv_hd = 0) {
         GemmArgs g{};
         g.A = A; g.B = W; g.bias = bias; g.res = res; g.C = C; g.M = M; g.N = N; g.K = K; g.act = act; g.out_bf16 = obf;
+        g.qkv_tokens = qkv_tokens; g.qkv_hd = qkv_hd;
         const int r = pp_launch_gemm_bf16(g, stream);
         e->mark(0, stream);
         ++e->n_gemm;
@@ -409,8 +419,11 @@ int pp_vit_encoder_run(pp_vit_encoder* e, const float* in, float* out, int batch
         if (i == 0) rc = ln(in, e->pos, e->X, b.ln1_g, b.ln1_b, e->hbuf, 1);   // x = patch_embed + pos, h = LN1(x)
         else rc = ln(e->X, nullptr, nullptr, b.ln1_g, b.ln1_b, e->hbuf, 1);
         if (rc != PP_OK) return rc;
-        if ((rc = gemm(e->hbuf, b.wqkv, b.bqkv, nullptr, e->qkv, 3 * D, D, 0, 1)) != PP_OK) return rc;
-        if ((rc = pp_launch_attention(e->qkv, batch, e->tokens, e->heads, D / e->heads, e->att, stream)) != PP_OK) return rc;
+        // head-major q / k / v (POSEPIPE_VIT_HEAD_MAJOR=1) makes the attention loads contiguous (3.66 -> 3.38 ms per step of
+        // 128 passes) but the scattering qkv epilogue costs more than that (GEMMs 34.3 -> 35.5 ms): off by default
+        const int hm = e->head_major;
+        if ((rc = gemm(e->hbuf, b.wqkv, b.bqkv, nullptr, e->qkv, 3 * D, D, 0, 1, hm ? e->tokens : 0, hm ? D / e->heads : 0)) != PP_OK) return rc;
+        if ((rc = pp_launch_attention(e->qkv, batch, e->tokens, e->heads, D / e->heads, e->att, stream, hm)) != PP_OK) return rc;
         e->mark(2, stream);
         if ((rc = gemm(e->att, b.wproj, b.bproj, e->X, e->X, D, D, 0, 0)) != PP_OK) return rc;
         if ((rc = ln(e->X, nullptr, nullptr, b.ln2_g, b.ln2_b, e->hbuf, 1)) != PP_OK) return rc;

@@ -169,6 +169,22 @@ def test_deconv_as_four_convs(ctx):
 SMALL = MV.VitPoseSpec(dim=640, depth=2, heads=8, mlp_ratio=4, num_joints=17, deconv=(64, 64))
 
 
+def test_head_major_qkv_layout_is_bit_identical(ctx, monkeypatch):
+    """POSEPIPE_VIT_HEAD_MAJOR=1 (qkv GEMM writes [3][sample][head][token][d], attention reads contiguous slabs) is the same
+    arithmetic on the same values: identical heat-maps."""
+    p = MV.synth_params(SMALL, seed=8)
+    prog = MV.build_vitpose_program(SMALL, p)
+    x = np.zeros((2, SMALL.in_h, SMALL.in_w, 4), np.float32)
+    x[..., :3] = np.random.default_rng(12).standard_normal((2, SMALL.in_h, SMALL.in_w, 3), dtype=np.float32)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("POSEPIPE_VIT_HEAD_MAJOR", flag)      # read when the encoder is created
+        net = Net(ctx, prog, 2)
+        outs.append(net.forward(x))
+        net.close()
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_vitpose_small_program(ctx):
     """patch embedding + 2-block encoder + head, program vs oracle (bf16 rounding emulated at the same points)."""
     p = MV.synth_params(SMALL, seed=3)
