@@ -128,3 +128,39 @@ def test_shard_bounds():
     assert parallel.shard_bounds(37, 2) == [0, 18, 37]
     assert parallel.shard_bounds(300, 8)[-1] == 300 and len(parallel.shard_bounds(300, 8)) == 9
     assert parallel.shard_bounds(3, 8) == [0, 0, 0, 1, 1, 1, 2, 2, 3]
+
+
+def test_bench_dist_helpers_world2_gloo(tmp_path):
+    """bench.py's N > 1 plumbing (weight broadcast, barrier, max-over-ranks timing) under torchrun with 2 gloo ranks: the
+    same Dist class the RCCL runs use (POSEPIPE_DIST_BACKEND=gloo keeps the tensors on the CPU)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "dist_probe.py"
+    script.write_text(
+        "import json, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import numpy as np\n"
+        "import bench\n"
+        "class Ctx:\n"
+        "    def synchronize(self):\n"
+        "        pass\n"
+        "D = bench.Dist()\n"
+        "blob = np.arange(1000, dtype=np.float32) * (1.0 if D.rank == 0 else -1.0)\n"
+        "got = D.bcast_blob(blob)\n"
+        "D.barrier(Ctx())\n"
+        "t = D.max_time(1.0 + D.rank)\n"
+        "ok = bool(np.array_equal(got, np.arange(1000, dtype=np.float32)))\n"
+        f"open({str(tmp_path)!r} + '/rank%d.json' % D.rank, 'w').write(json.dumps(dict(rank=D.rank, world=D.world, ok=ok, t=t)))\n"
+        "D.close()\n")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, POSEPIPE_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    import json
+    res = [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in (0, 1)]
+    assert all(r["ok"] and r["world"] == 2 for r in res)
+    assert res[0]["t"] == res[1]["t"] == 2.0          # every rank sees the slowest rank's time
