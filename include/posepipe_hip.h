@@ -97,7 +97,12 @@ typedef enum {
     PP_OP_VIT_ENCODER = 5,   /* ViT encoder on the bf16 matrix cores, see "ViT encoder" below */
     PP_OP_DEPTH_TO_SPACE = 6,/* in [h][w][4*cout] (channel groups g = 2*dy + dx) -> out [2h][2w][cout]; with four 2x2
                                 convolutions writing the groups this is ConvTranspose2d(k=4, s=2, p=1) */
-    PP_OP_UPSAMPLE_ADD = 7   /* out[y][x] = act((in[y >> up_log2][x >> up_log2] + res1[y][x]) + res2[y][x]): nearest
+    PP_OP_DECONV_BF16 = 8,   /* ConvTranspose2d(4, 2, 1) + bias + act on the bf16 matrix cores: in [h][w][cin] fp32 ->
+                                out [2h][2w][cout] fp32; w_off: fp32 W_all[16][cout][cin], block ((a*2+b)*2+r)*2+s =
+                                w[:, :, 3-a-2r, 3-b-2s]^T (output parity (a, b), tap (r, s)); b_off: bias[cout];
+                                cin % 64 == 0, cout % 8 == 0; relu PP_RELU_NONE / PP_RELU_LAST.  One GEMM with N = 16 cout
+                                and a 4-term gather; operands rounded to bf16, fp32 accumulation (tolerance-based parity) */
+    PP_OP_UPSAMPLE_ADD = 7,  /* out[y][x] = act((in[y >> up_log2][x >> up_log2] + res1[y][x]) + res2[y][x]): nearest
                                 upsample + accumulate of an HRNet fuse layer (relu: PP_RELU_NONE / PP_RELU_LAST);
                                 same additions, same order as a conv with up_log2, from a fully parallel kernel */
 } pp_op_type;

@@ -120,14 +120,24 @@ def conv_transpose_4s2p1(x_nhwc, w):
     return full[:, 1:1 + 2 * h, 1:1 + 2 * ww]
 
 
-def head(feat_nhwc, p):
-    """keypoint_head: deconv_layers (0 deconv, 1 BN, 2 ReLU, 3 deconv, 4 BN, 5 ReLU) + final_layer 1x1 -> NCHW heatmaps"""
+def head(feat_nhwc, p, q_first=False):
+    """keypoint_head: deconv_layers (0 deconv, 1 BN, 2 ReLU, 3 deconv, 4 BN, 5 ReLU) + final_layer 1x1 -> NCHW heatmaps.
+    q_first: the HIP path runs the FIRST deconvolution on the bf16 matrix cores (PP_OP_DECONV_BF16): BatchNorm folded into
+    the weights (float64, one rounding to float32, as posepipeline_amd.program.fold_bn), input and folded weights rounded
+    to bf16, then the folded bias."""
     x = feat_nhwc
     for d, bn in ((0, 1), (3, 4)):
         k = "keypoint_head.deconv_layers."
-        y = conv_transpose_4s2p1(x, p[f"{k}{d}.weight"])
         g, be = p[f"{k}{bn}.weight"].astype(np.float64), p[f"{k}{bn}.bias"].astype(np.float64)
         mu, var = p[f"{k}{bn}.running_mean"].astype(np.float64), p[f"{k}{bn}.running_var"].astype(np.float64)
+        if d == 0 and q_first:
+            scale = g / np.sqrt(var + BN_EPS)
+            wf = (p[f"{k}{d}.weight"].astype(np.float64) * scale[None, :, None, None]).astype(F32)
+            bf = (be - mu * scale).astype(F32)
+            y = conv_transpose_4s2p1(bf16_round(x), bf16_round(wf)) + bf.astype(np.float64)
+            x = np.maximum(y, 0.0).astype(F32)
+            continue
+        y = conv_transpose_4s2p1(x, p[f"{k}{d}.weight"])
         x = np.maximum((y - mu) / np.sqrt(var + BN_EPS) * g + be, 0.0).astype(F32)
     wf = p["keypoint_head.final_layer.weight"][:, :, 0, 0].astype(np.float64)
     y = x.astype(np.float64) @ wf.T + p["keypoint_head.final_layer.bias"].astype(np.float64)
@@ -138,4 +148,4 @@ def forward(x_nhwc, p, spec, emulate_bf16=True):
     """x [b][256][192][>=3] normalised image -> heatmaps [b][K][64][48]"""
     tok, (gh, gw) = patch_embed(x_nhwc, p["backbone.patch_embed.proj.weight"], p["backbone.patch_embed.proj.bias"])
     y = encoder(tok, p, spec, emulate_bf16)
-    return head(y.reshape(y.shape[0], gh, gw, -1), p)
+    return head(y.reshape(y.shape[0], gh, gw, -1), p, q_first=emulate_bf16 and getattr(spec, "head_bf16", False))

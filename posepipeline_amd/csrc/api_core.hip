@@ -209,6 +209,7 @@ struct pp_net {
     hipEvent_t fork_ev = nullptr;
     std::vector<hipEvent_t> join_ev;
     std::vector<pp_vit_encoder*> vits;   // per op: the encoder of a PP_OP_VIT_ENCODER, else null
+    std::vector<pp_deconv_bf16*> deconvs; // per op: the object of a PP_OP_DECONV_BF16, else null
 
     float* buf_ptr(int b) const { return arena + buf_off[b]; }
 };
@@ -300,6 +301,14 @@ static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
     } else if (op.type == PP_OP_DEPTH_TO_SPACE) {
         PP_REQUIRE(op.cout > 0 && (op.cout & 3) == 0 && bi.c == 4 * op.cout && bo.c == op.cout && bo.h == 2 * bi.h && bo.w == 2 * bi.w,
                    "op %d: depth_to_space needs in [h][w][4*cout] and out [2h][2w][cout]", idx);
+    } else if (op.type == PP_OP_DECONV_BF16) {
+        PP_REQUIRE(bi.c == op.cin && bo.c == op.cout && bo.h == 2 * bi.h && bo.w == 2 * bi.w && op.in != op.out,
+                   "op %d: deconv_bf16 needs in [h][w][cin] and out [2h][2w][cout]", idx);
+        PP_REQUIRE(op.cin % 64 == 0 && (op.cout & 7) == 0, "op %d: deconv_bf16 needs cin %% 64 == 0 and cout %% 8 == 0", idx);
+        PP_REQUIRE(op.relu == PP_RELU_NONE || op.relu == PP_RELU_LAST, "op %d: deconv_bf16 supports PP_RELU_NONE / PP_RELU_LAST", idx);
+        PP_REQUIRE(op.w_off >= 0 && (op.w_off % 4) == 0 && (size_t)op.w_off + (size_t)16 * op.cout * op.cin <= net.n_weights &&
+                       op.b_off >= 0 && (op.b_off % 4) == 0 && (size_t)op.b_off + op.cout <= net.n_weights,
+                   "op %d: deconv_bf16 parameters out of blob", idx);
     } else if (op.type == PP_OP_UPSAMPLE_ADD) {
         PP_REQUIRE(op.cin == op.cout && (op.cout & 3) == 0 && bi.c == op.cout && bo.c == op.cout && op.up_log2 >= 0 &&
                        (bi.h << op.up_log2) == bo.h && (bi.w << op.up_log2) == bo.w && op.in != op.out,
@@ -360,6 +369,9 @@ static int net_launch_op(pp_net* net, const pp_op& op, int batch, hipStream_t s)
         return PP_OK;
     } else if (op.type == PP_OP_DEPTH_TO_SPACE) {
         return pp_launch_depth_to_space(net->buf_ptr(op.in), net->buf_ptr(op.out), batch, bi.h, bi.w, op.cout, s);
+    } else if (op.type == PP_OP_DECONV_BF16) {
+        return pp_deconv_bf16_run(net->deconvs[&op - net->ops.data()], net->buf_ptr(op.in), net->buf_ptr(op.out), batch,
+                                  op.relu == PP_RELU_LAST, s);
     } else if (op.type == PP_OP_UPSAMPLE_ADD) {
         return pp_launch_upsample_add(net->buf_ptr(op.in), op.res1 >= 0 ? net->buf_ptr(op.res1) : nullptr,
                                       op.res2 >= 0 ? net->buf_ptr(op.res2) : nullptr, net->buf_ptr(op.out), batch, bo.h, bo.w,
@@ -411,8 +423,18 @@ int pp_net_create(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, 
     PP_HIP_CHECK(hipMalloc((void**)&net->arena, net->arena_floats * sizeof(float)));
     PP_HIP_CHECK(hipMemsetAsync(net->arena, 0, net->arena_floats * sizeof(float), ctx->stream));
     net->vits.assign(n_ops, nullptr);
+    net->deconvs.assign(n_ops, nullptr);
     for (int i = 0; i < n_ops; ++i) {
         const pp_op& op = net->ops[i];
+        if (op.type == PP_OP_DECONV_BF16) {
+            const pp_buf& bi = net->bufs[op.in];
+            int rc = pp_deconv_bf16_create(net->weights + op.w_off, net->weights + op.b_off, bi.h, bi.w, op.cin, op.cout,
+                                           max_batch, ctx->stream, &net->deconvs[i]);
+            if (rc != PP_OK) {
+                pp_net_destroy(net.release());
+                return rc;
+            }
+        }
         if (op.type != PP_OP_VIT_ENCODER) continue;
         const pp_buf& bi = net->bufs[op.in];
         int rc = pp_vit_encoder_create(net->weights + op.w_off, bi.h * bi.w, op.cin, op.kh, op.kw, op.cin * op.stride,
@@ -454,6 +476,7 @@ void pp_net_destroy(pp_net* net) {
     if (net->fork_ev) (void)hipEventDestroy(net->fork_ev);
     if (net->graph_exec) (void)hipGraphExecDestroy(net->graph_exec);
     for (auto* v : net->vits) pp_vit_encoder_destroy(v);
+    for (auto* d : net->deconvs) pp_deconv_bf16_destroy(d);
     if (net->weights) (void)hipFree(net->weights);
     if (net->arena) (void)hipFree(net->arena);
     delete net;

@@ -437,6 +437,7 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
         PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         configured = true;
     }
+    if (a.M <= 0) return PP_OK;        // configure-only call (pp_gemm_bf16_prepare)
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, stream, a);
     PP_HIP_CHECK(hipGetLastError());
@@ -499,6 +500,13 @@ int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream)
 //   7  128 x 128, 4 waves, 2 stages of K step 32, 32 KiB LDS -> 4 blocks / CU
 //   8  configuration 2 as a persistent kernel (one block per CU, next tile's first loads issued before the epilogue)
 //   9  256 x 256, 8 waves (128 x 64 each), register-pipelined fragments, barrier mid K step: 821 / 671 / 747 / 1020
+// set the dynamic-LDS attribute of the default large-tile kernel outside any hipGraph capture (called when an encoder /
+// deconvolution object is created)
+int pp_gemm_bf16_prepare() {
+    GemmArgs none{};
+    return launch_cfg<4, 4, 4, 4, 2>(none, nullptr);
+}
+
 int pp_launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
     if (a.group_m <= 0) {

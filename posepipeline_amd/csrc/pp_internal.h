@@ -105,6 +105,13 @@ struct GemmArgs {
     int qkv_tokens, qkv_hd;
 };
 int pp_launch_gemm_bf16(const GemmArgs& a, hipStream_t stream);
+int pp_gemm_bf16_prepare();
+// ConvTranspose2d(4, 2, 1) + bias + ReLU as one bf16 GEMM + gather (deconv_bf16.hip); weights / bias are DEVICE pointers
+struct pp_deconv_bf16;
+int pp_deconv_bf16_create(const float* weights, const float* bias, int h, int w, int cin, int cout, int max_batch,
+                          hipStream_t stream, pp_deconv_bf16** out);
+void pp_deconv_bf16_destroy(pp_deconv_bf16* d);
+int pp_deconv_bf16_run(pp_deconv_bf16* d, const float* x, float* out, int batch, int relu, hipStream_t stream);
 int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream);
 // y = LayerNorm(x [+ pos[row % pos_mod]]) over the last dim; x_out (optional) receives x + pos in fp32
 int pp_launch_layernorm(const float* x, const float* pos, int pos_mod, float* x_out, const float* gamma,

@@ -384,6 +384,7 @@ int pp_vit_encoder_create(const float* params, int tokens, int dim, int depth, i
     // one throw-away pass on the scratch buffers: sets the kernels' dynamic-LDS attributes now, so that a later first
     // launch inside a hipGraph capture (pp_net_capture) does not have to
     PP_HIP_CHECK(hipMemsetAsync(e->scratch, 0, bytes, stream));
+    if (pp_gemm_bf16_prepare() != PP_OK) return PP_ERR_HIP;
     int rc = pp_vit_encoder_run(e.get(), e->X, e->X, 1, stream);
     if (rc != PP_OK) return rc;
     *out = e.release();

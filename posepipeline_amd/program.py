@@ -188,6 +188,29 @@ class ProgramBuilder:
                               flops=0.0))
         return out
 
+    def deconv4x4s2_bf16(self, x, weight, bias, *, relu=L.PP_RELU_NONE, name="deconv_bf16") -> int:
+        """ConvTranspose2d(kernel 4, stride 2, padding 1) (+ folded BN, ReLU) as ONE bf16 GEMM over the 16 kernel taps +
+        a 4-term gather (PP_OP_DECONV_BF16).  weight: torch ConvTranspose2d layout [cin][cout][4][4], BN already folded."""
+        h, w, cin_buf = self.dims(x)
+        wt = np.asarray(weight, dtype=np.float32)
+        cin, cout = wt.shape[:2]
+        assert wt.shape[2:] == (4, 4) and cin == cin_buf and cin % 64 == 0 and cout % 8 == 0, (wt.shape, cin_buf)
+        blocks = np.empty((2, 2, 2, 2, cout, cin), np.float32)           # [a][b][r][s][cout][cin]
+        for a in (0, 1):
+            for b in (0, 1):
+                for r in (0, 1):
+                    for s in (0, 1):
+                        blocks[a, b, r, s] = wt[:, :, 3 - a - 2 * r, 3 - b - 2 * s].T
+        bb = np.zeros(cout, np.float32) if bias is None else np.asarray(bias, np.float32)
+        out = self.buf(2 * h, 2 * w, cout)
+        w_off = self._add_blob(blocks)
+        b_off = self._add_blob(bb)
+        self.vops.append(dict(type=L.PP_OP_DECONV_BF16, in_=x, out=out, res1=-1, res2=-1, cin=cin, cout=cout, kh=4, kw=4,
+                              stride=2, pad_h=1, pad_w=1, dil_h=1, dil_w=1, relu=relu, up_log2=0, out_nchw=0, res1_shift=0,
+                              res1_off_w=0, out_c_off=0, in_c_off=0, pad_end=0, w_off=w_off, b_off=b_off, name=name,
+                              flops=2.0 * h * w * cin * cout * 16))
+        return out
+
     def depth_to_space(self, x, name="depth_to_space") -> int:
         """[h][w][4c] (channel groups g = 2*dy + dx) -> [2h][2w][c]"""
         h, w, c4 = self.dims(x)

@@ -104,7 +104,7 @@ def test_conv_input_beyond_2_gib(ctx, n):
 def test_vitpose_huge_full_size(ctx):
     """configs[4] at full size: ViTPose-H (32 blocks, dim 1280) on 256x192.  One sample against the CPU oracle that rounds
     to bf16 at the same points (tolerance: 1e-2 of the heat-map range -- fp32 accumulation order and the occasional
-    1-ulp bf16 flip over 32 blocks; 4.5e-3 measured), and the size-independent properties: batch-position and batch-size
+    1-ulp bf16 flip over 32 blocks; 5.7e-3 measured), and the size-independent properties: batch-position and batch-size
     independence are EXACT (each output element is one MFMA chain over K in a fixed order, whatever the tile shape),
     and the hipGraph replay reproduces the same bits."""
     from oracle import vit as ovit

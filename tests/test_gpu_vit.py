@@ -211,3 +211,24 @@ def test_vitpose_small_program(ctx):
     got_tok = net.read(prog.ops[0].out, n).reshape(n, SMALL.tokens, SMALL.dim)
     np.testing.assert_allclose(got_tok, tok, rtol=1e-4, atol=1e-4)
     net.close()
+
+
+def test_deconv_bf16_op(ctx):
+    """PP_OP_DECONV_BF16 (one GEMM over the 16 kernel taps + gather) against the direct float64 ConvTranspose2d(4, 2, 1)
+    of the same bf16-rounded operands: fp32 accumulation tolerance only; borders (absent taps) included."""
+    rng = np.random.default_rng(15)
+    cin, cout, h, w, n = 128, 24, 5, 7, 3
+    x = rng.standard_normal((n, h, w, cin), dtype=np.float32)
+    wt = rng.standard_normal((cin, cout, 4, 4), dtype=np.float32) * np.float32(0.1)
+    bias = rng.standard_normal(cout, dtype=np.float32)
+    b = ProgramBuilder()
+    xin = b.buf(h, w, cin, name="input")
+    y = b.deconv4x4s2_bf16(xin, wt, bias, relu=L.PP_RELU_LAST)
+    out = b.buf(2 * h, 2 * w, cout, name="output")
+    b.conv(y, np.eye(cout, dtype=np.float32).reshape(cout, cout, 1, 1), None, out=out, name="copy")
+    net = Net(ctx, b.build(), n)
+    got = net.forward(x)
+    ref = np.maximum(OV.conv_transpose_4s2p1(OV.bf16_round(x), OV.bf16_round(wt)) + bias.astype(np.float64), 0.0)
+    np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4)
+    assert (got == 0).any() and (got > 0).any()
+    net.close()
