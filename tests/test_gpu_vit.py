@@ -232,3 +232,28 @@ def test_deconv_bf16_op(ctx):
     np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-4)
     assert (got == 0).any() and (got > 0).any()
     net.close()
+
+
+@pytest.mark.parametrize("cfg", ["2", "8", "9"])
+def test_two_stage_schedules_are_race_free_and_bit_equal_to_single_stage(ctx, monkeypatch, cfg):
+    """The pipelined schedules (loads of K tile k + 1 in flight while tile k is multiplied; one barrier per K step) on a
+    chip-filling problem, 25 launches: every launch must reproduce the first bit for bit, and all of them the plain
+    single-stage kernel (every output element is the same MFMA chain over K whatever the tiling), so a landing-order race
+    on an LDS stage cannot hide behind a tolerance."""
+    m, n, k = 6144, 3840, 1280
+    rng = np.random.default_rng(99)
+    a = OV.bf16_bits(rng.standard_normal((m, k), dtype=np.float32))
+    w = OV.bf16_bits(rng.standard_normal((n, k), dtype=np.float32) / np.float32(np.sqrt(k)))
+    da, dw, dc = Dev(ctx, a), Dev(ctx, w), Dev(ctx, nbytes=m * n * 4)
+
+    def run(c):
+        monkeypatch.setenv("POSEPIPE_GEMM_CFG", c)
+        L.check(ctx.lib.pp_gemm_bf16(ctx.handle, da.ptr, dw.ptr, None, None, 0, dc.ptr, m, n, k, 0, 0), "pp_gemm_bf16")
+        ctx.synchronize()
+        return dc.get((m, n), np.float32)
+
+    base = run("0")
+    for _ in range(25):
+        assert np.array_equal(run(cfg), base)
+    for d in (da, dw, dc):
+        d.free()
