@@ -115,8 +115,11 @@ def synth_1080p(rng, n_frames, persons, h=1080, w=1920):
     for p in range(persons):
         bw = int(rng.integers(80, 200))
         bh = int(rng.integers(250, 600))
+        # slow enough that the looped chunk is one continuous track for the tracker (frame 31 -> frame 0 keeps IoU > 0.5):
+        # a step then is the steady state of a long clip -- B new frames of 2D and B frames of 3D per person -- instead of a
+        # track death + birth (with their fills) at every step boundary
         people.append(dict(w=bw, h=bh, x=float(rng.uniform(0, w - bw - 60)), y=float(rng.uniform(0, h - bh)),
-                           vx=float(rng.uniform(1, 4)), tex=rng.integers(0, 256, (bh, bw, 3)).astype(np.uint8)))
+                           vx=float(rng.uniform(0.2, 0.6)), tex=rng.integers(0, 256, (bh, bw, 3)).astype(np.uint8)))
     boxes = []
     for t in range(n_frames):
         f = bg.copy()

@@ -31,8 +31,9 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 3   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
-                              3: PP_OP_VIT_ENCODER / PP_OP_DEPTH_TO_SPACE, bf16 building blocks, UDP top-down (post 2) */
+#define PP_ABI_VERSION 4   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
+                              3: PP_OP_VIT_ENCODER / PP_OP_DEPTH_TO_SPACE, bf16 building blocks, UDP top-down (post 2)
+                              4: pp_memcpy_d2d, pp_net_create_mem (weights already on the device, e.g. an RCCL broadcast) */
 
 typedef enum {
     PP_OK = 0,
@@ -65,6 +66,8 @@ int pp_malloc(pp_ctx* ctx, size_t bytes, void** dptr);
 int pp_free(pp_ctx* ctx, void* dptr);
 int pp_memcpy_h2d(pp_ctx* ctx, void* dst, const void* src, size_t bytes);
 int pp_memcpy_d2h(pp_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* device -> device on the ctx stream, asynchronous (ordered with the other work of the ctx) */
+int pp_memcpy_d2d(pp_ctx* ctx, void* dst, const void* src, size_t bytes);
 /* Frame upload path (replaces the per-frame cv2.VideoCapture.read() -> model H2D of wrappers/mmtrack.py:38-45 and
  * wrappers/mmpose.py:60-75 with a chunked, double-buffered transfer): page-locked host staging buffers and an
  * asynchronous host->device copy on the context's copy stream, so chunk k+1 is uploaded while chunk k computes.
@@ -145,6 +148,11 @@ typedef struct pp_buf {
  * size of the resident activation arena. */
 int pp_net_create(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, int n_bufs,
                   const float* weights, size_t n_weights, int max_batch, pp_net** out);
+/* same, with `weights` in `weights_mem` memory: PP_MEM_DEVICE takes a blob that is already resident (the tensor an
+ * RCCL broadcast delivered -- wrappers/mmtrack.py:30 / wrappers/mmpose.py:57 load a checkpoint file per process instead)
+ * and copies it device-to-device into the program's own allocation; no host round trip. */
+int pp_net_create_mem(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, int n_bufs,
+                      const float* weights, size_t n_weights, int weights_mem, int max_batch, pp_net** out);
 void pp_net_destroy(pp_net* net);
 /* device address of activation buffer `buf` (batch-major, then the pp_buf layout) */
 int pp_net_buffer(pp_net* net, int buf, void** dptr, size_t* bytes_per_sample);

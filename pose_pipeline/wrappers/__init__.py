@@ -1,0 +1,1 @@
+"""Module-path shim, see pose_pipeline/__init__.py."""

@@ -77,12 +77,14 @@ SIGNATURES = {
     "pp_free": (_i, [_vp, _vp]),
     "pp_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
     "pp_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "pp_memcpy_d2d": (_i, [_vp, _vp, _vp, _sz]),
     "pp_host_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "pp_host_free": (_i, [_vp, _vp]),
     "pp_upload_begin": (_i, [_vp, _vp, _vp, _sz]),
     "pp_upload_wait": (_i, [_vp, _i]),
     "pp_upload_release": (_i, [_vp]),
     "pp_net_create": (_i, [_vp, C.POINTER(pp_op), _i, C.POINTER(pp_buf), _i, _vp, _sz, _i, C.POINTER(_vp)]),
+    "pp_net_create_mem": (_i, [_vp, C.POINTER(pp_op), _i, C.POINTER(pp_buf), _i, _vp, _sz, _i, _i, C.POINTER(_vp)]),
     "pp_net_destroy": (None, [_vp]),
     "pp_net_buffer": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_sz)]),
     "pp_net_run": (_i, [_vp, _i, _i, _i]),
@@ -224,6 +226,10 @@ class Context:
     def h2d(self, dptr: int, arr: np.ndarray):
         arr = np.ascontiguousarray(arr)
         check(self.lib.pp_memcpy_h2d(self.handle, C.c_void_p(dptr), ptr(arr), arr.nbytes), "pp_memcpy_h2d")
+
+    def d2d(self, dst: int, src: int, nbytes: int):
+        """asynchronous device-to-device copy on the context's stream"""
+        check(self.lib.pp_memcpy_d2d(self.handle, C.c_void_p(dst), C.c_void_p(src), nbytes), "pp_memcpy_d2d")
 
     def d2h(self, arr: np.ndarray, dptr: int):
         assert arr.flags["C_CONTIGUOUS"]

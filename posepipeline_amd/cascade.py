@@ -1,12 +1,18 @@
 """The whole hot path in one object: detect -> track -> select person boxes -> top-down 2D -> 3D lifting.
 
-This is what the three Computed tables of the reference do one after the other for a video
+This is what the Computed tables of the reference do one after the other for a video
 (`TrackingBbox.make` -> `PersonBbox.make` -> `TopDownPerson.make` -> `LiftingPerson.make`,
 pose_pipeline/pipeline.py:515-578, 656-687, 1017-1095, 1259-1416, driven by
 utils/standard_pipelines.py:110-164), restructured as a chunked stream: a chunk of frames is resident
 on the device once and every stage consumes it there, instead of three full decodes of the file and
 batch-1 model calls.  Used by bench.py (headline metric) and by tests; the table-by-table drop-in path
 lives in posepipeline_amd/wrappers/.
+
+What is emitted is defined in person_stream.py: for every followed track id the values the reference's table chain
+stores for `keep_tracks = [tid]` -- PersonBbox's bfill / ffill(limit 2), zero rows for absent frames, VideoPose3D
+over the window [t-121, t+121] of the WHOLE clip -- with the latency those look-aheads need: the crops of frames whose
+box is back-filled from the next chunk come from a 2-frame tail buffer kept on the device, frame t is lifted once frame
+t+121 has its key points, `flush()` emits the rest at the end of the clip.
 """
 from __future__ import annotations
 
@@ -18,51 +24,86 @@ from .models import faster_rcnn as fr
 from .models import hrnet
 from .models import vitpose
 from .models import videopose3d as vp3d
+from .person_stream import FILL_LIMIT, PersonStreams, collect  # noqa: F401  (collect: re-exported for callers)
 from .program import Net
 from .tracking import Tracker
-from .wrappers.videopose3d import lift, normalize_screen_coordinates
+from .wrappers.videopose3d import lift
 
 
 class Cascade:
     """tracking: "MMTrack_deepsort" (Faster-RCNN R50-FPN + SORT, det_sd = detector weights) or "DeepSortYOLOv4"
-    (tracking_method 0, the reference recipes' default: det_sd = (yolov4 weights, mars-small128 weights))."""
+    (tracking_method 0, the reference recipes' default: det_sd = (yolov4 weights, mars-small128 weights)).
+    max_persons / keep_tracks: which track ids are followed (person_stream.PersonStreams).
+    In "DeepSortYOLOv4" mode every track the tracker keeps is a row of every frame (tentative and missed ones with their
+    Kalman box), because that is what the reference stores (parser.py:76-86) and PersonBbox selects from."""
 
     def __init__(self, ctx: L.Context, det_sd, pose_sd: dict, lift_sd: dict, src_h: int, src_w: int,
                  chunk: int = 8, max_persons: int = 1, pose_spec=None, post="unbiased", blur_kernel=17,
-                 tracking: str = "MMTrack_deepsort"):
+                 tracking: str = "MMTrack_deepsort", keep_tracks=None, flip_pairs=None, blobs_dev=None):
+        """blobs_dev: optional {"det_a", "det_b", "pose", "lift"} -> (device pointer, n_floats): weight blobs that are already
+        resident on the device (parallel.py: delivered by an RCCL broadcast); the *_sd arguments still define the programs."""
         self.ctx = ctx
         self.src = (src_h, src_w)
         self.chunk = chunk
         self.max_persons = max_persons
         self.tracking = tracking
+        self.keep_tracks = keep_tracks
+        bd = blobs_dev or {}
         if tracking == "DeepSortYOLOv4":
             from .models import mars, yolov4
             self.detector = yolov4.YoloV4Detector(ctx, det_sd[0], src_h, src_w, max_frames=chunk)
             self.encoder = mars.MarsEncoder(ctx, det_sd[1], src_h, src_w, max_patches=max(64, chunk * max_persons))
         else:
             assert tracking == "MMTrack_deepsort", tracking
-            self.detector = fr.Detector(ctx, det_sd, src_h, src_w, max_frames=chunk)
+            self.detector = fr.Detector(ctx, det_sd, src_h, src_w, max_frames=chunk,
+                                        blobs_dev=(bd.get("det_a"), bd.get("det_b")))
         self.pose_spec = pose_spec or hrnet.hrnet_w48_384x288()
         if isinstance(self.pose_spec, vitpose.VitPoseSpec):     # BASELINE.json configs[4]: ViTPose 2D stage (UDP, bf16 MFMA)
             pose_prog = vitpose.build_vitpose_program(self.pose_spec, pose_sd)
             post, blur_kernel, shift = "udp", 11, False
+            self.k = 17
         else:
             pose_prog = hrnet.build_hrnet_program(self.pose_spec, pose_sd)
             shift = True
-        self.pose_net = Net(ctx, pose_prog, max_batch=2 * chunk * max_persons)
-        self.topdown = ops.TopDown(self.pose_net, 17, flip_perm=hrnet.flip_perm(17), shift_heatmap=shift, post=post,
-                                   blur_kernel=blur_kernel)
+            self.k = int(self.pose_spec.num_joints)
+        self.pose_net = Net(ctx, pose_prog, max_batch=2 * chunk * max_persons, blob_dev=bd.get("pose"))
+        if flip_pairs is None:
+            flip_pairs = {17: hrnet.COCO_FLIP_PAIRS, 133: hrnet.WHOLEBODY_FLIP_PAIRS, 136: hrnet.HALPE_FLIP_PAIRS}[self.k]
+        self.topdown = ops.TopDown(self.pose_net, self.k, flip_perm=hrnet.flip_perm(self.k, flip_pairs), shift_heatmap=shift,
+                                   post=post, blur_kernel=blur_kernel)
         self.lift_spec = vp3d.VideoPose3DSpec()
-        self.lift_net = Net(ctx, vp3d.build_videopose3d_program(self.lift_spec, lift_sd), max_batch=max(1, max_persons))
+        self.lift_net = Net(ctx, vp3d.build_videopose3d_program(self.lift_spec, lift_sd), max_batch=max(1, max_persons),
+                            blob_dev=bd.get("lift"))
+        self.frame_bytes = src_h * src_w * 3
+        self.tail_dev = None          # device copy of the last FILL_LIMIT frames (slot = frame % FILL_LIMIT)
+        self.tail_host = None
+        self._cur = None              # (frames, frames_dev, first frame) of the chunk being processed
         self.reset()
+
+    def close(self):
+        if self.tail_dev is not None and getattr(self.ctx, "handle", None):
+            self.ctx.free(self.tail_dev)
+        self.tail_dev = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def reset(self):
         if self.tracking == "DeepSortYOLOv4":
             self.tracker = Tracker(mode=0, feat_dim=128, max_cosine_distance=0.3)       # parser.py:35-47
         else:
             self.tracker = Tracker(mode=1, match_iou_thr=0.5, obj_score_thr=0.5)
-        self.tracks = []          # per frame: list of (track_id, x1, y1, x2, y2, score)
-        self.kp2d = {}            # track_id -> list of (frame, (17,3))
+        # the lifting network takes the 17 COCO joints; wider heads (Halpe-136 / WholeBody-133) start with them
+        self.persons = PersonStreams(self.k, self.lift_spec.pad, self.src, self._topdown_jobs,
+                                     lambda kn: lift(self.lift_net, self.lift_spec, kn[:, :17]),
+                                     max_persons=self.max_persons, keep_tracks=self.keep_tracks)
+
+    @property
+    def n_frames(self):
+        return self.persons.n_frames
 
     @property
     def flops_per_frame(self):
@@ -70,17 +111,12 @@ class Cascade:
         return (self.detector.flops_per_frame + 2 * self.max_persons * self.pose_net.prog.flops +
                 self.max_persons * self.lift_net.prog.flops / self.lift_spec.chunk)
 
-    def step(self, frames, frames_dev=None, replay=None):
-        """One chunk.  frames: numpy [B][H][W][3] u8 BGR, or frames_dev=(device pointer, B).
-        replay: optional per-frame [n][5] boxes that stand in for the detector's output downstream (bench
-        with random-weight detectors, SURVEY.md 8d) -- the detector still runs.
-        Returns dict(tracks=per-frame rows, keypoints={track_id: (B,17,3)}, keypoints_3d={track_id: (B,17,3)})."""
-        b = frames_dev[1] if frames_dev is not None else frames.shape[0]
+    # ---- stage 1: detect + associate ------------------------------------------------------------------------
+    def _track_chunk(self, frames, frames_dev, replay):
         dets = self.detector.run(frames, frames_dev=frames_dev)
         chunk_tracks = []
         if self.tracking == "DeepSortYOLOv4":
-            # wrappers/deep_sort_yolov4/parser.py:52-86 per frame: persons -> appearance features -> NMS(1.0) -> DeepSORT;
-            # every live track is reported (tentative and missed ones with their Kalman box), like the reference's tables
+            # wrappers/deep_sort_yolov4/parser.py:52-86 per frame: persons -> appearance features -> NMS(1.0) -> DeepSORT
             if replay is not None:      # [n][5] x1 y1 x2 y2 score -> the int (x, y, w, h) boxes yolo.detect_image returns
                 dets = [(np.array([[int(r[0]), int(r[1]), int(r[2] - r[0]), int(r[3] - r[1])] for r in rows], np.int64).reshape(-1, 4),
                          np.asarray(rows, np.float32).reshape(-1, 5)[:, 4]) for rows in replay]
@@ -89,7 +125,7 @@ class Cascade:
                 tlwh, sc = boxes.astype(np.float64), conf.astype(np.float64)
                 keep = ops.nms(self.ctx, tlwh, sc, 1.0, convention=1) if len(tlwh) else np.zeros(0, np.int64)
                 ids, t, _ = self.tracker.step(tlwh[keep], sc[keep], feat[keep])
-                chunk_tracks.append([(int(i), bb[0], bb[1], bb[0] + bb[2], bb[1] + bb[3], 1.0) for i, bb in zip(ids, t)])
+                chunk_tracks.append([(int(i), bb[0], bb[1], bb[0] + bb[2], bb[1] + bb[3], 1.0, bb.copy()) for i, bb in zip(ids, t)])
         else:
             if replay is not None:
                 dets = replay
@@ -97,41 +133,81 @@ class Cascade:
                 rows = np.asarray(rows, np.float32).reshape(-1, 5)
                 ids, _, info = self.tracker.step(rows[:, :4].astype(np.float64), rows[:, 4].astype(np.float64))
                 chunk_tracks.append([(int(i), *rows[j]) for i, j in zip(ids, info[:, 1])])
-        f0 = len(self.tracks)
-        self.tracks += chunk_tracks
-        # person-frames for the 2D stage: every tracked box of the chunk (up to max_persons per frame)
-        fidx, boxes, owner = [], [], []
-        for t, fr_tracks in enumerate(chunk_tracks):
-            for (tid, x1, y1, x2, y2, _s) in fr_tracks[: self.max_persons]:
-                fidx.append(t)
-                boxes.append([x1, y1, x2 - x1, y2 - y1])
-                owner.append(tid)
-        kp = {}
-        kp3d = {}
-        if boxes:
+        return chunk_tracks
+
+    # ---- stage 2: top-down 2D on the decided person-frames --------------------------------------------------------
+    def _topdown_jobs(self, jobs):
+        """jobs: [(track_id, frame, tlwh)].  Crops come from the current chunk or, for frames of an earlier chunk whose box
+        was back-filled only now, from the tail buffer."""
+        frames, frames_dev, n0 = self._cur
+        cap = max(1, self.pose_net.max_batch // 2)
+        res = [None] * len(jobs)
+        cur = [i for i, j in enumerate(jobs) if j[1] >= n0]
+        old = [i for i, j in enumerate(jobs) if j[1] < n0]
+        for group, is_tail in ((old, True), (cur, False)):
+            for i0 in range(0, len(group), cap):
+                part = group[i0:i0 + cap]
+                boxes = np.array([jobs[i][2] for i in part], np.float64)
+                if is_tail:
+                    fidx = np.array([jobs[i][1] % FILL_LIMIT for i in part], np.int32)
+                    if self.tail_dev is not None:
+                        k2, _ = self.topdown.run(self.tail_dev, fidx, boxes, frames_dev_shape=(FILL_LIMIT, *self.src))
+                    else:
+                        k2, _ = self.topdown.run(self.tail_host, fidx, boxes)
+                else:
+                    fidx = np.array([jobs[i][1] - n0 for i in part], np.int32)
+                    if frames_dev is not None:
+                        k2, _ = self.topdown.run(frames_dev[0], fidx, boxes, frames_dev_shape=(frames_dev[1], *self.src))
+                    else:
+                        k2, _ = self.topdown.run(frames, fidx, boxes)
+                for i, row in zip(part, k2):
+                    res[i] = row
+        return res
+
+    def _save_tail(self, frames, frames_dev, n0, n1):
+        """keep the last FILL_LIMIT frames: a frame that is absent now may be back-filled by the next chunk's boxes"""
+        for t in range(max(n0, n1 - FILL_LIMIT), n1):
+            slot = t % FILL_LIMIT
             if frames_dev is not None:
-                k2, _ = self.topdown.run(frames_dev[0], np.array(fidx, np.int32), np.array(boxes, np.float64),
-                                         frames_dev_shape=(b, self.src[0], self.src[1]))
+                if self.tail_dev is None:
+                    self.tail_dev = self.ctx.malloc(FILL_LIMIT * self.frame_bytes)
+                self.ctx.d2d(self.tail_dev + slot * self.frame_bytes, frames_dev[0] + (t - n0) * self.frame_bytes, self.frame_bytes)
             else:
-                k2, _ = self.topdown.run(frames, np.array(fidx, np.int32), np.array(boxes, np.float64))
-            for i, tid in enumerate(owner):
-                self.kp2d.setdefault(tid, []).append((f0 + fidx[i], k2[i]))
-            for tid in sorted(set(owner)):
-                hist = self.kp2d[tid]
-                # lift this chunk's frames with the context accumulated so far (halo = receptive field)
-                n_new = sum(1 for fi, _ in hist if fi >= f0)
-                ctx_frames = hist[-(n_new + 2 * self.lift_spec.pad):]
-                arr = np.stack([k for _, k in ctx_frames])
-                kn = normalize_screen_coordinates(arr[:, :, :2].astype(np.float64), self.src[1], self.src[0])
-                out = lift(self.lift_net, self.lift_spec, kn)
-                kp[tid] = arr[-n_new:]
-                kp3d[tid] = out[-n_new:]
-        return dict(tracks=chunk_tracks, keypoints=kp, keypoints_3d=kp3d)
+                if self.tail_host is None:
+                    self.tail_host = np.zeros((FILL_LIMIT, *self.src, 3), np.uint8)
+                self.tail_host[slot] = frames[t - n0]
+
+    def step(self, frames, frames_dev=None, replay=None):
+        """One chunk.  frames: numpy [B][H][W][3] u8 BGR, or frames_dev=(device pointer, B).
+        replay: optional per-frame [n][5] boxes that stand in for the detector's output downstream (bench
+        with random-weight detectors, SURVEY.md 8d) -- the detector still runs.
+        Returns dict(tracks = per-frame tracker rows of the chunk,
+                     keypoints / keypoints_frames = {track_id: (n,K,3) / (n,) frame numbers} decided in this step,
+                     keypoints_3d / keypoints_3d_frames = {track_id: (m,17,3) / (m,)} emitted in this step)."""
+        b = frames_dev[1] if frames_dev is not None else frames.shape[0]
+        chunk_tracks = self._track_chunk(frames, frames_dev, replay)
+        n0 = self.persons.n_frames
+        self.persons.ingest(chunk_tracks)
+        self._cur = (frames, frames_dev, n0)
+        out = self.persons.advance(final=False)
+        self._save_tail(frames, frames_dev, n0, n0 + b)
+        self._cur = None
+        out["tracks"] = chunk_tracks
+        return out
+
+    def flush(self):
+        """End of clip: decide the open boxes (nothing follows), lift the remaining frames with the reference's edge
+        replication.  Returns the same dict as step() with tracks = []."""
+        self._cur = (None, None, self.persons.n_frames)
+        out = self.persons.advance(final=True)
+        self._cur = None
+        out["tracks"] = []
+        return out
 
     def run_video(self, video, replay_fn=None, max_frames=None):
         """Whole clip, read once: frames stream through page-locked staging buffers and the copy stream
         (streaming.FrameStreamer) while the previous chunk computes.  video: video.open_video() object.
-        replay_fn(first, n) -> per-frame replay boxes (see step).  Yields step() results, one per chunk."""
+        replay_fn(first, n) -> per-frame replay boxes (see step).  Yields step() results, one per chunk, then flush()'s."""
         from .streaming import FrameStreamer
         assert (video.height, video.width) == self.src, ((video.height, video.width), self.src)
         streamer = FrameStreamer(self.ctx, video, self.chunk, max_frames=max_frames)
@@ -141,5 +217,8 @@ class Cascade:
                 streamer.release()
                 out["first_frame"] = first
                 yield out
+            out = self.flush()
+            out["first_frame"] = self.n_frames
+            yield out
         finally:
             streamer.close()

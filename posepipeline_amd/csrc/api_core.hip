@@ -180,6 +180,12 @@ int pp_memcpy_d2h(pp_ctx* ctx, void* dst, const void* src, size_t bytes) {
     return PP_OK;
 }
 
+int pp_memcpy_d2d(pp_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    PP_REQUIRE(ctx && (bytes == 0 || (dst && src)), "pp_memcpy_d2d: NULL argument");
+    PP_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return PP_OK;
+}
+
 }  // extern "C"
 
 // ---- layer programs ----------------------------------------------------------------------------
@@ -395,7 +401,13 @@ extern "C" {
 
 int pp_net_create(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, int n_bufs,
                   const float* weights, size_t n_weights, int max_batch, pp_net** out) {
+    return pp_net_create_mem(ctx, ops, n_ops, bufs, n_bufs, weights, n_weights, PP_MEM_HOST, max_batch, out);
+}
+
+int pp_net_create_mem(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, int n_bufs,
+                      const float* weights, size_t n_weights, int weights_mem, int max_batch, pp_net** out) {
     PP_REQUIRE(ctx && ops && bufs && weights && out, "pp_net_create: NULL argument");
+    PP_REQUIRE(weights_mem == PP_MEM_HOST || weights_mem == PP_MEM_DEVICE, "pp_net_create: bad weights_mem %d", weights_mem);
     PP_REQUIRE(n_ops > 0 && n_bufs > 0 && max_batch > 0, "pp_net_create: empty program");
     *out = nullptr;
     std::unique_ptr<pp_net> net(new pp_net());
@@ -419,7 +431,8 @@ int pp_net_create(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, 
     }
     PP_HIP_CHECK(hipSetDevice(ctx->device));
     PP_HIP_CHECK(hipMalloc((void**)&net->weights, n_weights * sizeof(float)));
-    PP_HIP_CHECK(hipMemcpyAsync(net->weights, weights, n_weights * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PP_HIP_CHECK(hipMemcpyAsync(net->weights, weights, n_weights * sizeof(float),
+                                weights_mem == PP_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
     PP_HIP_CHECK(hipMalloc((void**)&net->arena, net->arena_floats * sizeof(float)));
     PP_HIP_CHECK(hipMemsetAsync(net->arena, 0, net->arena_floats * sizeof(float), ctx->stream));
     net->vits.assign(n_ops, nullptr);

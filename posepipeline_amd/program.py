@@ -299,7 +299,9 @@ class ProgramBuilder:
 class Net:
     """pp_net handle: resident weights + activation arena on one Context."""
 
-    def __init__(self, ctx: L.Context, prog: Program, max_batch: int):
+    def __init__(self, ctx: L.Context, prog: Program, max_batch: int, blob_dev=None):
+        """blob_dev: optional (device pointer, n_floats) of a weight blob that is already resident on ctx's device -- the
+        tensor an RCCL broadcast delivered; prog.blob (host) is not read then."""
         self.ctx = ctx
         self.prog = prog
         self.max_batch = int(max_batch)
@@ -308,9 +310,14 @@ class Net:
         ops = (L.pp_op * n_ops)(*prog.ops)
         bufs = (L.pp_buf * len(prog.bufs))(*[L.pp_buf(*d) for d in prog.bufs])
         h = C.c_void_p()
-        blob = np.ascontiguousarray(prog.blob, dtype=np.float32)
-        L.check(lib.pp_net_create(ctx.handle, ops, n_ops, bufs, len(prog.bufs), L.ptr(blob), blob.size, self.max_batch,
-                                  C.byref(h)), "pp_net_create")
+        if blob_dev is not None:
+            dptr, n_floats = blob_dev
+            L.check(lib.pp_net_create_mem(ctx.handle, ops, n_ops, bufs, len(prog.bufs), C.c_void_p(int(dptr)), int(n_floats),
+                                          L.PP_MEM_DEVICE, self.max_batch, C.byref(h)), "pp_net_create_mem")
+        else:
+            blob = np.ascontiguousarray(prog.blob, dtype=np.float32)
+            L.check(lib.pp_net_create(ctx.handle, ops, n_ops, bufs, len(prog.bufs), L.ptr(blob), blob.size, self.max_batch,
+                                      C.byref(h)), "pp_net_create")
         self.handle = h
 
     def close(self):

@@ -67,7 +67,14 @@ class Tracker:
         L.check(self.lib.pp_tracker_step(self.handle, L.ptr(tlwh), L.ptr(conf), L.ptr(f), n, cap, L.ptr(ids), L.ptr(out),
                                          L.ptr(info), C.byref(k)), "pp_tracker_step")
         k = k.value
+        self._last_ids = set(int(i) for i in ids[:k])
         return ids[:k].copy(), out[:k].copy(), info[:k].copy()
+
+    def live_ids(self) -> set:
+        """ids that can still be reported by a later frame.  Both built modes report every track they keep: mode 0 emits
+        all of tracker.tracks per frame (parser.py:76-86), mode 1 (no ReID) can only re-associate tracks seen in the
+        previous frame -- so the live set is the id set of the last step."""
+        return getattr(self, "_last_ids", set())
 
     def dump(self, cap=1024):
         ids = np.zeros(cap, np.int64)
@@ -153,6 +160,9 @@ class ByteTracker:
         self.tracks: dict = {}      # id -> [mean8, cov64, last_frame, hits, tentative]
         self.num_tracks = 0
         self.frame_id = -1
+
+    def live_ids(self) -> set:
+        return set(int(i) for i in self.tracks)
 
     # Kalman steps through the C ABI
     def _kf(self, fn, mean, cov, z=None):

@@ -1,96 +1,135 @@
-"""Recipes that chain the hot-path tables, with the reference's names and arguments
-(pose_pipeline/utils/standard_pipelines.py:10-164 `tracking_pipeline`, `top_down_pipeline`,
-`lifting_pipeline`; pose_pipeline/utils/tracking.py:5-21 `annotate_single_person`).
+"""Recipes over the hot-path tables: video key -> tracking -> person box -> top-down 2D -> 3D lifting.
 
-Differences kept deliberately small: the default tracking method stays "MMTrack_deepsort" (the reference's default
-"DeepSortYOLOv4" is built too -- pass tracking_method_name="DeepSortYOLOv4"), the default lifter is "VideoPose3D"
-(instead of "GastNet"), the reference's "MMpose" default for the 2D method -- a name that is not in its own
-lookup table -- is "MMPose", and `BestDetectedFrames` / OpenPose branches (out of scope) are not called.
+Same entry points, arguments and return values as the reference's recipes
+(pose_pipeline/utils/standard_pipelines.py:10 `tracking_pipeline`, :56 `top_down_pipeline`, :110 `lifting_pipeline`;
+pose_pipeline/utils/tracking.py:5 `annotate_single_person`), so `scripts/process_h36m.py`-style callers run unchanged.
+The bodies are this package's own: every recipe is a walk over the declarative `STAGES` table below (lookup table ->
+method table -> computed tables), so adding a stage or a method is a table entry, not another copy of the sequence.
+
+Defaults that differ from the reference, on purpose: tracking "MMTrack_deepsort" (the reference's "DeepSortYOLOv4" is
+built as well: pass its name), lifting "VideoPose3D" (the reference's "GastNet" is outside the hot path), 2D method
+"MMPose" (the reference's default string "MMpose" is not a row of its own lookup table).  `BestDetectedFrames` and the
+OpenPose branch (out of scope) are not part of the walk.
 """
 from __future__ import annotations
 
+from dataclasses import dataclass
 from typing import Dict, List, Union
 
 import numpy as np
 
-from ..pipeline import (DetectedFrames, LiftingMethod, LiftingMethodLookup, LiftingPerson, PersonBbox, PersonBboxValid,
-                        TopDownMethod, TopDownMethodLookup, TopDownPerson, TrackingBbox, TrackingBboxMethod,
-                        TrackingBboxMethodLookup, VideoInfo)
+from .. import pipeline as P
+
+
+@dataclass(frozen=True)
+class Stage:
+    """A method-selectable stage: `<column>_name` in `lookup` names the method, `method` holds (parent key, method id),
+    `computed` are the tables that a populate() on that key fills."""
+    column: str
+    lookup: type
+    method: type
+    computed: tuple
+
+    def method_id(self, name: str):
+        return (self.lookup & f'{self.column}_name="{name}"').fetch1(self.column)
+
+    def enter(self, parent_key: dict, name: str) -> dict:
+        """parent key + this stage's method id, registered in the method table (idempotent)"""
+        key = {**parent_key, self.column: self.method_id(name)}
+        self.method.insert1(key, skip_duplicates=True)
+        return key
+
+    def run(self, key: dict, reserve_jobs: bool):
+        for table in self.computed:
+            table.populate(key, reserve_jobs=reserve_jobs)
+
+
+STAGES = {
+    "tracking": Stage("tracking_method", P.TrackingBboxMethodLookup, P.TrackingBboxMethod, (P.TrackingBbox,)),
+    "top_down": Stage("top_down_method", P.TopDownMethodLookup, P.TopDownMethod, (P.TopDownPerson,)),
+    "lifting": Stage("lifting_method", P.LiftingMethodLookup, P.LiftingMethod, (P.LiftingPerson,)),
+}
 
 
 def annotate_single_person(filt, subject_id=0, confirm=False):
-    """utils/tracking.py:5-21: videos whose tracker found exactly one identity get that identity as the subject"""
-    keys = ((TrackingBbox & filt & "num_tracks=1") - PersonBboxValid).fetch("KEY")
-    for k in keys:
-        tracks = (TrackingBbox & k).fetch1("tracks")
-        track_id = np.unique([[t["track_id"] for t in t2] for t2 in tracks if len(t2) > 0])
-        assert len(track_id) == 1, "Found two tracks, should not have"
-        k.update({"video_subject_id": subject_id, "keep_tracks": track_id})
-        PersonBboxValid.insert1(k)
+    """Videos in which the tracker found exactly one identity get that identity as their subject of interest
+    (PersonBboxValid row), unless they already have one.  confirm=True asks on stdin first."""
+    todo = ((P.TrackingBbox & filt & "num_tracks=1") - P.PersonBboxValid).fetch("KEY")
+    if confirm:
+        answer = input(f"{len(todo)} single-person video(s) can be annotated automatically -- proceed? [y/N] ")
+        if not answer.strip().lower().startswith("y"):
+            print("nothing annotated")
+            return
+    for key in todo:
+        per_frame = (P.TrackingBbox & key).fetch1("tracks")
+        ids = sorted({row["track_id"] for frame in per_frame for row in frame})
+        assert len(ids) == 1, f"num_tracks = 1 but the track list holds ids {ids}"
+        P.PersonBboxValid.insert1({**key, "video_subject_id": subject_id, "keep_tracks": np.asarray(ids)})   # stored as an array, like np.unique's
+
+
+def _as_list(keys):
+    return [keys] if isinstance(keys, dict) else list(keys)
+
+
+def _person_key(tracking_key: dict):
+    """the PersonBbox key under a tracking key, or None while no (single) subject has been annotated / computed"""
+    P.PersonBbox.populate(tracking_key, reserve_jobs=True)
+    rows = P.PersonBbox & tracking_key
+    return rows.fetch1("KEY") if len(rows) == 1 else None
 
 
 def tracking_pipeline(keys: Union[Dict, List[Dict]], tracking_method_name: str = "MMTrack_deepsort", reserve_jobs: bool = False):
-    """Run the pipeline on a video through to the tracking layer; returns the PersonBbox keys that resulted."""
-    if isinstance(keys, dict):
-        keys = [keys]
-    tracking_keys = []
-    for key in keys:
-        VideoInfo.populate(key, reserve_jobs=reserve_jobs)
-        tracking_key = key.copy()
-        tracking_method = (TrackingBboxMethodLookup & f'tracking_method_name="{tracking_method_name}"').fetch1("tracking_method")
-        tracking_key["tracking_method"] = tracking_method
-        TrackingBboxMethod.insert1(tracking_key, skip_duplicates=True)
-        TrackingBbox.populate(tracking_key, reserve_jobs=reserve_jobs)
-        annotate_single_person(key)                         # auto-annotate single-identity videos
-        PersonBbox.populate(tracking_key, reserve_jobs=True)
-        DetectedFrames.populate(tracking_key, reserve_jobs=reserve_jobs)
-        if len(PersonBbox & tracking_key) == 1:
-            tracking_keys.append((PersonBbox & tracking_key).fetch1("KEY"))
-    return tracking_keys
+    """Video key(s) -> tracked boxes -> (auto-annotated) subject -> smoothed person box.
+    Returns the PersonBbox keys of the videos that have exactly one."""
+    done = []
+    for video_key in _as_list(keys):
+        P.VideoInfo.populate(video_key, reserve_jobs=reserve_jobs)
+        tracking_key = STAGES["tracking"].enter(video_key, tracking_method_name)
+        STAGES["tracking"].run(tracking_key, reserve_jobs)
+        annotate_single_person(video_key)
+        person = _person_key(tracking_key)
+        P.DetectedFrames.populate(tracking_key, reserve_jobs=reserve_jobs)
+        if person is not None:
+            done.append(person)
+    return done
 
 
 def top_down_pipeline(key: Union[Dict, List[Dict]], tracking_method_name: str = "MMTrack_deepsort",
                       top_down_method_name: str = "MMPose", reserve_jobs: bool = False):
-    """... through to the top-down person layer; returns the TopDownPerson keys (False while annotation is pending)."""
-    tracking_keys = tracking_pipeline(key, tracking_method_name, reserve_jobs=reserve_jobs)
-    top_down_person_keys = []
-    for tracking_key in tracking_keys:
-        PersonBbox.populate(tracking_key, reserve_jobs=True)
-        if len(PersonBbox & tracking_key) == 0:
-            if len(PersonBboxValid & tracking_key) == 1 and (PersonBboxValid & tracking_key).fetch1("video_subject_id") < 0:
-                print(f"Video {key} marked as invalid.")
-                return False
-            print(f"Waiting for annotation of subject of interest. {tracking_key}")
+    """... -> 2D key points of the subject.  Returns the TopDownPerson keys; False as soon as a video has no person box
+    (its subject is not annotated yet, or was marked invalid with a negative video_subject_id)."""
+    out = []
+    for person in tracking_pipeline(key, tracking_method_name, reserve_jobs=reserve_jobs):
+        if _person_key(person) is None:
+            marked = P.PersonBboxValid & person
+            if len(marked) == 1 and marked.fetch1("video_subject_id") < 0:
+                print(f"{key}: marked invalid, skipped")
+            else:
+                print(f"{person}: no subject of interest annotated yet")
             return False
-        top_down_key = (PersonBbox & tracking_key).fetch1("KEY")
-        top_down_method = (TopDownMethodLookup & f'top_down_method_name="{top_down_method_name}"').fetch1("top_down_method")
-        top_down_key["top_down_method"] = top_down_method
-        TopDownMethod.insert1(top_down_key, skip_duplicates=True)
-        TopDownPerson.populate(top_down_key, reserve_jobs=reserve_jobs)
-        top_down_person_keys.append(top_down_key)
-    return top_down_person_keys
+        top_down_key = STAGES["top_down"].enter(person, top_down_method_name)
+        STAGES["top_down"].run(top_down_key, reserve_jobs)
+        out.append(top_down_key)
+    return out
 
 
 def lifting_pipeline(key, tracking_method_name: str = "MMTrack_deepsort", top_down_method_name: str = "MMPose",
                      lifting_method_name: str = "VideoPose3D", reserve_jobs: bool = False):
-    """... through to the lifting layer; returns whether a LiftingPerson row now exists for the video."""
-    res = top_down_pipeline(key, tracking_method_name, top_down_method_name, reserve_jobs=reserve_jobs)
-    if not res:
-        return res
-    tracking_key = key.copy()
-    tracking_key["tracking_method"] = (TrackingBboxMethodLookup & f'tracking_method_name="{tracking_method_name}"').fetch1("tracking_method")
-    top_down_key = (PersonBbox & tracking_key).fetch1("KEY")
-    top_down_key["top_down_method"] = (TopDownMethodLookup & f'top_down_method_name="{top_down_method_name}"').fetch1("top_down_method")
-    if len(TopDownPerson & top_down_key) == 0:
-        print(f"Top down job must be reserved and not completed. {top_down_key}")
+    """... -> 3D joints.  Returns True when the video has a LiftingPerson row afterwards; the falsy result of
+    top_down_pipeline, or False, when an upstream row is missing (another worker holds the job)."""
+    upstream = top_down_pipeline(key, tracking_method_name, top_down_method_name, reserve_jobs=reserve_jobs)
+    if not upstream:
+        return upstream
+    person = (P.PersonBbox & {**key, "tracking_method": STAGES["tracking"].method_id(tracking_method_name)}).fetch1("KEY")
+    top_down_key = {**person, "top_down_method": STAGES["top_down"].method_id(top_down_method_name)}
+    if len(P.TopDownPerson & top_down_key) == 0:
+        print(f"{top_down_key}: 2D key points not available (job reserved elsewhere?)")
         return False
-    lifting_key = top_down_key.copy()
-    lifting_key["lifting_method"] = (LiftingMethodLookup & f'lifting_method_name="{lifting_method_name}"').fetch1("lifting_method")
-    LiftingMethod.insert1(lifting_key, skip_duplicates=True)
-    LiftingPerson.populate(key, reserve_jobs=reserve_jobs)
-    if len(LiftingPerson & lifting_key) == 0:
-        print(f"Lifting job must be reserved and not completed. {lifting_key}")
+    lifting_key = STAGES["lifting"].enter(top_down_key, lifting_method_name)
+    STAGES["lifting"].run(key, reserve_jobs)
+    if len(P.LiftingPerson & lifting_key) == 0:
+        print(f"{lifting_key}: 3D joints not available (job reserved elsewhere?)")
         return False
-    VideoInfo.populate(key, reserve_jobs=reserve_jobs)
-    DetectedFrames.populate(key, reserve_jobs=reserve_jobs)
-    return len(LiftingPerson & key) > 0
+    for table in (P.VideoInfo, P.DetectedFrames):
+        table.populate(key, reserve_jobs=reserve_jobs)
+    return len(P.LiftingPerson & key) > 0

@@ -1,6 +1,7 @@
 """N > 1 path on CPU: world_size-2 gloo processes run the frame-sharded cascade orchestration
-(posepipeline_amd/parallel.py) with the real host stages (C++ SORT tracker, PersonBbox selection) and stub
-compute stages; the result must equal the single-process run bit for bit."""
+(posepipeline_amd/parallel.py) with the real host stages (C++ SORT tracker, PersonStreams box decisions) and stub
+compute stages; the result must equal the single-process run -- sharded over one rank, and streamed chunk by chunk the
+way cascade.Cascade does it -- bit for bit.  The same orchestration with the GPU stages: tests/test_gpu_sharded.py."""
 import os
 import socket
 import tempfile
@@ -12,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from posepipeline_amd import parallel
-from posepipeline_amd.tracking import Tracker, person_bbox
+from posepipeline_amd.tracking import Tracker
 
 N_FRAMES = 37      # odd: shards of 18 and 19 frames
 
@@ -38,41 +39,60 @@ def associate(all_dets):
     tracks = []
     for rows in all_dets:
         ids, _, info = trk.step(rows[:, :4].astype(np.float64), rows[:, 4].astype(np.float64))
-        fr = []
-        for i, j in zip(ids, info[:, 1]):
-            x = rows[j]
-            fr.append({"track_id": int(i), "tlbr": x[:4], "tlhw": np.array([x[0], x[1], x[2] - x[0], x[3] - x[1]]),
-                       "confidence": x[4]})
-        tracks.append(fr)
-    bbox, _ = person_bbox(tracks, [0])
-    return bbox, tracks
+        tracks.append([(int(i), *rows[j]) for i, j in zip(ids, info[:, 1])])
+    return tracks
 
 
-def fake_topdown(frame_ids, bbox_rows):
-    kp = np.zeros((len(frame_ids), 17, 3))
-    for i, (t, bb) in enumerate(zip(frame_ids, bbox_rows)):
-        if np.isnan(bb).any():
-            continue
-        j = np.arange(17)
-        kp[i, :, 0] = bb[0] + bb[2] * (j % 4) / 4.0 + 0.01 * t
-        kp[i, :, 1] = bb[1] + bb[3] * (j // 4) / 5.0
-        kp[i, :, 2] = 0.5 + 0.01 * j
+def fake_rows(frame_ids, boxes):
+    kp = np.zeros((len(frame_ids), 17, 3), np.float32)
+    j = np.arange(17)
+    for i, (t, bb) in enumerate(zip(frame_ids, boxes)):
+        kp[i, :, 0] = np.float32(bb[0]) + np.float32(bb[2]) * (j % 4).astype(np.float32) / np.float32(4) + np.float32(t)
+        kp[i, :, 1] = np.float32(bb[1]) + np.float32(bb[3]) * (j // 4).astype(np.float32) / np.float32(8)
+        kp[i, :, 2] = np.float32(0.5) + np.float32(0.01) * j.astype(np.float32)
     return kp
 
 
-def fake_lift(kp_all, lo, hi):
-    n = kp_all.shape[0]
-    out = np.zeros((hi - lo, 17, 3))
-    for i, t in enumerate(range(lo, hi)):
-        idx = np.clip(np.arange(t - 121, t + 122), 0, n - 1)        # 243-frame edge-replicated window
-        out[i, :, :2] = kp_all[idx, :, :2].mean(axis=0)
-        out[i, :, 2] = t
-    return out
+PAD = 6
+SRC = (1024, 2048)
 
 
-def run(d):
-    return parallel.process_video_sharded(d, N_FRAMES, lambda lo, hi: np.arange(lo, hi), fake_detect, associate, fake_topdown,
-                                          fake_lift)
+def fake_lift(kn):
+    """a function of the whole +-PAD window of every frame (edge-clamped inside the passed context, like pp_videopose3d_lift)"""
+    n = kn.shape[0]
+    p = np.pad(kn.astype(np.float32), ((PAD, PAD), (0, 0), (0, 0)), mode="edge")
+    w = np.stack([p[i:i + 2 * PAD + 1] for i in range(n)]).astype(np.float64)
+    out = np.zeros((n, 17, 3))
+    out[:, :, :2] = w.mean(axis=1)
+    out[:, :, 2] = w[:, 0, :, 0] - w[:, -1, :, 1]
+    return out.astype(np.float32)
+
+
+def chunks_fn(lo, hi, size=5):
+    return [(f, min(size, hi - f), np.arange(f, min(f + size, hi))) for f in range(lo, hi, size)]
+
+
+def run(d, timings=None):
+    return parallel.process_video_sharded(
+        d, N_FRAMES, chunks_fn, lambda handle, first, n: fake_detect(handle), associate,
+        lambda handle, n, idx, boxes: fake_rows(handle[idx], boxes), fake_lift, SRC, pad=PAD, max_persons=3, timings=timings)
+
+
+def run_streamed(chunk):
+    """the single-process form: what cascade.Cascade does chunk after chunk with the same stages"""
+    from posepipeline_amd.person_stream import PersonStreams, collect
+    trk = Tracker(mode=1, match_iou_thr=0.5, obj_score_thr=0.5)
+    ps = PersonStreams(17, PAD, SRC, lambda jobs: fake_rows([j[1] for j in jobs], [j[2] for j in jobs]), fake_lift, max_persons=3)
+    outs = []
+    for f in range(0, N_FRAMES, chunk):
+        rows_all = []
+        for rows in fake_detect(np.arange(f, min(f + chunk, N_FRAMES))):
+            ids, _, info = trk.step(rows[:, :4].astype(np.float64), rows[:, 4].astype(np.float64))
+            rows_all.append([(int(i), *rows[j]) for i, j in zip(ids, info[:, 1])])
+        ps.ingest(rows_all)
+        outs.append(ps.advance())
+    outs.append(ps.advance(final=True))
+    return collect(outs, "keypoints"), collect(outs, "keypoints_3d")
 
 
 class LocalDist:
@@ -90,37 +110,56 @@ class LocalDist:
         pass
 
 
+def _pack(res):
+    out = {}
+    for what in ("keypoints", "keypoints_3d"):
+        for tid, (first, arr) in res[what].items():
+            out[f"{what}_{tid}_first"] = first
+            out[f"{what}_{tid}"] = arr
+    out["ids"] = np.array([[r[0] for r in fr] + [-1] * (8 - len(fr)) for fr in res["tracks"]])
+    return out
+
+
 def _worker(rank, world, port, outdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = run(dist)
+        tm = {}
+        res = run(dist, tm)
+        assert set(tm) >= {"detect", "gather_dets", "associate", "topdown", "gather_2d", "lift", "total"}
         blob = np.arange(1000, dtype=np.float32) * (1 if rank == 0 else -1)
         got = parallel.broadcast_blob(blob, dist)
+        got_dev = parallel.broadcast_blob_device(blob if rank == 0 else None, 1000, dist, "cpu", backend="gloo").numpy()
         ragged = parallel.all_gather_ragged(np.full((rank + 2, 3), rank, np.float64), [2, 3], dist)
-        np.savez(os.path.join(outdir, f"r{rank}.npz"), bbox=res["bbox"], kp=res["keypoints"], k3=res["keypoints_3d"],
-                 ids=np.array([[t["track_id"] for t in fr] + [-1] * (8 - len(fr)) for fr in res["tracks"]]), blob=got, ragged=ragged)
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), blob=got, blob_dev=got_dev, ragged=ragged, **_pack(res))
     finally:
         dist.destroy_process_group()
 
 
 def test_sharded_video_equals_single_process():
-    ref = run(LocalDist())
-    # SORT without ReID re-ids a person after a dropout, so track 0 covers the frames up to its first miss
-    assert np.isnan(ref["bbox"]).any() and (~np.isnan(ref["bbox"]).any(axis=1)).sum() >= 10
+    ref = _pack(run(LocalDist()))
+    # SORT without ReID re-ids a person after a dropout: several ids per person, short tracks with fills at both ends
+    tids = sorted(int(k.split("_")[2]) for k in ref if k.startswith("keypoints_3d_") and not k.endswith("first"))
+    assert len(tids) >= 4
+    # the sharded whole-clip form equals the streamed single-process form (what Cascade does), for any chunking
+    for chunk in (1, 4, 37):
+        k2, k3 = run_streamed(chunk)
+        assert sorted(k3) == tids
+        for tid in tids:
+            assert k2[tid][0] == ref[f"keypoints_{tid}_first"] and np.array_equal(k2[tid][1], ref[f"keypoints_{tid}"])
+            assert k3[tid][0] == ref[f"keypoints_3d_{tid}_first"] and np.array_equal(k3[tid][1], ref[f"keypoints_3d_{tid}"])
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, port, d), nprocs=2, join=True)
-        ref_ids = np.array([[t["track_id"] for t in fr] + [-1] * (8 - len(fr)) for fr in ref["tracks"]])
         for r in range(2):
             g = np.load(os.path.join(d, f"r{r}.npz"))
-            assert np.array_equal(g["ids"], ref_ids)                                     # track ids bit-exact
-            assert np.array_equal(np.nan_to_num(g["bbox"]), np.nan_to_num(ref["bbox"]))
-            assert np.array_equal(g["kp"], ref["keypoints"])
-            assert np.array_equal(g["k3"], ref["keypoints_3d"])
+            assert np.array_equal(g["ids"], ref["ids"])                                  # track ids bit-exact
+            for k, v in ref.items():
+                assert np.array_equal(g[k], v), k                                        # 2D and 3D of every track, bit for bit
             assert np.array_equal(g["blob"], np.arange(1000, dtype=np.float32))          # rank 0's weights everywhere
+            assert np.array_equal(g["blob_dev"], np.arange(1000, dtype=np.float32))
             assert np.array_equal(g["ragged"], np.array([[0.0] * 3] * 2 + [[1.0] * 3] * 3))
 
 

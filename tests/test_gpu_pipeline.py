@@ -92,20 +92,22 @@ def oracle_topdown(sd, width, frames_bgr, bboxes, image_size, post, kernel, pair
     return out
 
 
-def test_halpe_136_head_and_flip_pairs(ctx):
-    """MMPoseHalpe (the method scripts/process_h36m.py uses): same backbone, K = 136, Halpe flip pairs"""
-    assert len(hrnet.HALPE_FLIP_PAIRS) == 61 and len(hrnet.WHOLEBODY_FLIP_PAIRS) == 61
-    for pairs, k in ((hrnet.HALPE_FLIP_PAIRS, 136), (hrnet.WHOLEBODY_FLIP_PAIRS, 133)):
-        perm = hrnet.flip_perm(k, pairs)
-        assert np.array_equal(perm[perm], np.arange(k)) and (perm != np.arange(k)).sum() == 122
-    spec = hrnet.HRNetSpec(32, 136, 128, 96)
+@pytest.mark.parametrize("k,pairs", [(136, hrnet.HALPE_FLIP_PAIRS), (133, hrnet.WHOLEBODY_FLIP_PAIRS)])
+def test_wide_heads_and_flip_pairs(ctx, k, pairs):
+    """MMPoseHalpe (the method scripts/process_h36m.py uses, K = 136) and MMPoseWholebody (K = 133): same backbone, wider
+    head, their own flip pairs (wrappers/mmpose.py:41-52) -- crop -> backbone x 2 -> flip merge -> DARK decode against the
+    oracle chain"""
+    assert len(pairs) == 61
+    perm = hrnet.flip_perm(k, pairs)
+    assert np.array_equal(perm[perm], np.arange(k)) and (perm != np.arange(k)).sum() == 122
+    spec = hrnet.HRNetSpec(32, k, 128, 96)
     sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(spec), seed=6)
     net = Net(ctx, hrnet.build_hrnet_program(spec, sd), max_batch=8)
-    td = ops.TopDown(net, 136, flip_perm=hrnet.flip_perm(136, hrnet.HALPE_FLIP_PAIRS), post="unbiased", blur_kernel=17)
+    td = ops.TopDown(net, k, flip_perm=perm, post="unbiased", blur_kernel=17)
     frames, bboxes = synth_clip(np.random.default_rng(4), 2, 240, 320)
     kp, valid = td.run(frames, np.arange(2, dtype=np.int32), bboxes)
-    ref = oracle_topdown(sd, 32, frames, bboxes, (96, 128), "unbiased", 17, hrnet.HALPE_FLIP_PAIRS, 136)
-    assert kp.shape == (2, 136, 3)
+    ref = oracle_topdown(sd, 32, frames, bboxes, (96, 128), "unbiased", 17, pairs, k)
+    assert kp.shape == (2, k, 3)
     for i in range(2):
         assert np.array_equal(kp[i][:, 2], ref[i][:, 2].astype(np.float32))
         assert np.abs(kp[i][:, :2] - ref[i][:, :2]).max() <= 1e-3

@@ -158,9 +158,9 @@ def test_cascade_with_vitpose_2d_stage(ctx):
     lift_sd = synth.synth_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3)
     cas = Cascade(ctx, det_sd, p, lift_sd, h, w, chunk=2, max_persons=1, pose_spec=spec)
     gt = [np.array([[60 + 4 * t, 20, 130 + 4 * t, 120, 0.9]], np.float32) for t in range(4)]
-    out = [cas.step(frames[0:2], replay=gt[0:2]), cas.step(frames[2:4], replay=gt[2:4])]
+    out = [cas.step(frames[0:2], replay=gt[0:2]), cas.step(frames[2:4], replay=gt[2:4]), cas.flush()]
     tid = out[0]["tracks"][0][0][0]
-    k2 = np.concatenate([o["keypoints"][tid] for o in out])
+    k2 = np.concatenate([o["keypoints"][tid] for o in out[:2]])
     assert k2.shape == (4, 17, 3)
     boxes = np.array([[g[0, 0], g[0, 1], g[0, 2] - g[0, 0], g[0, 3] - g[0, 1]] for g in gt], np.float64)
     net = Net(ctx, MV.build_vitpose_program(spec, p), max_batch=8)
@@ -168,9 +168,9 @@ def test_cascade_with_vitpose_2d_stage(ctx):
     ref, _ = td.run(frames, np.arange(4, dtype=np.int32), boxes)
     # same kernels, same inputs, other batch size (2 + 2 vs 4): the tile schedule does not depend on the batch, so equal
     assert np.array_equal(k2, ref)
-    kn = normalize_screen_coordinates(k2[:, :, :2].astype(np.float64), w, h).astype(np.float32)
+    kn = normalize_screen_coordinates(k2[:, :, :2], w, h).astype(np.float32)      # float32 track: the reference's float32 path
     ref3 = onets.VideoPose3DRef(lift_sd).forward(onets.videopose3d_windows(kn, 121))
-    assert np.array_equal(out[1]["keypoints_3d"][tid], ref3[2:4])
+    assert np.array_equal(out[2]["keypoints_3d"][tid], ref3)                     # whole clip, emitted at flush
     td.close()
     net.close()
 
