@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--persons", type=int, default=1, help="cascade: tracked persons per frame")
     ap.add_argument("--batch", type=int, default=64, help="c2 / c5: person-frames per step per GPU")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "shard"],
+                    help="N > 1: independent frame shards per rank (default, no data-path collective) or ONE clip sharded over "
+                         "the ranks with the detection / 2D all_gathers of posepipeline_amd/parallel.py")
     return ap.parse_args()
 
 
@@ -89,6 +92,24 @@ class Dist:
         t = torch.from_numpy(blob).to(dev) if self.rank == 0 else torch.empty(blob.size, dtype=torch.float32, device=dev)
         self.dist.broadcast(t, src=0)
         return t.cpu().numpy()
+
+    def bcast_blob_fn(self):
+        """weights stay on the device: rank 0's blobs arrive as device tensors and pp_net_create_mem reads them in place"""
+        if self.dist is None:
+            return None
+        import torch
+        from posepipeline_amd import parallel
+        dev = torch.device("cuda", self.local_rank)
+        self.blob_log = []
+        return parallel.broadcast_blob_fn(self.dist, dev, backend=self.backend, log=self.blob_log)
+
+    def gather_obj(self, obj):
+        """every rank's small Python object on rank 0 (per-rank step times of the N > 1 lines)"""
+        if self.dist is None:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
 
     def max_time(self, dt):
         if self.dist is None:
@@ -151,13 +172,13 @@ def run_cascade(args, D):
         pose_sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(pose_spec), seed=1)
     lift_sd = synth.synth_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3)
     B, P = args.chunk, args.persons
-    cas = Cascade(ctx, det_sd, pose_sd, lift_sd, 1080, 1920, chunk=B, max_persons=P, pose_spec=pose_spec)
+    # N > 1: every program's blob is rank 0's, delivered by one RCCL broadcast per program as a device tensor that
+    # pp_net_create_mem consumes in place (the locally built state dicts only define the program structure)
+    cas = Cascade(ctx, det_sd, pose_sd, lift_sd, 1080, 1920, chunk=B, max_persons=P, pose_spec=pose_spec, blob_fn=D.bcast_blob_fn())
     if D.world > 1:
-        # the resident blobs were uploaded from locally generated (identical, seeded) weights; exercise the
-        # RCCL weight broadcast the multi-GPU deployment uses and check that it delivers the same bytes
-        for prog in (cas.detector.prog_a, cas.detector.prog_b, cas.pose_net.prog, cas.lift_net.prog):
-            got = D.bcast_blob(prog.blob)
-            assert np.array_equal(got, prog.blob)
+        D.blob_log.clear()
+    if args.mode == "shard":
+        return run_cascade_sharded(args, D, ctx, cas)
     rng = np.random.default_rng(3000 + D.rank)                     # config index 3, per-rank shard
     frames, gt = synth_1080p(rng, B, P)
     dptr = ctx.malloc(frames.nbytes)
@@ -195,7 +216,9 @@ def run_cascade(args, D):
     for _ in range(args.steps):
         res = step(True)
     D.barrier(ctx)
-    dt = D.max_time(time.perf_counter() - t0)
+    dt_own = time.perf_counter() - t0
+    dt = D.max_time(dt_own)
+    per_rank = D.gather_obj(dt_own / args.steps * 1e3)
     if D.rank != 0:
         return
     K = args.steps
@@ -251,6 +274,8 @@ def run_cascade(args, D):
                                 "note": "same step, one stream (pp_net_set_lanes 0): comparable with rocprofv3 --stats AverageNs "
                                         "of profiles/*_serial_kernel_stats.csv"}},
     }
+    if D.world > 1:
+        out["per_rank_ms_per_step"] = per_rank
     if D.world == 1:
         # PCIe-inclusive leg (reported beside `value`, never as it): the same chunks streamed from host memory through
         # page-locked staging buffers and the copy stream (posepipeline_amd/streaming.py), upload overlapped with compute
@@ -280,6 +305,64 @@ def run_cascade(args, D):
     if n_cpu > 0 and D.world == 1 and not vit:          # the CPU baseline is a rank-0, N=1 leg (c5 carries the ViT one)
         out["cpu_baseline"] = cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames[0], gt[0][0], cas, ctx)
     print(json.dumps(out), flush=True)
+
+
+def run_cascade_sharded(args, D, ctx, cas):
+    """--mode shard: ONE clip of world x steps x chunk frames, frames sharded contiguously over the ranks
+    (posepipeline_amd/parallel.py): local detection -> all_gather of detection slabs -> identical association on every rank
+    -> 2D on the own shard -> all_gather of the 2D rows -> lifting.  A step = one chunk per rank; the timed region is the
+    whole sharded run over `steps` chunks per rank (after a run over `warmup` chunks)."""
+    from posepipeline_amd import parallel
+    B, P, K = args.chunk, args.persons, args.steps
+    rng = np.random.default_rng(3000 + D.rank)
+    frames, gt = synth_1080p(rng, B, P)
+    dptr = ctx.malloc(frames.nbytes)
+    ctx.h2d(dptr, frames)                                          # the rank's frames are resident in HBM before timing
+    rb = [np.concatenate([g[:, :4], np.full((len(g), 1), 0.9, np.float32)], axis=1) for g in gt]
+    stages = parallel.cascade_stages(cas, lambda first, n: rb[:n])
+
+    class _Local:      # world_size 1: the torch.distributed calls parallel.py uses
+        def get_rank(self): return 0
+        def get_world_size(self): return 1
+        def all_gather(self, outs, t): outs[0].copy_(t)
+
+    dist = D.dist if D.dist is not None else _Local()
+    dev = "cpu" if D.dist is None or D.backend != "nccl" else "cuda"
+
+    def run(chunks_per_rank, tm=None):
+        n = D.world * chunks_per_rank * B
+        lo = parallel.shard_bounds(n, D.world)[D.rank]
+        return parallel.process_video_sharded(dist, n, lambda lo_, hi_: [(lo + i * B, B, dptr) for i in range(chunks_per_rank)],
+                                              *stages, src_hw=(1080, 1920), device=dev, max_persons=P, timings=tm)
+
+    if args.warmup > 0:
+        run(args.warmup)
+    D.barrier(ctx)
+    tm = {}
+    t0 = time.perf_counter()
+    res = run(K, tm)
+    D.barrier(ctx)
+    dt_own = time.perf_counter() - t0
+    dt = D.max_time(dt_own)
+    per_rank = D.gather_obj({k: round(v * 1e3, 3) for k, v in tm.items()})
+    if D.rank != 0:
+        return
+    flops_step = B * (cas.detector.flops_per_frame + 2 * P * cas.pose_net.prog.flops)
+    print(json.dumps({
+        "metric": METRIC, "value": D.world * B * K / dt, "unit": "frames/s", "n_gpus": D.world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[3]: ONE 1080p clip of %d frames sharded over %d rank(s): detect (Faster-RCNN R50-FPN) -> all_gather of "
+                               "detection slabs -> SORT on every rank -> HRNet-W48 384x288 flip_test + DARK decode on the own shard -> "
+                               "all_gather of 2D rows -> VideoPose3D 243-frame lifting" % (D.world * B * K, D.world),
+                   "mode": "shard", "frames_per_step_per_gpu": B, "persons_per_frame": P, "gflop_per_frame": flops_step / B / 1e9,
+                   "tracks": len(res["keypoints_3d"]),
+                   "detector_boxes": "detector runs on every frame; downstream boxes are replayed synthetic GT (random-weight detector)"},
+        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": D.world * flops_step * K / dt / 1e12 / D.world,
+                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops_step * K / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                     "traffic": None, "note": "end-to-end conv FLOP rate per GPU over the whole sharded run (the per-kernel roofline "
+                                              "line is the default mode's)"},
+        "per_rank_phase_ms": per_rank,
+    }), flush=True)
 
 
 def cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frame_bgr, gt_box, cas, ctx):

@@ -170,6 +170,11 @@ int pp_net_capture(pp_net* net, int batch);
 /* per-op elapsed time of the last profiled run (HIP events around each op), ms; NULL-safe */
 int pp_net_profile(pp_net* net, int batch, float* ms_per_op);
 
+/* Tile configuration of the convolution kernel for all later launches of this process: ct = output-channel tile / 16
+ * (1..4), pt = pixel tile / 64 (1, 2); 0 = automatic (posepipeline_amd/conv_tuning.txt, then the built-in heuristic).
+ * Results do not depend on it; tools/autotune_conv.py uses it to measure every configuration per layer. */
+int pp_conv_force(int ct, int pt);
+
 /* single convolution on caller-provided device/host buffers (tests, VideoPose3D, FC layers).
  * x: [n][hin][win][cin]; bias: [cout_pad16]; y per op flags.
  * w: [ceil(K/32)][cout_pad16][32], K = kh*kw*cin, k = (kh_i*kw + kw_i)*cin + c; within a chunk of 32 k's the

@@ -39,24 +39,24 @@ class Cascade:
 
     def __init__(self, ctx: L.Context, det_sd, pose_sd: dict, lift_sd: dict, src_h: int, src_w: int,
                  chunk: int = 8, max_persons: int = 1, pose_spec=None, post="unbiased", blur_kernel=17,
-                 tracking: str = "MMTrack_deepsort", keep_tracks=None, flip_pairs=None, blobs_dev=None):
-        """blobs_dev: optional {"det_a", "det_b", "pose", "lift"} -> (device pointer, n_floats): weight blobs that are already
-        resident on the device (parallel.py: delivered by an RCCL broadcast); the *_sd arguments still define the programs."""
+                 tracking: str = "MMTrack_deepsort", keep_tracks=None, flip_pairs=None, blob_fn=None):
+        """blob_fn(name, program) -> (device pointer, n_floats) or None, name in "det_a", "det_b", "pose", "lift" (called in
+        that order): a weight blob that is already resident on the device -- parallel.broadcast_blob_device delivers rank
+        0's over RCCL; the *_sd arguments then only define the program structure (ops, buffers, blob offsets)."""
         self.ctx = ctx
         self.src = (src_h, src_w)
         self.chunk = chunk
         self.max_persons = max_persons
         self.tracking = tracking
         self.keep_tracks = keep_tracks
-        bd = blobs_dev or {}
+        blob_fn = blob_fn or (lambda name, prog: None)
         if tracking == "DeepSortYOLOv4":
             from .models import mars, yolov4
             self.detector = yolov4.YoloV4Detector(ctx, det_sd[0], src_h, src_w, max_frames=chunk)
             self.encoder = mars.MarsEncoder(ctx, det_sd[1], src_h, src_w, max_patches=max(64, chunk * max_persons))
         else:
             assert tracking == "MMTrack_deepsort", tracking
-            self.detector = fr.Detector(ctx, det_sd, src_h, src_w, max_frames=chunk,
-                                        blobs_dev=(bd.get("det_a"), bd.get("det_b")))
+            self.detector = fr.Detector(ctx, det_sd, src_h, src_w, max_frames=chunk, blob_fn=blob_fn)
         self.pose_spec = pose_spec or hrnet.hrnet_w48_384x288()
         if isinstance(self.pose_spec, vitpose.VitPoseSpec):     # BASELINE.json configs[4]: ViTPose 2D stage (UDP, bf16 MFMA)
             pose_prog = vitpose.build_vitpose_program(self.pose_spec, pose_sd)
@@ -66,14 +66,14 @@ class Cascade:
             pose_prog = hrnet.build_hrnet_program(self.pose_spec, pose_sd)
             shift = True
             self.k = int(self.pose_spec.num_joints)
-        self.pose_net = Net(ctx, pose_prog, max_batch=2 * chunk * max_persons, blob_dev=bd.get("pose"))
+        self.pose_net = Net(ctx, pose_prog, max_batch=2 * chunk * max_persons, blob_dev=blob_fn("pose", pose_prog))
         if flip_pairs is None:
             flip_pairs = {17: hrnet.COCO_FLIP_PAIRS, 133: hrnet.WHOLEBODY_FLIP_PAIRS, 136: hrnet.HALPE_FLIP_PAIRS}[self.k]
         self.topdown = ops.TopDown(self.pose_net, self.k, flip_perm=hrnet.flip_perm(self.k, flip_pairs), shift_heatmap=shift,
                                    post=post, blur_kernel=blur_kernel)
         self.lift_spec = vp3d.VideoPose3DSpec()
-        self.lift_net = Net(ctx, vp3d.build_videopose3d_program(self.lift_spec, lift_sd), max_batch=max(1, max_persons),
-                            blob_dev=bd.get("lift"))
+        lift_prog = vp3d.build_videopose3d_program(self.lift_spec, lift_sd)
+        self.lift_net = Net(ctx, lift_prog, max_batch=max(1, max_persons), blob_dev=blob_fn("lift", lift_prog))
         self.frame_bytes = src_h * src_w * 3
         self.tail_dev = None          # device copy of the last FILL_LIMIT frames (slot = frame % FILL_LIMIT)
         self.tail_host = None

@@ -24,7 +24,10 @@
 // ds_write_b32 pattern of the pixel loader are bank-conflict free.
 // Pixel loader: lanes run along k first (8 lanes x 16 B = one 128-byte line of a pixel's channels), so a
 // wave-load touches 8 cache lines instead of 64.
+#include <dlfcn.h>
+
 #include <cstdlib>
+#include <map>
 
 #include "pp_internal.h"
 
@@ -482,7 +485,59 @@ int env_int(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
+// ---- tile selection: measured table first, heuristic otherwise --------------------------------------------------------
+// The best (channel tile, pixel tile) of a layer depends on how its grid quantises onto 256 CUs x 4 resident blocks, which
+// no closed formula predicts well (HRNet's 24x18 / 12x9 layers launch 0.4-0.9 "rounds" of blocks).  tools/autotune_conv.py
+// measures every instantiated (CT, PT) per layer shape on the GPU and writes posepipeline_amd/conv_tuning.txt:
+//   Cin Cout KH KW stride dil_h dil_w M  CT PT      (one line per shape; M = batch * Hout * Wout)
+// Results are identical for every choice (same k order per output); only the speed differs.
+struct TuneKey {
+    int cin, cout, kh, kw, stride, dil_h, dil_w, m;
+    bool operator<(const TuneKey& o) const { return memcmp(this, &o, sizeof(TuneKey)) < 0; }
+};
+struct TuneTable {
+    std::map<TuneKey, std::pair<int, int>> best;
+    TuneTable() {
+        std::string path;
+        if (const char* e = getenv("POSEPIPE_CONV_TUNING")) {
+            path = e;                                    // "" / "0" disables the table
+        } else {
+            Dl_info info;
+            if (dladdr((void*)&pp_conv_out_dim, &info) && info.dli_fname) {
+                path = info.dli_fname;
+                const size_t slash = path.rfind('/');
+                path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/conv_tuning.txt";
+            }
+        }
+        if (path.empty() || path == "0") return;
+        FILE* f = fopen(path.c_str(), "r");
+        if (!f) return;
+        char line[256];
+        while (fgets(line, sizeof(line), f)) {
+            TuneKey k;
+            memset(&k, 0, sizeof(k));
+            int ct, pt;
+            if (line[0] == '#' || sscanf(line, "%d %d %d %d %d %d %d %d %d %d", &k.cin, &k.cout, &k.kh, &k.kw, &k.stride, &k.dil_h,
+                                         &k.dil_w, &k.m, &ct, &pt) != 10)
+                continue;
+            if (ct >= 1 && ct <= 4 && (pt == 1 || pt == 2)) best[k] = {ct, pt};
+        }
+        fclose(f);
+    }
+};
+int g_force_ct = 0, g_force_pt = 0;   // pp_conv_force (autotuner, A/B experiments)
+
 }  // namespace
+
+extern "C" int pp_conv_force(int ct, int pt) {
+    if (ct < 0 || ct > 4 || (pt != 0 && pt != 1 && pt != 2)) {
+        pp_set_error("pp_conv_force: ct in 0..4, pt in {0, 1, 2} (0 = automatic)");
+        return PP_ERR_ARG;
+    }
+    g_force_ct = ct;
+    g_force_pt = pt;
+    return PP_OK;
+}
 
 int pp_conv_out_dim(int in, int k, int stride, int pad, int dil) {
     return (in + 2 * pad - dil * (k - 1) - 1) / stride + 1;
@@ -554,13 +609,28 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
             best_ct = ct;
         }
     }
+    static const TuneTable tuning;
+    int tuned_pt = 0;
+    if (!tuning.best.empty()) {
+        TuneKey k;
+        memset(&k, 0, sizeof(k));
+        k.cin = a.Cin; k.cout = a.Cout; k.kh = a.KH; k.kw = a.KW; k.stride = a.stride; k.dil_h = a.dil_h; k.dil_w = a.dil_w; k.m = a.M;
+        auto it = tuning.best.find(k);
+        if (it != tuning.best.end()) {
+            best_ct = it->second.first;
+            tuned_pt = it->second.second;
+        }
+    }
     if (force_ct) best_ct = force_ct;
+    if (g_force_ct) best_ct = g_force_ct;
     const int cblocks = (tiles + best_ct - 1) / best_ct;
     // pixel tile: 128 pixels (PT=2: 4 waves/SIMD by registers) when that still gives >= ~2 blocks per CU,
     // else 64.  PT=4 halves the occupancy and measured 20 % slower on HRNet-W48, so it is never chosen.
     int pt = 2;
     while (pt > 1 && (long)((a.M + 64 * pt - 1) / (64 * pt)) * cblocks < min_blocks) pt >>= 1;
+    if (tuned_pt) pt = tuned_pt;
     if (force_pt) pt = force_pt;
+    if (g_force_pt) pt = g_force_pt;
     {
         // experiment knob: POSEPIPE_CONV_PT_CT<ct>=<pt> forces the pixel tile for one channel-tile class
         static const int pt_by_ct[5] = {0, env_int("POSEPIPE_CONV_PT_CT1", 0), env_int("POSEPIPE_CONV_PT_CT2", 0),

@@ -64,10 +64,26 @@ def broadcast_blob_device(blob, n_floats: int, dist, device, src=0, backend="ncc
         t = torch.from_numpy(np.ascontiguousarray(blob, np.float32)).to(device) if is_src else \
             torch.empty(n_floats, dtype=torch.float32, device=device)
         dist.broadcast(t, src=src)
+        torch.cuda.synchronize(device)          # the consumer reads the tensor on another stream (the library's own)
         return t
     h = torch.from_numpy(np.ascontiguousarray(blob, np.float32)) if is_src else torch.empty(n_floats, dtype=torch.float32)
     dist.broadcast(h, src=src)
-    return h.to(device)
+    t = h.to(device)
+    if str(device) != "cpu":
+        torch.cuda.synchronize(device)
+    return t
+
+
+def broadcast_blob_fn(dist, device, backend="nccl", src=0, log=None):
+    """blob_fn for cascade.Cascade / faster_rcnn.Detector: every program's blob comes from rank `src` and stays on the
+    device (the receivers never touch their own prog.blob).  log: optional list that receives (name, n_floats)."""
+    def blob_fn(name, prog):
+        n = int(prog.blob.size)
+        t = broadcast_blob_device(prog.blob if dist.get_rank() == src else None, n, dist, device, src=src, backend=backend)
+        if log is not None:
+            log.append((name, n, t))            # keeps the tensor alive until the caller drops the log
+        return int(t.data_ptr()), n
+    return blob_fn
 
 
 def all_gather_ragged(local: np.ndarray, counts, dist, device="cpu") -> np.ndarray:

@@ -311,9 +311,15 @@ def gen_dark():
     tay_noisy = np.array([inf.taylor(noisy[j], preds[0, j].copy()) for j in range(hms.shape[1])])
     bbox = np.array([120.5, 60.25, 211.0, 333.5])
     tp = inf.transform_preds(tay, bbox, [w, h])
+    # the same Taylor step on float32-ROUNDED logs (held in float64 arrays): the inputs mmpose's float32 heat-maps give the
+    # oracle, so that the comparison isolates the algorithm from the rounding of its input (tight pin: 1e-4 px)
+    logs32 = logs[0].astype(np.float32).astype(np.float64)
+    noisy32 = noisy.astype(np.float32).astype(np.float64)
+    tay32 = np.array([inf.taylor(logs32[j], preds[0, j].copy()) for j in range(hms.shape[1])])
+    tay_noisy32 = np.array([inf.taylor(noisy32[j], preds[0, j].copy()) for j in range(hms.shape[1])])
     np.savez_compressed(os.path.join(OUT, "dark_decode.npz"), heatmaps=hms, centres=np.array(centres), preds=preds,
                         maxvals=maxvals, taylor=tay, log_noisy=noisy, taylor_noisy=tay_noisy, bbox=bbox,
-                        transformed=tp)
+                        transformed=tp, taylor_f32in=tay32, taylor_noisy_f32in=tay_noisy32)
 
 
 def gen_bbox_aspect(pp):

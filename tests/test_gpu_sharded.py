@@ -1,0 +1,113 @@
+"""The frame-sharded cascade (posepipeline_amd/parallel.py) with the REAL GPU stages: two ranks (gloo rendezvous, both on
+GPU 0 -- the rehearsal mode of a box with fewer GPUs than ranks) process one clip; every rank's result must equal the
+single-process streamed `Cascade` bit for bit, ids included.  Rank 1 builds its programs from WRONG weights and
+receives rank 0's blobs as device tensors (`broadcast_blob_fn` -> `pp_net_create_mem`): the comparison only holds if the
+broadcast weights are the ones the kernels read."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+H, W, N, CHUNK = 135, 240, 22, 4
+
+
+def _clip():
+    from tests.test_gpu_detector import synth_frame
+    rng = np.random.default_rng(17)
+    frames = np.stack([synth_frame(rng, H, W) for _ in range(N)])
+    gt = []
+    for t in range(N):
+        rows = [[30 + 3.0 * t, 15, 100 + 3.0 * t, 118, 0.9], [150 - 2.0 * t, 30, 215 - 2.0 * t, 125, 0.8]]
+        if t == 9:
+            rows = rows[1:]                    # person 0 missed once: new id, fills on both sides of the gap
+        if t in (15, 16):
+            rows = rows[:1]                    # person 1 missed twice (spans the rank boundary's neighbourhood)
+        gt.append(np.array(rows, np.float32))
+    return frames, gt
+
+
+def _state_dicts(seed_shift):
+    from posepipeline_amd.models import faster_rcnn as fr, hrnet, synth
+    from posepipeline_amd.models import videopose3d as vp3d
+    spec = hrnet.HRNetSpec(32, 17, 128, 96)
+    return (synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2 + seed_shift), spec,
+            synth.synth_state_dict(hrnet.hrnet_param_shapes(spec), seed=1 + seed_shift),
+            synth.synth_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3 + seed_shift))
+
+
+def _pack(tracks, k2, k3):
+    out = {"ids": np.array([[r[0] for r in fr] + [-1] * (4 - len(fr)) for fr in tracks])}
+    for name, d in (("k2", k2), ("k3", k3)):
+        for tid, (first, arr) in d.items():
+            out[f"{name}_{tid}_first"] = first
+            out[f"{name}_{tid}"] = arr
+    return out
+
+
+def _worker(rank, world, port, outdir):
+    import torch
+    import torch.distributed as dist
+    from posepipeline_amd import _lib, parallel
+    from posepipeline_amd.cascade import Cascade
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frames, gt = _clip()
+        det_sd, spec, pose_sd, lift_sd = _state_dicts(0 if rank == 0 else 100)      # rank 1: wrong weights, right shapes
+        ctx = _lib.Context(0)
+        log = []
+        cas = Cascade(ctx, det_sd, pose_sd, lift_sd, H, W, chunk=CHUNK, max_persons=3, pose_spec=spec,
+                      blob_fn=parallel.broadcast_blob_fn(dist, torch.device("cuda", 0), backend="gloo", log=log))
+        assert [n for n, _, _ in log] == ["det_a", "det_b", "pose", "lift"]
+        log.clear()                                                                   # pp_net_create_mem copied the blobs
+        b = parallel.shard_bounds(N, world)
+        lo, hi = b[rank], b[rank + 1]
+        dptr = ctx.malloc(frames[lo:hi].nbytes)
+        ctx.h2d(dptr, frames[lo:hi])                                                  # the rank's shard stays resident
+        fb = H * W * 3
+
+        def chunks_fn(lo_, hi_):
+            assert (lo_, hi_) == (lo, hi)
+            return [(f, min(CHUNK, hi - f), dptr + (f - lo) * fb) for f in range(lo, hi, CHUNK)]
+
+        tm = {}
+        res = parallel.process_video_sharded(dist, N, chunks_fn, *parallel.cascade_stages(cas, lambda first, n: gt[first:first + n]),
+                                             src_hw=(H, W), max_persons=3, timings=tm)
+        # the detector really ran on this rank's frames with the BROADCAST weights: compare one frame's own detections
+        own = cas.detector.run(frames[lo:lo + 1])[0]
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), own_det=own, total=tm["total"], **_pack(res["tracks"], res["keypoints"], res["keypoints_3d"]))
+        ctx.free(dptr)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_single_process_cascade(ctx):
+    import torch.multiprocessing as mp
+    from oracle import detector as odet
+    from posepipeline_amd import parallel
+    from posepipeline_amd.cascade import Cascade, collect
+    frames, gt = _clip()
+    det_sd, spec, pose_sd, lift_sd = _state_dicts(0)
+    cas = Cascade(ctx, det_sd, pose_sd, lift_sd, H, W, chunk=CHUNK, max_persons=3, pose_spec=spec)
+    outs = [cas.step(frames[i:i + CHUNK], replay=gt[i:i + CHUNK]) for i in range(0, N, CHUNK)] + [cas.flush()]
+    ref = _pack([fr for o in outs for fr in o["tracks"]], collect(outs, "keypoints"), collect(outs, "keypoints_3d"))
+    assert sum(k.startswith("k3_") and not k.endswith("first") for k in ref) >= 4        # re-identified persons: >= 4 tracks
+    cas.close()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    model = odet.FasterRCNNRef(det_sd)
+    b = parallel.shard_bounds(N, 2)
+    with tempfile.TemporaryDirectory() as d:
+        mp.get_context("spawn")
+        mp.spawn(_worker, args=(2, port, d), nprocs=2, join=True)
+        for r in range(2):
+            g = np.load(os.path.join(d, f"r{r}.npz"))
+            assert sorted(k for k in g.files if k not in ("own_det", "total")) == sorted(ref)
+            for k, v in ref.items():
+                assert np.array_equal(g[k], v), (r, k)                                    # ids, 2D, 3D: bit for bit
+            assert np.array_equal(g["own_det"], odet.detect(model, frames[b[r]][:, :, ::-1])), r

@@ -129,6 +129,11 @@ def test_dark_decode_against_in_tree_inference():
             start = ref_p[0, j].astype(np.float32)
             got = odec.taylor(logs[j].astype(np.float32), start.copy())
             assert np.abs(got - g[name_out][j]).max() < 2e-3, (name_out, j, got, g[name_out][j])
+            # tight pin: the reference's taylor on the SAME float32-rounded logs (taylor*_f32in).  What is left is the
+            # oracle's mmpose-style float32 differences against the in-tree float64 ones: <= 1e-4 px, ten times inside
+            # the 1e-3 px budget this step has to protect
+            got32 = odec.taylor(logs[j].astype(np.float32), start.copy())
+            assert np.abs(got32 - g[name_out + "_f32in"][j]).max() <= 1e-4, (name_out, j, got32, g[name_out + "_f32in"][j])
     # analytic Gaussians away from the border are recovered (SURVEY.md 4.2 known-answer)
     cen = g["centres"]
     assert np.abs(g["taylor"][0] - cen[0]).max() < 1e-6

@@ -141,3 +141,43 @@ def test_videopose3d_oracle_vs_torch_and_window_semantics():
             x = res + F.relu(bn(F.conv1d(x, t[f"layers_conv.{2 * i + 1}.weight"]), f"layers_bn.{2 * i + 1}"))
         ref = F.conv1d(x, t["shrink.weight"], t["shrink.bias"]).permute(0, 2, 1).reshape(9, 17, 3).numpy()
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+
+
+def test_folded_bn_gap_in_decoded_pixels():
+    """The oracle (and the HIP kernels) fold BatchNorm into the convolution in float64 and sum in one fixed order; the
+    reference runs UNFOLDED float32 BatchNorm after cuDNN / MKL convolutions.  What that difference is worth where it
+    matters -- in decoded key-point pixels, against the 1e-3 px budget of north_star -- is measured here: heat-maps of the
+    oracle and of the independent torch model (unfolded BN, torch's summation order) for the same weights and crop go
+    through the same flip-merge + DARK decode; a 64x64 heat-map px maps to 3 image px for the 192-px-wide box used.
+    Peaks are made well-conditioned (a sharp blob is added to both, as a trained network's maps are) -- on the raw maps of a
+    random-weight network the arg-max itself is unstable and no tolerance is meaningful."""
+    from oracle import decode as odec
+    spec = hrnet.HRNetSpec(32, 17, 256, 256)
+    sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(spec), seed=9)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((1, 3, 256, 256)).astype(np.float32)
+    with torch.no_grad():
+        m = TorchHRNet(sd, 32)
+        ref = [m.forward(T(x)).numpy(), m.forward(T(np.ascontiguousarray(x[:, :, :, ::-1]))).numpy()]
+    o = onets.HRNetRef(sd, 32)
+    got = [o.forward(x), o.forward(np.ascontiguousarray(x[:, :, :, ::-1]))]
+    scale = max(np.abs(r).max() for r in ref)
+    gap_hm = max(np.abs(g - r).max() for g, r in zip(got, ref)) / scale
+    assert gap_hm <= 2e-4, gap_hm
+    # a trained network's response: a Gaussian blob (sigma 2 px) of the map's own scale at a sub-pixel position per joint,
+    # added identically to both sides; what differs between the sides is exactly the folded-vs-unfolded network output
+    yy, xx = np.mgrid[0:64, 0:64].astype(np.float32)
+    blob = np.stack([np.exp(-((yy - (8.3 + 2.9 * j)) ** 2 + (xx - (10.6 + 2.6 * j)) ** 2) / 8.0) for j in range(17)]).astype(np.float32)
+    amp = np.float32(2.0 * scale)
+
+    def decode(hm, hmf):
+        a = (hm + amp * blob[None]).astype(np.float32)
+        b = (hmf + amp * blob[None][:, hrnet.flip_perm(17)][:, :, :, ::-1]).astype(np.float32)
+        c, s = np.array([[300.0, 200.0]], np.float32), np.array([[192 / 200, 192 / 200]], np.float32)
+        return odec.decode_topdown(a, b, hrnet.COCO_FLIP_PAIRS, c, s, post_process="unbiased", kernel=17)[0]
+
+    k_ref, k_got = decode(*ref), decode(*got)
+    gap_px = float(np.abs(k_ref[0, :, :2] - k_got[0, :, :2]).max())
+    print(f"folded-BN / fixed-order network vs unfolded torch network: heat-map gap {gap_hm:.2e} of the range, decoded key points {gap_px:.2e} px")
+    assert gap_px <= 1e-3, gap_px          # inside the north-star budget, with the measured figure in the test log
+    assert np.array_equal(k_ref[0, :, 2], k_got[0, :, 2]) or np.abs(k_ref[0, :, 2] - k_got[0, :, 2]).max() <= 2e-4 * float(amp)
