@@ -174,6 +174,9 @@ int pp_net_profile(pp_net* net, int batch, float* ms_per_op);
  * (1..4), pt = pixel tile / 64 (1, 2); 0 = automatic (posepipeline_amd/conv_tuning.txt, then the built-in heuristic).
  * Results do not depend on it; tools/autotune_conv.py uses it to measure every configuration per layer. */
 int pp_conv_force(int ct, int pt);
+/* Kernel variant for all later launches: 0 = two-barrier K step (conv_igemm.hip), 1 = three-stage software pipeline
+ * (conv_igemm_p3.hip), -1 = default (tuning table / POSEPIPE_CONV_VARIANT).  Bit-identical results. */
+int pp_conv_variant(int variant);
 
 /* single convolution on caller-provided device/host buffers (tests, VideoPose3D, FC layers).
  * x: [n][hin][win][cin]; bias: [cout_pad16]; y per op flags.

@@ -26,6 +26,7 @@
 // wave-load touches 8 cache lines instead of 64.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <map>
 
@@ -489,14 +490,15 @@ int env_int(const char* name, int dflt) {
 // The best (channel tile, pixel tile) of a layer depends on how its grid quantises onto 256 CUs x 4 resident blocks, which
 // no closed formula predicts well (HRNet's 24x18 / 12x9 layers launch 0.4-0.9 "rounds" of blocks).  tools/autotune_conv.py
 // measures every instantiated (CT, PT) per layer shape on the GPU and writes posepipeline_amd/conv_tuning.txt:
-//   Cin Cout KH KW stride dil_h dil_w M  CT PT      (one line per shape; M = batch * Hout * Wout)
+//   Cin Cout KH KW stride dil_h dil_w M  CT PT [variant]     (one line per shape; M = batch * Hout * Wout)
 // Results are identical for every choice (same k order per output); only the speed differs.
 struct TuneKey {
-    int cin, cout, kh, kw, stride, dil_h, dil_w, m;
+    int cin, cout, kh, kw, stride, dil_h, dil_w;
     bool operator<(const TuneKey& o) const { return memcmp(this, &o, sizeof(TuneKey)) < 0; }
 };
 struct TuneTable {
-    std::map<TuneKey, std::pair<int, int>> best;
+    struct Choice { int m, ct, pt, variant; };
+    std::map<TuneKey, std::vector<Choice>> best;     // per layer shape: the measured batch sizes (M), ascending
     TuneTable() {
         std::string path;
         if (const char* e = getenv("POSEPIPE_CONV_TUNING")) {
@@ -516,18 +518,44 @@ struct TuneTable {
         while (fgets(line, sizeof(line), f)) {
             TuneKey k;
             memset(&k, 0, sizeof(k));
-            int ct, pt;
-            if (line[0] == '#' || sscanf(line, "%d %d %d %d %d %d %d %d %d %d", &k.cin, &k.cout, &k.kh, &k.kw, &k.stride, &k.dil_h,
-                                         &k.dil_w, &k.m, &ct, &pt) != 10)
+            Choice c{0, 0, 0, -1};
+            if (line[0] == '#' || sscanf(line, "%d %d %d %d %d %d %d %d %d %d %d", &k.cin, &k.cout, &k.kh, &k.kw, &k.stride, &k.dil_h,
+                                         &k.dil_w, &c.m, &c.ct, &c.pt, &c.variant) < 10)
                 continue;
-            if (ct >= 1 && ct <= 4 && (pt == 1 || pt == 2)) best[k] = {ct, pt};
+            if (c.ct >= 1 && c.ct <= 4 && (c.pt == 1 || c.pt == 2) && c.m > 0) best[k].push_back(c);
         }
         fclose(f);
+        for (auto& kv : best) std::sort(kv.second.begin(), kv.second.end(), [](const Choice& x, const Choice& y) { return x.m < y.m; });
+    }
+    // the entry measured at the nearest M (ratio-wise), if it is within a factor 1.5 (grid quantisation changes beyond that)
+    const Choice* find(const TuneKey& k, int m) const {
+        auto it = best.find(k);
+        if (it == best.end()) return nullptr;
+        const Choice* pick = nullptr;
+        double best_r = 1.5;
+        for (const Choice& c : it->second) {
+            const double r = c.m > m ? (double)c.m / m : (double)m / c.m;
+            if (r <= best_r) {
+                best_r = r;
+                pick = &c;
+            }
+        }
+        return pick;
     }
 };
 int g_force_ct = 0, g_force_pt = 0;   // pp_conv_force (autotuner, A/B experiments)
+int g_variant = -1;                   // pp_conv_variant: -1 = default (env POSEPIPE_CONV_VARIANT, else table / built-in)
 
 }  // namespace
+
+extern "C" int pp_conv_variant(int variant) {
+    if (variant < -1 || variant > 1) {
+        pp_set_error("pp_conv_variant: -1 (default), 0 (two-barrier kernel) or 1 (three-stage pipelined kernel)");
+        return PP_ERR_ARG;
+    }
+    g_variant = variant;
+    return PP_OK;
+}
 
 extern "C" int pp_conv_force(int ct, int pt) {
     if (ct < 0 || ct > 4 || (pt != 0 && pt != 1 && pt != 2)) {
@@ -610,17 +638,20 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
         }
     }
     static const TuneTable tuning;
-    int tuned_pt = 0;
+    static const int env_variant = env_int("POSEPIPE_CONV_VARIANT", -1);
+    int tuned_pt = 0, variant = 0;       // built-in default: the two-barrier kernel
     if (!tuning.best.empty()) {
         TuneKey k;
         memset(&k, 0, sizeof(k));
-        k.cin = a.Cin; k.cout = a.Cout; k.kh = a.KH; k.kw = a.KW; k.stride = a.stride; k.dil_h = a.dil_h; k.dil_w = a.dil_w; k.m = a.M;
-        auto it = tuning.best.find(k);
-        if (it != tuning.best.end()) {
-            best_ct = it->second.first;
-            tuned_pt = it->second.second;
+        k.cin = a.Cin; k.cout = a.Cout; k.kh = a.KH; k.kw = a.KW; k.stride = a.stride; k.dil_h = a.dil_h; k.dil_w = a.dil_w;
+        if (const TuneTable::Choice* c = tuning.find(k, a.M)) {
+            best_ct = c->ct;
+            tuned_pt = c->pt;
+            if (c->variant >= 0) variant = c->variant;
         }
     }
+    if (env_variant >= 0) variant = env_variant;
+    if (g_variant >= 0) variant = g_variant;
     if (force_ct) best_ct = force_ct;
     if (g_force_ct) best_ct = g_force_ct;
     const int cblocks = (tiles + best_ct - 1) / best_ct;
@@ -638,6 +669,7 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
         if (pt_by_ct[best_ct] && (long)((a.M + 64 * pt_by_ct[best_ct] - 1) / (64 * pt_by_ct[best_ct])) * cblocks >= min_blocks)
             pt = pt_by_ct[best_ct];
     }
+    if (variant == 1) return pp_launch_conv_p3(a, best_ct, pt, stream);
     switch (best_ct) {
         case 4: return launch_ct<4>(a, pt, stream);
         case 3: return launch_ct<3>(a, pt, stream);

@@ -80,6 +80,8 @@ struct ConvArgs {
 };
 int pp_conv_out_dim(int in, int k, int stride, int pad, int dil);
 int pp_launch_conv(const ConvArgs& a, hipStream_t stream);
+// software-pipelined variant (conv_igemm_p3.hip): same results; `a` as prepared by pp_launch_conv
+int pp_launch_conv_p3(const ConvArgs& a, int ct, int pt, hipStream_t stream);
 
 struct PoolArgs {
     const float* x;

@@ -32,6 +32,8 @@ int pp_net_dims(pp_net* net, int buf, int* h, int* w, int* c);
 int pp_net_max_batch(pp_net* net);
 pp_ctx* pp_net_ctx(pp_net* net);
 
+extern "C" void pp_topdown_destroy(pp_topdown* t);
+
 extern "C" {
 
 int pp_topdown_create(pp_net* net, int in_buf, int out_buf, int num_joints, const int32_t* flip_perm,
@@ -39,7 +41,8 @@ int pp_topdown_create(pp_net* net, int in_buf, int out_buf, int num_joints, cons
                       pp_topdown** out) {
     PP_REQUIRE(net && lut && chan_map && out, "pp_topdown_create: NULL argument");
     *out = nullptr;
-    std::unique_ptr<pp_topdown> t(new pp_topdown());
+    // every early return below (PP_REQUIRE / PP_HIP_CHECK) releases what has been allocated so far
+    std::unique_ptr<pp_topdown, void (*)(pp_topdown*)> t(new pp_topdown(), pp_topdown_destroy);
     t->net = net;
     t->ctx = pp_net_ctx(net);
     int c = 0, oc = 0;
@@ -93,7 +96,9 @@ void pp_topdown_destroy(pp_topdown* t) {
     delete t;
 }
 
-static int topdown_tail(pp_topdown* t, int n_person, float* kpts, int kpts_mem) {
+// check_valid: zero the rows of absent persons (h_xf[i].valid == 0) ON THE DEVICE, so that host and device outputs both
+// keep the reference's zeros((K, 3)) contract (wrappers/mmpose.py:67-69)
+static int topdown_tail(pp_topdown* t, int n_person, float* kpts, int kpts_mem, bool check_valid) {
     hipStream_t s = t->ctx->stream;
     const int batch = n_person * (t->flip ? 2 : 1);
     PP_HIP_CHECK(hipEventRecord(t->ev[1], s));
@@ -111,6 +116,11 @@ static int topdown_tail(pp_topdown* t, int n_person, float* kpts, int kpts_mem) 
     rc = pp_enqueue_decode(s, dp, hm, hm_flip, t->d_perm, t->d_cs, dk, nullptr);
     if (rc != PP_OK) return rc;
     PP_HIP_CHECK(hipEventRecord(t->ev[3], s));
+    if (check_valid) {
+        const size_t row = (size_t)t->k * 3;
+        for (int i = 0; i < n_person; ++i)
+            if (!t->h_xf[i].valid) PP_HIP_CHECK(hipMemsetAsync(dk + (size_t)i * row, 0, row * sizeof(float), s));
+    }
     if (kpts_mem == PP_MEM_HOST) {
         PP_HIP_CHECK(hipMemcpyAsync(kpts, dk, (size_t)n_person * t->k * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
     }
@@ -153,14 +163,7 @@ int pp_topdown_run(pp_topdown* t, const uint8_t* frames, int n_frames, int h, in
     rc = pp_enqueue_crop(s, dframes, h, w, t->d_xf, n_person, t->in_w, t->in_h, t->d_lut, t->chan_map, t->flip,
                          static_cast<float*>(in_ptr), nullptr);
     if (rc != PP_OK) return rc;
-    rc = topdown_tail(t, n_person, kpts, kpts_mem);
-    if (rc != PP_OK) return rc;
-    // absent persons: the reference appends zeros((K, 3)) (wrappers/mmpose.py:67-69)
-    if (kpts_mem == PP_MEM_HOST) {
-        for (int i = 0; i < n_person; ++i)
-            if (!t->h_xf[i].valid) memset(kpts + (size_t)i * t->k * 3, 0, (size_t)t->k * 3 * sizeof(float));
-    }
-    return PP_OK;
+    return topdown_tail(t, n_person, kpts, kpts_mem, true);
 }
 
 int pp_topdown_run_precropped(pp_topdown* t, const float* x_nhwc4, int x_mem, const float* center_scale,
@@ -186,7 +189,7 @@ int pp_topdown_run_precropped(pp_topdown* t, const float* x_nhwc4, int x_mem, co
         rc = pp_enqueue_flip_w(s, din, din + (size_t)n_person * (in_bytes / sizeof(float)), n_person, t->in_h, t->in_w);
         if (rc != PP_OK) return rc;
     }
-    return topdown_tail(t, n_person, kpts, kpts_mem);
+    return topdown_tail(t, n_person, kpts, kpts_mem, false);
 }
 
 int pp_topdown_timing(pp_topdown* t, float* ms3) {

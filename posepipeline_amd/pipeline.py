@@ -43,10 +43,11 @@ class Video(dj.Manual):  # pipeline.py:25-33
 
     @staticmethod
     def get_robust_reader(key, return_cap=True):
-        """pipeline.py:47-87: hand back the video path (or an opened reader).  The reference validates
-        by decoding every frame once and transcodes with ffmpeg on failure; the frame sources here are
-        validated when opened."""
-        path = (Video & key).fetch1("video")
+        """pipeline.py:47-87: the path of a readable copy of the video (or an opened reader): every announced frame must
+        decode, else the file is transcoded with the reference's ffmpeg command and read from the transcode
+        (video.robust_path; validated once per file instead of once per stage).  Unlike the reference the attachment is not
+        moved into a temporary file: `video` holds a path the caller owns, and the wrappers do not delete it."""
+        path = _video.robust_path((Video & key).fetch1("video"))
         if return_cap:
             return _video.open_video(path)
         return path

@@ -90,6 +90,48 @@ def write_ppvid(path, frames: np.ndarray, fps: float = 30.0):
         f.write(frames.tobytes())
 
 
+_ROBUST: dict = {}      # validated path -> path to read (itself, or its ffmpeg transcode)
+
+
+def robust_path(path, run=None):
+    """`Video.get_robust_reader`'s check (pose_pipeline/pipeline.py:47-87): every frame the container announces must decode;
+    if one does not, the WHOLE file is transcoded (`ffmpeg -y -i <video> -c:v libx264 -b:v 1M <tmp>.mp4`, the reference's
+    command) and every frame is then read from the transcode.  The reference repeats this full decode in each stage
+    (pipeline.py:517, wrappers/mmpose.py:54); here the verdict is cached per file (path, size, mtime), so a video is
+    validated once and afterwards streamed in a single pass.
+    Raw containers (.npy / .ppvid) have nothing to decode: their header is checked against the file size when opened.
+    `run`: subprocess.run stand-in (tests)."""
+    import subprocess
+    import tempfile
+    if isinstance(path, np.ndarray) or os.path.splitext(path)[1].lower() in (".npy", ".ppvid"):
+        return path
+    st = os.stat(path)
+    key = (os.path.abspath(path), st.st_size, st.st_mtime_ns)
+    if key in _ROBUST and os.path.exists(_ROBUST[key]):
+        return _ROBUST[key]
+    try:
+        import cv2
+    except ImportError as e:
+        raise RuntimeError(f"cannot decode {path}: OpenCV is not installed and the file is not .npy/.ppvid") from e
+    cap = cv2.VideoCapture(path)
+    expected = int(cap.get(cv2.CAP_PROP_FRAME_COUNT))
+    good = path
+    for _ in range(expected):
+        ret, frame = cap.read()
+        if not ret or frame is None:
+            fd, good = tempfile.mkstemp(suffix=".mp4")
+            os.close(fd)
+            print(f"Unable to read all the frames. Transcoding {path} to {good}")
+            try:
+                (run or subprocess.run)(["ffmpeg", "-y", "-i", path, "-c:v", "libx264", "-b:v", "1M", good])
+            except FileNotFoundError as e:
+                raise RuntimeError(f"{path}: a frame does not decode and ffmpeg is not installed to transcode the file") from e
+            break
+    cap.release()
+    _ROBUST[key] = good
+    return good
+
+
 def open_video(path):
     """-> object with fps / num_frames / height / width / read() / read_batch(n) / release()."""
     if isinstance(path, np.ndarray):
@@ -103,6 +145,9 @@ def open_video(path):
         if head[:8] != MAGIC:
             raise ValueError(f"{path}: not a PPVID001 file")
         n, h, w, fps1000 = struct.unpack("<iiii", head[8:24])
+        have = (os.path.getsize(path) - 32) // max(h * w * 3, 1)
+        if have < n:          # truncated file: like a cv2 reader whose read() fails early, the stream simply ends there
+            n = max(have, 0)
         frames = np.memmap(path, dtype=np.uint8, mode="r", offset=32, shape=(n, h, w, 3))
         return ArrayVideo(frames, fps1000 / 1000.0)
     try:

@@ -9,7 +9,8 @@ The reference runs, per frame: YOLOv4 (`yolo.detect_image`, persons only) -> mar
 read in batches; letterbox, the two networks and the box decode run on the GPU, NMS through pp_nms, the strictly
 sequential association in C++ (pp_tracker mode 0, fixture-pinned against the reference's own deep_sort package).
 `outfile` (annotated video writer, parser.py:29-31,88-129) is not supported.
-Checkpoints: yolo4.h5 (Keras/HDF5) and mars-small128.pb (TensorFlow GraphDef) cannot be parsed in this environment;
+Checkpoints (checkpoints_tf.py): mars-small128.pb (TensorFlow GraphDef) is read directly with a protobuf wire decoder,
+yolo4.h5 (Keras/HDF5) through `tools/convert_yolo4_h5.py` -> yolo4.npz (or h5py when importable); without the files,
 POSEPIPE_SYNTHETIC_WEIGHTS=1 runs seeded weights of the same architectures.
 """
 from __future__ import annotations
@@ -28,19 +29,26 @@ _cache: dict = {}
 
 
 def _params(relpath, shapes, seed, **kw):
+    """the reference's checkpoint when it is installed (checkpoints_tf: GraphDef constants read directly, Keras HDF5 through
+    its converted .npz or h5py), seeded weights of the same architecture with POSEPIPE_SYNTHETIC_WEIGHTS=1"""
+    from ... import checkpoints_tf
     path = os.path.join(weights.model_data_dir(), relpath)
+    converted = os.path.splitext(path)[0] + ".npz"
+    if os.path.exists(path) or os.path.exists(converted):
+        if relpath.endswith(".pb"):
+            return checkpoints_tf.mars_params(path if os.path.exists(path) else converted, shapes)
+        return checkpoints_tf.yolo_params(path, shapes)
     if os.environ.get("POSEPIPE_SYNTHETIC_WEIGHTS") == "1":
         return yolov4.synth_params(shapes, seed, **kw)
-    if os.path.exists(path):
-        raise NotImplementedError(f"{path}: no Keras-HDF5 / TensorFlow-GraphDef reader in this environment "
-                                  "(set POSEPIPE_SYNTHETIC_WEIGHTS=1 for seeded weights)")
     raise FileNotFoundError(f"{path} (set POSEPIPE_SYNTHETIC_WEIGHTS=1 to run with seeded synthetic weights)")
 
 
 def _models(src_h, src_w, device=0):
     key = (src_h, src_w, device)
     if key not in _cache:
-        ysd = yolov4.seed_person_head(_params("deep_sort_yolov4/yolo4.h5", yolov4.yolov4_param_shapes(), seed=4))
+        ysd = _params("deep_sort_yolov4/yolo4.h5", yolov4.yolov4_param_shapes(), seed=4)
+        if not os.path.exists(os.path.join(weights.model_data_dir(), "deep_sort_yolov4/yolo4.h5")):
+            yolov4.seed_person_head(ysd)                 # seeded weights only: make the random head produce person candidates
         msd = _params("deep_sort_yolov4/mars-small128.pb", mars.mars_param_shapes(), seed=5)
         ctx = _lib.Context(device)
         _cache[key] = (ctx, yolov4.YoloV4Detector(ctx, ysd, src_h, src_w, max_frames=BATCH),
@@ -67,26 +75,28 @@ def tracking_bounding_boxes(file_path, outfile=None):
         return tracks
     # the clip is read once and streamed to the device BATCH frames at a time; a read failure ends the stream (:52-53)
     streamer = FrameStreamer(ctx, cap, min(BATCH, video_length), max_frames=video_length)
-    for dev_ptr, n, _first in streamer:
-        dets = yolo.run(None, frames_dev=(dev_ptr, n))               # per frame: boxes [m][4] int, confidences [m]
-        feats = encoder.encode(None, [b for b, _ in dets], frames_dev=(dev_ptr, n))
-        streamer.release()
-        for (boxes, conf), feat in zip(dets, feats):
-            tlwh = boxes.astype(np.float64)                          # Detection.tlwh (detection.py:29)
-            scores = conf.astype(np.float64)
-            keep = ops.nms(ctx, tlwh, scores, nms_max_overlap, convention=1) if len(tlwh) else np.zeros(0, np.int64)
-            ids, t_tlwh, info = tracker.step(tlwh[keep], scores[keep], feat[keep])
-            tracks.append(
-                [
-                    {
-                        "track_id": int(i),
-                        "tlhw": b.copy(),
-                        "tlbr": np.concatenate([b[:2], b[:2] + b[2:]]),
-                        "time_since_update": int(s[3]),
-                    }
-                    for i, b, s in zip(ids, t_tlwh, info)
-                ]
-            )
-    streamer.close()
-    cap.release()
+    try:      # an error in a stage must not leak the reader thread, the page-locked staging buffers and the open video
+        for dev_ptr, n, _first in streamer:
+            dets = yolo.run(None, frames_dev=(dev_ptr, n))               # per frame: boxes [m][4] int, confidences [m]
+            feats = encoder.encode(None, [b for b, _ in dets], frames_dev=(dev_ptr, n))
+            streamer.release()
+            for (boxes, conf), feat in zip(dets, feats):
+                tlwh = boxes.astype(np.float64)                          # Detection.tlwh (detection.py:29)
+                scores = conf.astype(np.float64)
+                keep = ops.nms(ctx, tlwh, scores, nms_max_overlap, convention=1) if len(tlwh) else np.zeros(0, np.int64)
+                ids, t_tlwh, info = tracker.step(tlwh[keep], scores[keep], feat[keep])
+                tracks.append(
+                    [
+                        {
+                            "track_id": int(i),
+                            "tlhw": b.copy(),
+                            "tlbr": np.concatenate([b[:2], b[:2] + b[2:]]),
+                            "time_since_update": int(s[3]),
+                        }
+                        for i, b, s in zip(ids, t_tlwh, info)
+                    ]
+                )
+    finally:
+        streamer.close()
+        cap.release()
     return tracks

@@ -84,16 +84,18 @@ def mmtrack_bounding_boxes(file_path, method="tracktor"):
     # the clip is read once and streamed to the device `batch` frames at a time (the reference: one cap.read() and one
     # blocking upload per frame, :38-45); a read failure simply ends the stream (:41-42)
     streamer = FrameStreamer(ctx, cap, min(batch, video_length), max_frames=video_length)
-    for dev_ptr, n, _first in streamer:
-        per_frame = det.run(None, frames_dev=(dev_ptr, n))          # [n][5] float32: x1 y1 x2 y2 score
-        streamer.release()
-        for rows in per_frame:
-            if byte:
-                track_results = list(tracker.step(rows))                                     # [id, x1, y1, x2, y2, score]
-            else:
-                ids, _, info = tracker.step(rows[:, :4].astype(np.float64), rows[:, 4].astype(np.float64))
-                track_results = [np.concatenate([[np.float32(i)], rows[j]]).astype(np.float32) for i, j in zip(ids, info[:, 1])]
-            tracks.append(_rows_to_dicts(track_results))
-    streamer.close()
-    cap.release()
+    try:      # an error in a stage must not leak the reader thread, the page-locked staging buffers and the open video
+        for dev_ptr, n, _first in streamer:
+            per_frame = det.run(None, frames_dev=(dev_ptr, n))          # [n][5] float32: x1 y1 x2 y2 score
+            streamer.release()
+            for rows in per_frame:
+                if byte:
+                    track_results = list(tracker.step(rows))                                     # [id, x1, y1, x2, y2, score]
+                else:
+                    ids, _, info = tracker.step(rows[:, :4].astype(np.float64), rows[:, 4].astype(np.float64))
+                    track_results = [np.concatenate([[np.float32(i)], rows[j]]).astype(np.float32) for i, j in zip(ids, info[:, 1])]
+                tracks.append(_rows_to_dicts(track_results))
+    finally:
+        streamer.close()
+        cap.release()
     return tracks

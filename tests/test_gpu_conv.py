@@ -28,8 +28,17 @@ CASES = [
 ]
 
 
+@pytest.fixture(params=[0, 1], ids=["two_barrier", "pipelined"])
+def variant(ctx, request):
+    """both kernels (conv_igemm.hip / conv_igemm_p3.hip) must give the oracle's bits"""
+    L.check(ctx.lib.pp_conv_variant(request.param), "pp_conv_variant")
+    yield request.param
+    L.check(ctx.lib.pp_conv_variant(-1), "pp_conv_variant")
+    L.check(ctx.lib.pp_conv_force(0, 0), "pp_conv_force")
+
+
 @pytest.mark.parametrize("case", CASES)
-def test_conv_bit_exact(ctx, case):
+def test_conv_bit_exact(ctx, case, variant):
     n, h, w, cin, cout, k, stride, pad, dil = case
     rng = np.random.default_rng(hash(case) % (2 ** 31))
     kh = 1 if h == 1 else k
@@ -43,7 +52,24 @@ def test_conv_bit_exact(ctx, case):
     assert np.array_equal(got, ref), f"max |d| = {np.abs(got - ref).max()}"
 
 
-def test_conv_epilogues(ctx):
+@pytest.mark.parametrize("case", [CASES[2], CASES[4], CASES[8], CASES[11], CASES[12], CASES[15]])
+def test_conv_every_tile_configuration(ctx, case, variant):
+    """results do not depend on the tile configuration (channel tile 16..64, pixel tile 64 / 128) of either kernel"""
+    n, h, w, cin, cout, k, stride, pad, dil = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    kh = 1 if h == 1 else k
+    x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, kh, k)) / np.sqrt(cin * kh * k)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    kw = dict(stride=stride, pad=(0 if h == 1 else pad, pad), dil=(1, dil))
+    ref = ref_conv_op(x, wt, b, **kw)
+    for ct in (1, 2, 3, 4):
+        for pt in (1, 2):
+            L.check(ctx.lib.pp_conv_force(ct, pt), "pp_conv_force")
+            assert np.array_equal(hip_conv_op(ctx, x, wt, b, **kw), ref), (ct, pt)
+
+
+def test_conv_epilogues(ctx, variant):
     rng = np.random.default_rng(7)
     x = rng.standard_normal((3, 12, 9, 96)).astype(np.float32)
     wt = (rng.standard_normal((48, 96, 1, 1)) / 10).astype(np.float32)

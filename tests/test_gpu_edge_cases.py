@@ -133,3 +133,24 @@ print("SPLIT_OK")
     env = dict(os.environ, POSEPIPE_CONV_MAX_MB="1")
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
     assert "SPLIT_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_absent_person_rows_are_zero_in_device_outputs_too(ctx, small_td):
+    """wrappers/mmpose.py:67-69: a NaN box yields zeros((K, 3)).  With a DEVICE output buffer (PP_MEM_DEVICE) the library has
+    to zero those rows itself -- the decode of an all-zero crop is not zero."""
+    net, td = small_td
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, (2, 48, 64, 3)).astype(np.uint8)
+    boxes = np.array([[5.0, 4.0, 30.0, 40.0], [np.nan] * 4, [20.0, 2.0, 25.0, 44.0]], np.float64)
+    fidx = np.array([0, 1, 1], np.int32)
+    host, valid = td.run(frames, fidx, boxes)
+    assert valid.tolist() == [1, 0, 1] and not host[1].any() and host[0].any() and host[2].any()
+    dk = ctx.malloc(3 * 17 * 3 * 4)
+    ctx.h2d(dk, np.full((3, 17, 3), 7.0, np.float32))
+    v = np.zeros(3, np.int32)
+    L.check(ctx.lib.pp_topdown_run(td.handle, L.ptr(frames), 2, 48, 64, L.PP_MEM_HOST, L.ptr(fidx), L.ptr(boxes), 3,
+                                   C.c_void_p(dk), L.PP_MEM_DEVICE, L.ptr(v)), "pp_topdown_run")
+    dev = np.empty((3, 17, 3), np.float32)
+    ctx.d2h(dev, dk)
+    ctx.free(dk)
+    assert np.array_equal(dev, host)

@@ -1,0 +1,97 @@
+"""Video.get_robust_reader's validation + ffmpeg fallback (pose_pipeline/pipeline.py:47-87) on stand-ins for cv2 and ffmpeg
+(neither is installed here): control flow, the exact transcode command, one validation per file, raw containers."""
+import sys
+import types
+
+import numpy as np
+import pytest
+
+from posepipeline_amd import video
+
+
+class FakeCapture:
+    """frames_ok[path] readable frames of `announced`"""
+    announced = 12
+    frames_ok: dict = {}
+    opened: list = []
+
+    def __init__(self, path):
+        self.path, self.pos = path, 0
+        FakeCapture.opened.append(path)
+
+    def get(self, prop):
+        return {7: self.announced, 5: 30.0, 3: 64, 4: 48}.get(prop, 0)
+
+    def read(self):
+        if self.pos >= self.frames_ok.get(self.path, self.announced):
+            return False, None
+        self.pos += 1
+        return True, np.zeros((48, 64, 3), np.uint8)
+
+    def release(self):
+        pass
+
+
+@pytest.fixture
+def fake_cv2(monkeypatch):
+    m = types.ModuleType("cv2")
+    m.VideoCapture = FakeCapture
+    m.CAP_PROP_FRAME_COUNT, m.CAP_PROP_FPS, m.CAP_PROP_FRAME_WIDTH, m.CAP_PROP_FRAME_HEIGHT = 7, 5, 3, 4
+    monkeypatch.setitem(sys.modules, "cv2", m)
+    FakeCapture.frames_ok, FakeCapture.opened = {}, []
+    video._ROBUST.clear()
+    return m
+
+
+def test_good_file_is_validated_once(fake_cv2, tmp_path):
+    p = tmp_path / "ok.mp4"
+    p.write_bytes(b"x" * 100)
+    calls = []
+    assert video.robust_path(str(p), run=lambda cmd: calls.append(cmd)) == str(p)
+    assert video.robust_path(str(p), run=lambda cmd: calls.append(cmd)) == str(p)
+    assert calls == [] and FakeCapture.opened == [str(p)]                    # second call: cached verdict, no decode
+    cap = video.open_video(str(p))
+    assert cap.num_frames == 12 and cap.read_batch(5).shape == (5, 48, 64, 3)
+
+
+def test_unreadable_frame_transcodes_whole_file(fake_cv2, tmp_path, capsys):
+    p = tmp_path / "bad.mp4"
+    p.write_bytes(b"x" * 100)
+    FakeCapture.frames_ok[str(p)] = 7                                        # frame 7 of 12 does not decode
+    calls = []
+    out = video.robust_path(str(p), run=lambda cmd: calls.append(cmd))
+    assert out != str(p) and out.endswith(".mp4")
+    assert calls == [["ffmpeg", "-y", "-i", str(p), "-c:v", "libx264", "-b:v", "1M", out]]     # the reference's command
+    assert "Transcoding" in capsys.readouterr().out
+    assert video.robust_path(str(p), run=lambda cmd: calls.append(cmd)) == out and len(calls) == 1
+    # through the table API: the path handed to the wrappers is the transcode
+    import datetime
+    from posepipeline_amd import djshim, pipeline as pl
+    djshim.reset()
+    key = {"video_project": "p", "filename": "bad"}
+    pl.Video.insert1({**key, "video": str(p), "start_time": datetime.datetime(2024, 1, 1)})
+    assert pl.Video.get_robust_reader(key, return_cap=False) == out
+    djshim.reset()
+
+
+def test_missing_ffmpeg_is_an_error_not_a_silent_short_clip(fake_cv2, tmp_path):
+    p = tmp_path / "bad2.mp4"
+    p.write_bytes(b"y" * 10)
+    FakeCapture.frames_ok[str(p)] = 0
+
+    def no_ffmpeg(cmd):
+        raise FileNotFoundError("ffmpeg")
+    with pytest.raises(RuntimeError, match="ffmpeg is not installed"):
+        video.robust_path(str(p), run=no_ffmpeg)
+
+
+def test_raw_containers_need_no_decoder(tmp_path):
+    frames = np.arange(4 * 6 * 8 * 3, dtype=np.uint8).reshape(4, 6, 8, 3)
+    path = str(tmp_path / "c.ppvid")
+    video.write_ppvid(path, frames)
+    assert video.robust_path(path) == path
+    assert np.array_equal(video.open_video(path).read_batch(10), frames)
+    with open(path, "r+b") as f:                                             # truncated: the stream ends at the last whole frame
+        f.truncate(32 + 2 * 6 * 8 * 3 + 5)
+    v = video.open_video(path)
+    assert v.num_frames == 2 and np.array_equal(v.read_batch(10), frames[:2])

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--cfg", nargs="*", default=["0,0"])
     ap.add_argument("--res", action="store_true", help="residual add + ReLU epilogue (BasicBlock conv2)")
     ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--variants", default="0", help="kernel variants to time: 0 two-barrier, 1 three-stage pipelined")
     a = ap.parse_args()
     h, w, cin, cout, k = a.dims[:5]
     stride = a.dims[5] if len(a.dims) > 5 else 1
@@ -41,9 +42,10 @@ def main():
     net = Net(ctx, prog, max_batch=max(batches))
     flop = 2.0 * ho * wo * cout * cin * k * k
     print(f"{h}x{w} {cin}->{cout} k{k} s{stride}{' +res' if a.res else ''}: {flop / 1e9:.3f} GFLOP per sample")
-    for cfg in a.cfg:
+    for variant, cfg in [(int(v), c) for v in a.variants.split(",") for c in a.cfg]:
         ct, pt = (int(v) for v in cfg.split(","))
         L.check(ctx.lib.pp_conv_force(ct, pt), "pp_conv_force")
+        L.check(ctx.lib.pp_conv_variant(variant), "pp_conv_variant")
         for b in batches:
             net.profile(b)
             ms = float(np.median([net.profile(b)[0] for _ in range(a.reps)]))
@@ -53,8 +55,9 @@ def main():
             if ct and pt:
                 nb = -(-m // (64 * pt)) * -(-((cout + 15) // 16) // ct)
                 blocks = f" blocks {nb:6d} = {nb / 1024:5.2f} rounds"
-            print(f"  cfg {ect},{ept} batch {b:4d}: {ms * 1e3:9.1f} us  {flop * b / ms / 1e9:7.2f} TFLOP/s{blocks}")
+            print(f"  v{variant} cfg {ect},{ept} batch {b:4d}: {ms * 1e3:9.1f} us  {flop * b / ms / 1e9:7.2f} TFLOP/s{blocks}")
     L.check(ctx.lib.pp_conv_force(0, 0), "pp_conv_force")
+    L.check(ctx.lib.pp_conv_variant(-1), "pp_conv_variant")
 
 
 if __name__ == "__main__":
