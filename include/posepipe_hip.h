@@ -105,6 +105,8 @@ typedef enum {
                                 w[:, :, 3-a-2r, 3-b-2s]^T (output parity (a, b), tap (r, s)); b_off: bias[cout];
                                 cin % 64 == 0, cout % 8 == 0; relu PP_RELU_NONE / PP_RELU_LAST.  One GEMM with N = 16 cout
                                 and a 4-term gather; operands rounded to bf16, fp32 accumulation (tolerance-based parity) */
+    PP_OP_AVGPOOL = 9,       /* nn.AvgPool2d((kh, kw), stride), no padding: float32 sum in (kh, kw) order / (kh * kw)  (the
+                                GlobalAveragePooling neck of mmtrack's ReID model, mot/deepsort/deepsort_*.py:27) */
     PP_OP_UPSAMPLE_ADD = 7,  /* out[y][x] = act((in[y >> up_log2][x >> up_log2] + res1[y][x]) + res2[y][x]): nearest
                                 upsample + accumulate of an HRNet fuse layer (relu: PP_RELU_NONE / PP_RELU_LAST);
                                 same additions, same order as a conv with up_log2, from a fully parallel kernel */
@@ -185,6 +187,13 @@ int pp_conv_variant(int variant);
 int pp_conv2d(pp_ctx* ctx, const pp_op* op, int n, int hin, int win, const float* x,
               const float* w, const float* bias, const float* res1, const float* res2, float* y,
               int res1_h, int res1_w, int mem);
+
+/* Crops for mmtrack's ReID branch (SortTracker.crop_imgs: `F.interpolate(img[:, :, y1:y2, x1:x2], (256, 128), 'bilinear',
+ * align_corners=False)` on the DETECTOR's normalised input tensor, mot/deepsort/deepsort_*.py:43-49).  src: DEVICE [n_src][src_h]
+ * [src_w][4] float32; rects5: HOST int32 [n][5] = (source image, x1, y1, x2, y2), x2 > x1, y2 > y1, inside the image;
+ * out: DEVICE [n][out_h][out_w][4].  PyTorch's float32 upsample_bilinear2d arithmetic. */
+int pp_crop_resize_bilinear(pp_ctx* ctx, const float* src_nhwc4, int n_src, int src_h, int src_w, const int32_t* rects5, int n,
+                            int out_h, int out_w, float* out_nhwc4);
 
 /* ---- ViT encoder (bf16 MFMA path) -----------------------------------------------------------
  * BASELINE.json configs[4] "ViTPose-H backbone (bf16 MFMA path)".  ViTPose is NOT in the reference tree; it fills the

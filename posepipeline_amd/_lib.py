@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("POSEPIPE_LIB", os.path.join(_HERE, "libposepipe_hip.s
 PP_MEM_HOST, PP_MEM_DEVICE = 0, 1
 PP_OP_CONV, PP_OP_MAXPOOL, PP_OP_ROIALIGN, PP_OP_COPY, PP_OP_VIT_ENCODER, PP_OP_DEPTH_TO_SPACE, PP_OP_UPSAMPLE_ADD = 1, 2, 3, 4, 5, 6, 7
 PP_OP_DECONV_BF16 = 8
+PP_OP_AVGPOOL = 9
 PP_RELU_NONE, PP_RELU_LAST, PP_RELU_FIRST = 0, 1, 2
 PP_ACT_LEAKY, PP_ACT_MISH, PP_ACT_ELU, PP_ACT_SWISH = 3, 4, 5, 6
 
@@ -92,6 +93,7 @@ SIGNATURES = {
     "pp_net_capture": (_i, [_vp, _i]),
     "pp_net_set_lanes": (_i, [_vp, _i]),
     "pp_net_profile": (_i, [_vp, _i, _vp]),
+    "pp_crop_resize_bilinear": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "pp_conv_force": (_i, [_i, _i]),
     "pp_conv_variant": (_i, [_i]),
     "pp_conv2d": (_i, [_vp, C.POINTER(pp_op), _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),

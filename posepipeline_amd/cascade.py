@@ -31,15 +31,17 @@ from .wrappers.videopose3d import lift
 
 
 class Cascade:
-    """tracking: "MMTrack_deepsort" (Faster-RCNN R50-FPN + SORT, det_sd = detector weights) or "DeepSortYOLOv4"
-    (tracking_method 0, the reference recipes' default: det_sd = (yolov4 weights, mars-small128 weights)).
+    """tracking: "MMTrack_deepsort" (Faster-RCNN R50-FPN, det_sd = detector weights; association = mmtrack SortTracker: with
+    reid_sd (ReID ResNet-50 weights) the DeepSORT configuration with its appearance branch, without it the SORT
+    configuration BASELINE.json configs[2] names) or "DeepSortYOLOv4" (tracking_method 0, the reference recipes' default:
+    det_sd = (yolov4 weights, mars-small128 weights)).
     max_persons / keep_tracks: which track ids are followed (person_stream.PersonStreams).
     In "DeepSortYOLOv4" mode every track the tracker keeps is a row of every frame (tentative and missed ones with their
     Kalman box), because that is what the reference stores (parser.py:76-86) and PersonBbox selects from."""
 
     def __init__(self, ctx: L.Context, det_sd, pose_sd: dict, lift_sd: dict, src_h: int, src_w: int,
                  chunk: int = 8, max_persons: int = 1, pose_spec=None, post="unbiased", blur_kernel=17,
-                 tracking: str = "MMTrack_deepsort", keep_tracks=None, flip_pairs=None, blob_fn=None):
+                 tracking: str = "MMTrack_deepsort", keep_tracks=None, flip_pairs=None, blob_fn=None, reid_sd=None):
         """blob_fn(name, program) -> (device pointer, n_floats) or None, name in "det_a", "det_b", "pose", "lift" (called in
         that order): a weight blob that is already resident on the device -- parallel.broadcast_blob_device delivers rank
         0's over RCCL; the *_sd arguments then only define the program structure (ops, buffers, blob offsets)."""
@@ -50,6 +52,7 @@ class Cascade:
         self.tracking = tracking
         self.keep_tracks = keep_tracks
         blob_fn = blob_fn or (lambda name, prog: None)
+        self.reid = None
         if tracking == "DeepSortYOLOv4":
             from .models import mars, yolov4
             self.detector = yolov4.YoloV4Detector(ctx, det_sd[0], src_h, src_w, max_frames=chunk)
@@ -57,6 +60,9 @@ class Cascade:
         else:
             assert tracking == "MMTrack_deepsort", tracking
             self.detector = fr.Detector(ctx, det_sd, src_h, src_w, max_frames=chunk, blob_fn=blob_fn)
+            if reid_sd is not None:
+                from .models import reid_r50
+                self.reid = reid_r50.ReidEncoder(ctx, reid_sd, self.detector, max_crops=max(64, chunk * max_persons), blob_fn=blob_fn)
         self.pose_spec = pose_spec or hrnet.hrnet_w48_384x288()
         if isinstance(self.pose_spec, vitpose.VitPoseSpec):     # BASELINE.json configs[4]: ViTPose 2D stage (UDP, bf16 MFMA)
             pose_prog = vitpose.build_vitpose_program(self.pose_spec, pose_sd)
@@ -94,6 +100,9 @@ class Cascade:
     def reset(self):
         if self.tracking == "DeepSortYOLOv4":
             self.tracker = Tracker(mode=0, feat_dim=128, max_cosine_distance=0.3)       # parser.py:35-47
+        elif getattr(self, "reid", None) is not None:
+            from .tracking import SortReidTracker
+            self.tracker = SortReidTracker()
         else:
             self.tracker = Tracker(mode=1, match_iou_thr=0.5, obj_score_thr=0.5)
         # the lifting network takes the 17 COCO joints; wider heads (Halpe-136 / WholeBody-133) start with them
@@ -126,6 +135,19 @@ class Cascade:
                 keep = ops.nms(self.ctx, tlwh, sc, 1.0, convention=1) if len(tlwh) else np.zeros(0, np.int64)
                 ids, t, _ = self.tracker.step(tlwh[keep], sc[keep], feat[keep])
                 chunk_tracks.append([(int(i), bb[0], bb[1], bb[0] + bb[2], bb[1] + bb[3], 1.0, bb.copy()) for i, bb in zip(ids, t)])
+        elif self.reid is not None:
+            # mmtrack DeepSORT: embeddings of the kept detections from the detector's resident input tensor, then
+            # appearance + IoU association; ids survive misses (up to num_frames_retain), so liveness is the tracker's
+            if replay is not None:
+                dets = replay
+            dets = [np.asarray(r, np.float32).reshape(-1, 5) for r in dets]
+            dets = [r[self.tracker.keep(r)] for r in dets]
+            embeds = self.reid.encode(dets)
+            self._live_sets = []
+            for rows, emb in zip(dets, embeds):
+                out = self.tracker.step(rows, emb)
+                chunk_tracks.append([(int(r[0]), *r[1:]) for r in out])
+                self._live_sets.append(self.tracker.live_ids())
         else:
             if replay is not None:
                 dets = replay
@@ -185,9 +207,10 @@ class Cascade:
                      keypoints / keypoints_frames = {track_id: (n,K,3) / (n,) frame numbers} decided in this step,
                      keypoints_3d / keypoints_3d_frames = {track_id: (m,17,3) / (m,)} emitted in this step)."""
         b = frames_dev[1] if frames_dev is not None else frames.shape[0]
+        self._live_sets = None
         chunk_tracks = self._track_chunk(frames, frames_dev, replay)
         n0 = self.persons.n_frames
-        self.persons.ingest(chunk_tracks)
+        self.persons.ingest(chunk_tracks, self._live_sets)
         self._cur = (frames, frames_dev, n0)
         out = self.persons.advance(final=False)
         self._save_tail(frames, frames_dev, n0, n0 + b)

@@ -302,6 +302,11 @@ static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
         PP_REQUIRE(pp_conv_out_dim(bi.h + eh, op.kh, op.stride, op.pad_h, 1) == bo.h &&
                        pp_conv_out_dim(bi.w + ew, op.kw, op.stride, op.pad_w, 1) == bo.w,
                    "op %d: maxpool output dims mismatch", idx);
+    } else if (op.type == PP_OP_AVGPOOL) {
+        PP_REQUIRE(op.cin == op.cout && (op.cin & 3) == 0 && bi.c == op.cin && bo.c == op.cin && op.in != op.out && op.kh > 0 &&
+                       op.kw > 0 && op.stride > 0 && bi.h >= op.kh && bi.w >= op.kw && (bi.h - op.kh) / op.stride + 1 == bo.h &&
+                       (bi.w - op.kw) / op.stride + 1 == bo.w,
+                   "op %d: avgpool needs in [h][w][c] and out [(h - kh) / s + 1][(w - kw) / s + 1][c], c %% 4 == 0", idx);
     } else if (op.type == PP_OP_COPY) {
         PP_REQUIRE(bi.c == bo.c && bi.h == bo.h && bi.w == bo.w, "op %d: copy shape mismatch", idx);
     } else if (op.type == PP_OP_DEPTH_TO_SPACE) {
@@ -368,6 +373,8 @@ static int net_launch_op(pp_net* net, const pp_op& op, int batch, hipStream_t s)
         p.x_stride = bi.c; p.x_coff = op.in_c_off; p.y_stride = bo.c; p.y_coff = op.out_c_off;
         p.KH = op.kh; p.KW = op.kw; p.stride = op.stride; p.pad_h = op.pad_h; p.pad_w = op.pad_w;
         return pp_launch_maxpool(p, s);
+    } else if (op.type == PP_OP_AVGPOOL) {
+        return pp_launch_avgpool(net->buf_ptr(op.in), net->buf_ptr(op.out), batch, bi.h, bi.w, op.cin, op.kh, op.kw, op.stride, s);
     } else if (op.type == PP_OP_COPY) {
         PP_HIP_CHECK(hipMemcpyAsync(net->buf_ptr(op.out), net->buf_ptr(op.in),
                                     (size_t)batch * net->buf_elems[op.in] * sizeof(float),

@@ -90,6 +90,8 @@ struct PoolArgs {
     int x_stride, x_coff, y_stride, y_coff;   // channel slices of wider buffers (0 stride: = C)
 };
 int pp_launch_maxpool(const PoolArgs& a, hipStream_t stream);
+// nn.AvgPool2d((kh, kw), stride), no padding, NHWC, c % 4 == 0 (elementwise.hip)
+int pp_launch_avgpool(const float* x, float* y, int n, int hin, int win, int c, int kh, int kw, int stride, hipStream_t stream);
 
 // ---- ViT encoder pieces, bf16 MFMA path (gemm_bf16.hip, vit_encoder.hip) ---------------------------
 struct GemmArgs {

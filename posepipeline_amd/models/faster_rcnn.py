@@ -85,8 +85,28 @@ def faster_rcnn_param_shapes(prefix="detector.") -> dict:
     return sh
 
 
-def build_image_program(sd: dict, hp: int, wp: int, prefix="detector.") -> Program:
-    pb = ProgramBuilder()
+def resnet50_param_shapes(sh: dict, prefix: str):
+    """conv + BatchNorm parameters of a torchvision-style ResNet-50 (`backbone.*` names of mmdet / mmcls checkpoints)"""
+    def cb(conv, bn, cout, cin, k):
+        sh[prefix + conv + ".weight"] = (cout, cin, k, k)
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            sh[prefix + bn + "." + s] = (cout,)
+
+    cb("backbone.conv1", "backbone.bn1", 64, 3, 7)
+    inpl = 64
+    for li, (blocks, planes, _) in enumerate(R50_LAYERS):
+        for b in range(blocks):
+            q = f"backbone.layer{li + 1}.{b}."
+            cb(q + "conv1", q + "bn1", planes, inpl, 1)
+            cb(q + "conv2", q + "bn2", planes, planes, 3)
+            cb(q + "conv3", q + "bn3", planes * 4, planes, 1)
+            if b == 0:
+                cb(q + "downsample.0", q + "downsample.1", planes * 4, inpl, 1)
+            inpl = planes * 4
+
+
+def resnet50_body(pb, sd: dict, x, prefix: str):
+    """ResNet-50, style 'pytorch' (stride on the 3x3), BatchNorm folded: -> [C2, C3, C4, C5]"""
     R = L.PP_RELU_LAST
     p = prefix
 
@@ -95,10 +115,6 @@ def build_image_program(sd: dict, hp: int, wp: int, prefix="detector.") -> Progr
                        sd[p + bn + ".running_mean"], sd[p + bn + ".running_var"])
         return pb.conv(x, w, b, name=conv, **kw)
 
-    def cbias(x, name, **kw):
-        return pb.conv(x, sd[p + name + ".weight"], sd[p + name + ".bias"], name=name, **kw)
-
-    x = pb.buf(hp, wp, 4, name="input")
     x = cb(x, "backbone.conv1", "backbone.bn1", stride=2, pad=3, relu=R)
     x = pb.maxpool(x, 3, 2, 1)
     feats = []
@@ -111,6 +127,19 @@ def build_image_program(sd: dict, hp: int, wp: int, prefix="detector.") -> Progr
             y = cb(y, q + "conv2", q + "bn2", stride=s, pad=1, relu=R)
             x = cb(y, q + "conv3", q + "bn3", relu=R, res1=idn)
         feats.append(x)
+    return feats
+
+
+def build_image_program(sd: dict, hp: int, wp: int, prefix="detector.") -> Program:
+    pb = ProgramBuilder()
+    R = L.PP_RELU_LAST
+    p = prefix
+
+    def cbias(x, name, **kw):
+        return pb.conv(x, sd[p + name + ".weight"], sd[p + name + ".bias"], name=name, **kw)
+
+    x = pb.buf(hp, wp, 4, name="input")
+    feats = resnet50_body(pb, sd, x, prefix)
     # FPN: lat[3] = conv(C5); lat[i-1] = conv(C_{i-1}) + nearest_up(lat[i])  (fused as a shifted residual read)
     lat = [None] * 4
     lat[3] = cbias(feats[3], "neck.lateral_convs.3.conv")

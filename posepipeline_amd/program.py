@@ -158,6 +158,12 @@ class ProgramBuilder:
                               w_off=0, b_off=0, name=name, flops=0.0))
         return out
 
+    def avgpool(self, x, kh, kw, stride=1, name="avgpool") -> int:
+        """nn.AvgPool2d((kh, kw), stride) without padding"""
+        h, w, c = self.dims(x)
+        out = self.buf((h - kh) // stride + 1, (w - kw) // stride + 1, c)
+        return self._plain_op(L.PP_OP_AVGPOOL, x, out, cin=c, cout=c, kh=kh, kw=kw, stride=stride, name=name)
+
     def _plain_op(self, type_, x, out, *, cin, cout, kh=1, kw=1, stride=1, w_off=0, name="op", flops=0.0):
         self.vops.append(dict(type=type_, in_=x, out=out, res1=-1, res2=-1, cin=cin, cout=cout, kh=kh, kw=kw, stride=stride,
                               pad_h=0, pad_w=0, dil_h=1, dil_w=1, relu=0, up_log2=0, out_nchw=0, res1_shift=0,

@@ -257,3 +257,124 @@ class ByteTracker:
         if len(out) == 0:
             return np.zeros((0, 6), np.float32)
         return np.concatenate([ids[:, None].astype(np.float32), out], axis=1).astype(np.float32)
+
+
+# ---- mmtrack SortTracker WITH its ReID branch (method "deepsort" of wrappers/mmtrack.py) ---------------------------------
+REID_GATED = 1e6      # surrogate cost of a Kalman-gated (track, detection) pair in the appearance assignment, see below
+
+
+def reid_cdist(a, b):
+    """torch.cdist(a, b) (p = 2) of float32 rows, defined here as: float64 sum of squared float32 differences, sqrt,
+    rounded to float32"""
+    d = a.astype(np.float32)[:, None, :].astype(np.float64) - b.astype(np.float32)[None, :, :].astype(np.float64)
+    return np.sqrt((d * d).sum(-1)).astype(np.float32)
+
+
+class SortReidTracker:
+    """mmtrack 0.x `SortTracker.track` as configured by 3rdparty/mmtracking/mot/deepsort/
+    deepsort_faster-rcnn_fpn_4e_mot17-private-half.py:43-54 (obj_score_thr .5, reid num_samples 10 / match_score_thr 2.0,
+    match_iou_thr .5, num_tentatives 2, num_frames_retain 100; motion = KalmanFilter(center_only=False)):
+
+      frame with no track yet (or no kept detection): every kept detection starts a track (tentative until it has
+      `num_tentatives` boxes; a tentative track that misses a frame is dropped), ids from a running counter starting at 0;
+      otherwise: Kalman-predict EVERY track and gate it against every detection (chi-square 0.95, 4 dof);
+        1. appearance: confirmed tracks (any age up to num_frames_retain) vs detections, Euclidean distance between the mean
+           of the track's last <= 10 embeddings and the detection's embedding, gated pairs excluded, Hungarian, accept
+           distance <= 2.0;
+        2. IoU: tracks updated in the previous frame and not matched yet vs the unmatched detections, cost 1 - IoU of the
+           last OBSERVED box (float32), Hungarian, accept cost < 0.5;
+      unmatched detections start new tracks; matched tracks get a Kalman update with the detection.
+
+    The gated pairs: mmtrack writes NaN into the distance matrix before scipy.optimize.linear_sum_assignment, which current
+    scipy rejects ("matrix contains invalid numeric entries") and old scipy resolved by unspecified NaN comparisons.  The
+    well-defined reading implemented here (and in oracle/reid_mm.py): a gated pair costs REID_GATED = 1e6 in the assignment
+    -- so the optimum uses as few gated pairs as possible -- and is never accepted.
+    Kalman filter / Hungarian: the C++ restatements behind pp_kalman_* / pp_linear_sum_assignment (fixture-pinned on the
+    in-tree deep_sort filter, which mmtrack's KalmanFilter copies).  mmtrack is not vendored: PARITY UNPINNED."""
+
+    CHI2INV95_4 = 9.4877
+
+    def __init__(self, obj_score_thr=0.5, match_iou_thr=0.5, match_score_thr=2.0, num_samples=10, num_tentatives=2,
+                 num_frames_retain=100):
+        self.lib = L.load_library()
+        self.obj_score_thr, self.match_iou_thr, self.match_score_thr = np.float32(obj_score_thr), match_iou_thr, match_score_thr
+        self.num_samples, self.num_tentatives, self.retain = num_samples, num_tentatives, num_frames_retain
+        self.tracks: dict = {}      # id -> dict(mean, cov, box, last, n, tentative, embeds); insertion-ordered like mmtrack's
+        self.num_tracks = 0
+        self.frame_id = -1
+
+    def live_ids(self) -> set:
+        return set(self.tracks)
+
+    def keep(self, dets):
+        """mask of the detections the tracker uses (score > obj_score_thr): only these need an embedding"""
+        return np.asarray(dets, np.float32).reshape(-1, 5)[:, 4] > self.obj_score_thr
+
+    def _kf(self, fn, *args):
+        L.check(getattr(self.lib, fn)(*[L.ptr(a) for a in args]), fn)
+
+    def step(self, dets, embeds):
+        """dets [n][5] float32 (x1, y1, x2, y2, score), ALREADY filtered with keep(); embeds [n][d] float32
+        -> rows [n][6] float32 (id, x1, y1, x2, y2, score)"""
+        self.frame_id += 1
+        fid = self.frame_id
+        dets = np.asarray(dets, np.float32).reshape(-1, 5)
+        n = len(dets)
+        embeds = np.asarray(embeds, np.float32).reshape(n, -1) if n else np.zeros((0, 1), np.float32)
+        zs = np.stack([ByteTracker._cxcyah(d[:4]) for d in dets]) if n else np.zeros((0, 4))
+        ids = np.full(n, -1, np.int64)
+        if self.tracks and n:
+            order = list(self.tracks)
+            gate = np.zeros((len(order), n))
+            for r, i in enumerate(order):
+                t = self.tracks[i]
+                self._kf("pp_kalman_predict", t["mean"], t["cov"])
+                out = np.zeros(n)
+                L.check(self.lib.pp_kalman_gating_distance(L.ptr(t["mean"]), L.ptr(t["cov"]), L.ptr(np.ascontiguousarray(zs)), n, L.ptr(out)),
+                        "pp_kalman_gating_distance")
+                gate[r] = out
+            gated = gate > self.CHI2INV95_4
+            confirmed = [i for i in order if not self.tracks[i]["tentative"]]
+            if confirmed:
+                means = []
+                for i in confirmed:
+                    e = self.tracks[i]["embeds"][-self.num_samples:]
+                    acc = np.zeros_like(e[0])
+                    for v in e:
+                        acc = (acc + v).astype(np.float32)
+                    means.append((acc / np.float32(len(e))).astype(np.float32))
+                dist = reid_cdist(np.stack(means), embeds)
+                g = gated[[order.index(i) for i in confirmed]]
+                cost = np.where(g, REID_GATED, dist.astype(np.float64))
+                rows, cols = linear_sum_assignment(cost)
+                for r, c in zip(rows, cols):
+                    if not g[r, c] and dist[r, c] <= self.match_score_thr:
+                        ids[c] = confirmed[r]
+            active = [i for i in order if i not in set(ids.tolist()) and self.tracks[i]["last"] == fid - 1]
+            if active:
+                free = np.flatnonzero(ids == -1)
+                if len(free):
+                    tb = np.stack([self.tracks[i]["box"] for i in active])
+                    dists = (np.float32(1) - _iou_f32(tb, dets[free, :4])).astype(np.float64)
+                    rows, cols = linear_sum_assignment(dists)
+                    for r, c in zip(rows, cols):
+                        if dists[r, c] < 1 - self.match_iou_thr:
+                            ids[free[c]] = active[r]
+        new = ids == -1
+        ids[new] = np.arange(self.num_tracks, self.num_tracks + int(new.sum()))
+        self.num_tracks += int(new.sum())
+        for i, d, z, e in zip(ids.tolist(), dets, zs, embeds):
+            if i in self.tracks:
+                t = self.tracks[i]
+                self._kf("pp_kalman_update", t["mean"], t["cov"], np.ascontiguousarray(z))
+                t["box"], t["last"], t["n"] = d[:4].copy(), fid, t["n"] + 1
+                t["embeds"] = (t["embeds"] + [e.copy()])[-self.num_samples:]
+                if t["tentative"] and t["n"] >= self.num_tentatives:
+                    t["tentative"] = False
+            else:
+                mean, cov = np.zeros(8), np.zeros(64)
+                L.check(self.lib.pp_kalman_initiate(L.ptr(np.ascontiguousarray(z)), L.ptr(mean), L.ptr(cov)), "pp_kalman_initiate")
+                self.tracks[i] = dict(mean=mean, cov=cov, box=d[:4].copy(), last=fid, n=1, tentative=True, embeds=[e.copy()])
+        for i in [i for i, t in self.tracks.items() if fid - t["last"] >= self.retain or (t["tentative"] and t["last"] != fid)]:
+            del self.tracks[i]
+        return np.concatenate([ids[:, None].astype(np.float32), dets], axis=1).astype(np.float32) if n else np.zeros((0, 6), np.float32)

@@ -7,9 +7,12 @@ frame; here the clip is streamed to the device in batches, the detector runs bat
 sequential association runs on the host.
 
 Built:
-  "deepsort"   Faster-RCNN R50-FPN (pp_detector) + mmtrack SortTracker (pp_tracker mode 1) of
-               mot/deepsort/*_faster-rcnn_fpn_4e_mot17-private-half.py WITHOUT its ReID appearance branch (DESIGN.md 7:
-               that branch feeds NaN costs to the Hungarian solver), i.e. the `sort_faster-rcnn` configuration;
+  "deepsort"   mot/deepsort/deepsort_faster-rcnn_fpn_4e_mot17-private-half.py, the configuration the reference selects
+               (wrappers/mmtrack.py:16-19): Faster-RCNN R50-FPN (pp_detector) + mmtrack SortTracker WITH its ReID
+               appearance branch -- ResNet-50 ReID model on 256x128 crops of the detector's input tensor
+               (models/reid_r50.py), Kalman gating, appearance then IoU assignment (tracking.SortReidTracker; the
+               NaN-gated assignment is given an explicit reading there).  POSEPIPE_MMTRACK_REID=0 drops the appearance
+               branch (= the sort_faster-rcnn configuration of the same directory, pp_tracker mode 1);
   "bytetrack"  YOLOX-X (models/yolox.py) + mmtrack ByteTracker (tracking.ByteTracker) of
                mot/bytetrack/bytetrack_yolox_x_crowdhuman_mot17-private.py -- restated from mmdet / mmtrack 0.x, unpinned.
 tracktor / qdtrack use other model families and raise NotImplementedError.  Unknown names raise Exception like the
@@ -19,9 +22,11 @@ from __future__ import annotations
 
 import numpy as np
 
+import os
+
 from .. import _lib, weights
 from ..models import faster_rcnn as fr
-from ..tracking import ByteTracker, Tracker
+from ..tracking import ByteTracker, SortReidTracker, Tracker
 from ..video import open_video
 
 BATCH = 16
@@ -46,7 +51,14 @@ def _detector(src_h, src_w, device=0, method="deepsort"):
         else:
             sd = weights.get_state_dict("mmtracking/checkpoints/faster-rcnn_r50_fpn_4e_mot17-half-64ee2ed4.pth",
                                         fr.faster_rcnn_param_shapes(), seed=2)
-            _cache[key] = (ctx, fr.Detector(ctx, sd, src_h, src_w, max_frames=BATCH))
+            det = fr.Detector(ctx, sd, src_h, src_w, max_frames=BATCH)
+            if method == "deepsort" and os.environ.get("POSEPIPE_MMTRACK_REID", "1") != "0":
+                from ..models import reid_r50
+                # init_cfg of the config's reid section (:39-42)
+                rsd = weights.get_state_dict("mmtracking/checkpoints/tracktor_reid_r50_iter25245-a452f51f.pth",
+                                             reid_r50.reid_param_shapes(), seed=7)
+                det.reid = reid_r50.ReidEncoder(ctx, rsd, det)
+            _cache[key] = (ctx, det)
     return _cache[key]
 
 
@@ -74,7 +86,8 @@ def mmtrack_bounding_boxes(file_path, method="tracktor"):
     video_length = int(cap.num_frames)
     ctx, det = _detector(cap.height, cap.width, method=method)
     byte = method == "bytetrack"
-    tracker = ByteTracker() if byte else Tracker(mode=1, match_iou_thr=0.5, obj_score_thr=0.5)
+    reid = getattr(det, "reid", None)
+    tracker = ByteTracker() if byte else SortReidTracker() if reid is not None else Tracker(mode=1, match_iou_thr=0.5, obj_score_thr=0.5)
     batch = BATCH_YOLOX if byte else BATCH
 
     tracks = []
@@ -87,10 +100,16 @@ def mmtrack_bounding_boxes(file_path, method="tracktor"):
     try:      # an error in a stage must not leak the reader thread, the page-locked staging buffers and the open video
         for dev_ptr, n, _first in streamer:
             per_frame = det.run(None, frames_dev=(dev_ptr, n))          # [n][5] float32: x1 y1 x2 y2 score
+            if reid is not None:
+                # appearance embeddings of the detections the tracker keeps, from the detector's resident input tensor
+                per_frame = [rows[tracker.keep(rows)] for rows in per_frame]
+                embeds = reid.encode(per_frame)
             streamer.release()
-            for rows in per_frame:
-                if byte:
-                    track_results = list(tracker.step(rows))                                     # [id, x1, y1, x2, y2, score]
+            for k, rows in enumerate(per_frame):
+                if reid is not None:
+                    track_results = list(tracker.step(rows, embeds[k]))                          # [id, x1, y1, x2, y2, score]
+                elif byte:
+                    track_results = list(tracker.step(rows))
                 else:
                     ids, _, info = tracker.step(rows[:, :4].astype(np.float64), rows[:, 4].astype(np.float64))
                     track_results = [np.concatenate([[np.float32(i)], rows[j]]).astype(np.float32) for i, j in zip(ids, info[:, 1])]

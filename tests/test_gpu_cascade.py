@@ -15,9 +15,12 @@ pytestmark = pytest.mark.gpu
 
 
 def test_mmtrack_wrapper_matches_oracle(ctx, tmp_path, monkeypatch):
+    """the sort_faster-rcnn configuration (appearance branch off); the ReID branch: tests/test_gpu_reid.py"""
     monkeypatch.setenv("POSEPIPE_SYNTHETIC_WEIGHTS", "1")
+    monkeypatch.setenv("POSEPIPE_MMTRACK_REID", "0")
     from posepipeline_amd import video
     from posepipeline_amd.wrappers import mmtrack as wmt
+    wmt._cache.clear()
     rng = np.random.default_rng(2)
     frames = np.stack([synth_frame(rng, 135, 240) for _ in range(3)])
     path = str(tmp_path / "v.ppvid")
