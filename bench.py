@@ -48,14 +48,45 @@ def parse():
     return ap.parse_args()
 
 
+def kernel_source_sha():
+    """fingerprint of what decides the conv kernels' memory traffic: their sources and the tile table"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("posepipeline_amd/csrc/conv_igemm.hip", "posepipeline_amd/csrc/conv_igemm_p3.hip", "posepipeline_amd/conv_tuning.txt"):
+        try:
+            with open(os.path.join(ROOT, rel), "rb") as f:
+                h.update(f.read())
+        except OSError:
+            h.update(b"-")
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(key):
-    """HBM bytes per conv launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json); the
-    counters cannot be read from inside the process, so the figure is the profiled one for this exact shape."""
+    """HBM bytes per conv launch from rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be read from inside the process):
+    profiles/pmc_traffic.json, written by tools/profile_round.sh together with the fingerprint of the kernel sources it was
+    measured on.  A figure measured on other sources is NOT reported (null + the reason), so the number cannot go stale."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)[key]["traffic_bytes_per_launch"]
+            e = json.load(f)[key]
     except (OSError, KeyError, ValueError):
-        return None
+        return None, "no rocprofv3 --pmc measurement for this workload shape (tools/profile_round.sh)"
+    if e.get("kernel_sha") != kernel_source_sha():
+        return None, "profiles/pmc_traffic.json was measured on other kernel sources (%s): rerun tools/profile_round.sh" % e.get("kernel_sha")
+    return e["traffic_bytes_per_launch"], e.get("source", "")
+
+
+def algorithmic_bytes(prog, batch):
+    """HBM bytes the conv launches of a program would move if every operand were read / written exactly once: per op, input
+    activations + weights + bias + residuals + output, float32 (the figure `traffic` is to be compared with)"""
+    total = 0
+    for op in prog.ops:
+        if op.type != 1:      # PP_OP_CONV
+            continue
+        elems = lambda b: prog.bufs[b][0] * prog.bufs[b][1] * prog.bufs[b][2]
+        act = elems(op.in_) + sum(elems(r) for r in (op.res1, op.res2) if r >= 0)
+        out = (prog.bufs[op.out][0] * prog.bufs[op.out][1]) * op.cout
+        total += 4 * (batch * (act + out) + op.kh * op.kw * op.cin * op.cout + op.cout)
+    return total
 
 
 class Dist:
@@ -251,6 +282,9 @@ def run_cascade(args, D):
     else:
         flops_conv = flops_step
     achieved = flops_conv / (conv_ms * 1e-3) / 1e12
+    traffic, traffic_note = pmc_traffic("cascade_chunk%d_persons%d" % (B, P))
+    alg_bytes = algorithmic_bytes(cas.detector.prog_a, B) + algorithmic_bytes(cas.detector.prog_b, B * cas.detector.MAX_ROIS) + \
+        (0 if vit else algorithmic_bytes(cas.pose_net.prog, 2 * B * P))
     out = {
         "metric": METRIC, "value": D.world * B * K / dt, "unit": "frames/s", "n_gpus": D.world, "steps": K,
         "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -265,7 +299,10 @@ def run_cascade(args, D):
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (%d launches per step: detector image + RoI-head programs, HRNet-W48)" % n_launch,
                      "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": pmc_traffic("cascade_chunk%d_persons%d" % (B, P)),
+                     "traffic": traffic, "traffic_source": traffic_note,
+                     "algorithmic_bytes": alg_bytes / n_launch,
+                     "algorithmic_bytes_note": "per launch: every conv operand (input, weights, bias, residuals) read once and "
+                                               "every output written once, float32; `traffic` / this = the re-read factor",
                      "flops_per_launch": flops_conv / n_launch, "avg_launch_ms": conv_ms / n_launch, "stage_ms": stage,
                      "launch_overlap": "programs run on 4 HIP streams; avg_launch_ms = wall time of the conv programs / launches "
                                        "(rocprof per-kernel durations overlap and sum to more)",
@@ -448,7 +485,8 @@ def run_c2(args, D):
                    "not_in_this_line": "detector, tracker, 3D lifting (see --workload cascade)"},
         "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (all %d conv launches of the backbone program)" % n_launch,
                      "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": pmc_traffic("c2_batch%d" % n), "flops_per_launch": flops_step / n_launch, "avg_launch_ms": net_ms / n_launch,
+                     "traffic": pmc_traffic("c2_batch%d" % n)[0], "algorithmic_bytes": algorithmic_bytes(prog, 2 * n) / n_launch,
+                     "flops_per_launch": flops_step / n_launch, "avg_launch_ms": net_ms / n_launch,
                      "stage_ms": {"pre": t_pre / args.steps, "backbone": net_ms, "decode": t_dec / args.steps}},
     }
     n_cpu = 6 if args.cpu_frames is None else args.cpu_frames
@@ -541,7 +579,7 @@ def run_c5(args, D):
                    "not_in_this_line": "detector, tracker, 3D lifting (see --workload cascade); ViTPose is not in the reference tree"},
         "roofline": {"bound": "mfma", "kernel": "gemm_bf16_kernel (%d launches per step: qkv / proj / fc1 / fc2 of %d blocks)" % (n_gemm.value, spec.depth),
                      "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / BF16_MFMA_PEAK_TFLOPS,
-                     "traffic": pmc_traffic("c5_batch%d" % n), "flops_per_launch": gemm_flops / max(n_gemm.value, 1),
+                     "traffic": pmc_traffic("c5_batch%d" % n)[0], "flops_per_launch": gemm_flops / max(n_gemm.value, 1),
                      "avg_launch_ms": float(ms3[0]) / max(n_gemm.value, 1),
                      "encoder_ms": {"gemm": float(ms3[0]), "layernorm": float(ms3[1]), "attention": float(ms3[2])},
                      "program_tflops": prog.flops * 2 * n / (net_ms * 1e-3) / 1e12,

@@ -31,9 +31,11 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 4   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
+#define PP_ABI_VERSION 5   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
                               3: PP_OP_VIT_ENCODER / PP_OP_DEPTH_TO_SPACE, bf16 building blocks, UDP top-down (post 2)
-                              4: pp_memcpy_d2d, pp_net_create_mem (weights already on the device, e.g. an RCCL broadcast) */
+                              4: pp_memcpy_d2d, pp_net_create_mem (weights already on the device, e.g. an RCCL broadcast)
+                              5: pp_buf.pad (zero halo of conv-only buffers), PP_OP_AVGPOOL, pp_crop_resize_bilinear,
+                                 pp_conv_force / pp_conv_variant */
 
 typedef enum {
     PP_OK = 0,
@@ -144,6 +146,12 @@ typedef struct pp_op {
 
 typedef struct pp_buf {
     int32_t h, w, c;          /* per-sample dims */
+    int32_t pad;              /* > 0: the buffer is stored [h + pad][w + pad][c] per sample with `pad` ZERO columns at the right of
+                                 every row and `pad` zero rows below every image (never written).  A padded 3x3 convolution
+                                 reading it needs no bounds test: a tap left of column 0 lands in the previous row's zero
+                                 columns, a tap above row 0 in the previous image's zero rows (or before the buffer, where the
+                                 buffer descriptor returns zeros).  Only PP_OP_CONV may touch a padded buffer; buffers that
+                                 pp_net_buffer / pp_net_forward expose must have pad = 0. */
 } pp_buf;
 
 /* weights: host pointer to the flat fp32 blob (copied to the device once).  max_batch fixes the

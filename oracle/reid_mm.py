@@ -40,6 +40,9 @@ def crop_rects(boxes, scale_factor, img_hw):
             x2 = x1 + 1
         if y2 == y1:
             y2 = y1 + 1
+        # entirely beyond the right / bottom edge: mmtrack's slice would be empty (and F.interpolate would raise); take the
+        # last pixel column / row -- the product does the same
+        x1, x2, y1, y2 = min(x1, w - 1), min(x2, w), min(y1, h - 1), min(y2, h)
         out.append((x1, y1, x2, y2))
     return np.array(out, np.int32).reshape(-1, 4)
 

@@ -56,7 +56,7 @@ class pp_op(C.Structure):
 
 
 class pp_buf(C.Structure):
-    _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32)]
+    _fields_ = [("h", C.c_int32), ("w", C.c_int32), ("c", C.c_int32), ("pad", C.c_int32)]   # pad: zero halo (ABI v5)
 
 
 _vp = C.c_void_p

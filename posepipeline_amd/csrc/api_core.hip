@@ -273,6 +273,13 @@ static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
     const int eh = op.pad_end & 1, ew = (op.pad_end >> 1) & 1;   // TensorFlow SAME: the odd padding row / column goes last
     PP_REQUIRE(op.out_c_off >= 0 && op.in_c_off >= 0 && (op.out_c_off & 3) == 0 && (op.in_c_off & 3) == 0,
                "op %d: channel offsets must be non-negative multiples of 4", idx);
+    if (op.type != PP_OP_CONV) {
+        for (int b : {op.in, op.out, op.res1, op.res2})
+            PP_REQUIRE(b < 0 || net.bufs[b].pad == 0, "op %d: only convolutions may touch a buffer with a zero halo (buffer %d)", idx, b);
+    } else {
+        PP_REQUIRE(bo.pad == 0 || (!op.out_nchw && op.out_c_off == 0 && bo.c == op.cout && (op.cout & 3) == 0),
+                   "op %d: a halo output buffer must be a plain NHWC tensor of the op's own channels", idx);
+    }
     if (op.type == PP_OP_CONV) {
         PP_REQUIRE(bi.c == op.cin && op.in_c_off == 0, "op %d: in buffer has %d channels, op.cin=%d", idx, bi.c, op.cin);
         PP_REQUIRE(op.out_c_off + op.cout <= bo.c && (op.out_c_off == 0 ? true : !op.out_nchw),
@@ -342,29 +349,39 @@ static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
     return PP_OK;
 }
 
+static ConvArgs net_conv_args(pp_net* net, const pp_op& op, int batch) {
+    const pp_buf& bi = net->bufs[op.in];
+    const pp_buf& bo = net->bufs[op.out];
+    ConvArgs a{};
+    a.x = net->buf_ptr(op.in);
+    a.y = net->buf_ptr(op.out);
+    a.w = net->weights + op.w_off;
+    a.bias = net->weights + op.b_off;
+    a.res1 = op.res1 >= 0 ? net->buf_ptr(op.res1) : nullptr;
+    a.res2 = op.res2 >= 0 ? net->buf_ptr(op.res2) : nullptr;
+    a.N = batch; a.Hin = bi.h; a.Win = bi.w; a.Cin = op.cin;
+    a.Hout = bo.h >> op.up_log2; a.Wout = bo.w >> op.up_log2;
+    a.Cout = op.cout; a.CoutPad = (op.cout + 15) / 16 * 16;
+    a.KH = op.kh; a.KW = op.kw; a.stride = op.stride; a.pad_h = op.pad_h; a.pad_w = op.pad_w;
+    a.dil_h = op.dil_h; a.dil_w = op.dil_w;
+    a.K = op.kh * op.kw * op.cin; a.Kpad = (a.K + 31) / 32 * 32;
+    a.HWout = a.Hout * a.Wout; a.M = batch * a.HWout;
+    a.relu = op.relu; a.up_log2 = op.up_log2; a.out_nchw = op.out_nchw;
+    a.res1_shift = op.res1_shift; a.res1_off_w = op.res1_off_w;
+    a.res1_H = op.res1 >= 0 ? net->bufs[op.res1].h : 0;
+    a.res1_W = op.res1 >= 0 ? net->bufs[op.res1].w : 0;
+    a.y_stride = bo.c; a.y_coff = op.out_c_off;
+    a.x_pad = bi.pad; a.y_pad = bo.pad;
+    a.r1_pad = op.res1 >= 0 ? net->bufs[op.res1].pad : 0;
+    a.r2_pad = op.res2 >= 0 ? net->bufs[op.res2].pad : 0;
+    return a;
+}
+
 static int net_launch_op(pp_net* net, const pp_op& op, int batch, hipStream_t s) {
     const pp_buf& bi = net->bufs[op.in];
     const pp_buf& bo = net->bufs[op.out];
     if (op.type == PP_OP_CONV) {
-        ConvArgs a{};
-        a.x = net->buf_ptr(op.in);
-        a.y = net->buf_ptr(op.out);
-        a.w = net->weights + op.w_off;
-        a.bias = net->weights + op.b_off;
-        a.res1 = op.res1 >= 0 ? net->buf_ptr(op.res1) : nullptr;
-        a.res2 = op.res2 >= 0 ? net->buf_ptr(op.res2) : nullptr;
-        a.N = batch; a.Hin = bi.h; a.Win = bi.w; a.Cin = op.cin;
-        a.Hout = bo.h >> op.up_log2; a.Wout = bo.w >> op.up_log2;
-        a.Cout = op.cout; a.CoutPad = (op.cout + 15) / 16 * 16;
-        a.KH = op.kh; a.KW = op.kw; a.stride = op.stride; a.pad_h = op.pad_h; a.pad_w = op.pad_w;
-        a.dil_h = op.dil_h; a.dil_w = op.dil_w;
-        a.K = op.kh * op.kw * op.cin; a.Kpad = (a.K + 31) / 32 * 32;
-        a.HWout = a.Hout * a.Wout; a.M = batch * a.HWout;
-        a.relu = op.relu; a.up_log2 = op.up_log2; a.out_nchw = op.out_nchw;
-        a.res1_shift = op.res1_shift; a.res1_off_w = op.res1_off_w;
-        a.res1_H = op.res1 >= 0 ? net->bufs[op.res1].h : 0;
-        a.res1_W = op.res1 >= 0 ? net->bufs[op.res1].w : 0;
-        a.y_stride = bo.c; a.y_coff = op.out_c_off;
+        const ConvArgs a = net_conv_args(net, op, batch);
         return pp_launch_conv(a, s);
     } else if (op.type == PP_OP_MAXPOOL) {
         PoolArgs p{};
@@ -425,8 +442,8 @@ int pp_net_create_mem(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bu
     net->n_weights = n_weights;
     size_t off = 0;
     for (int b = 0; b < n_bufs; ++b) {
-        PP_REQUIRE(bufs[b].h > 0 && bufs[b].w > 0 && bufs[b].c > 0, "buffer %d has an empty dim", b);
-        const size_t e = (size_t)bufs[b].h * bufs[b].w * bufs[b].c;
+        PP_REQUIRE(bufs[b].h > 0 && bufs[b].w > 0 && bufs[b].c > 0 && bufs[b].pad >= 0 && bufs[b].pad <= 8, "buffer %d has an empty dim / bad halo", b);
+        const size_t e = (size_t)(bufs[b].h + bufs[b].pad) * (bufs[b].w + bufs[b].pad) * bufs[b].c;   // halo: never written, stays zero
         net->buf_elems.push_back(e);
         net->buf_off.push_back(off);
         off += (e * max_batch + 63) / 64 * 64;   // 256-byte aligned
@@ -465,6 +482,12 @@ int pp_net_create_mem(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bu
         }
     }
     PP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    // per-geometry tables of the pipelined conv kernel: built here, never inside a launch that may be under graph capture
+    for (int i = 0; i < n_ops; ++i)
+        if (net->ops[i].type == PP_OP_CONV) {
+            int rc = pp_conv_prepare(net_conv_args(net.get(), net->ops[i], 1));
+            if (rc != PP_OK) return rc;
+        }
     const char* env_lanes = getenv("POSEPIPE_NET_LANES");
     const int n_lanes = env_lanes ? atoi(env_lanes) : 4;
     if (n_lanes > 1 && n_ops >= 8) {
@@ -504,6 +527,7 @@ void pp_net_destroy(pp_net* net) {
 
 int pp_net_buffer(pp_net* net, int buf, void** dptr, size_t* bytes_per_sample) {
     PP_REQUIRE(net && buf >= 0 && buf < (int)net->bufs.size(), "pp_net_buffer: bad buffer id");
+    PP_REQUIRE(net->bufs[buf].pad == 0, "pp_net_buffer: buffer %d has a zero halo (conv-internal layout); expose dense buffers only", buf);
     if (dptr) *dptr = net->buf_ptr(buf);
     if (bytes_per_sample) *bytes_per_sample = net->buf_elems[buf] * sizeof(float);
     return PP_OK;
@@ -598,6 +622,7 @@ int pp_net_forward(pp_net* net, int batch, int in_buf, const float* in, int out_
     PP_REQUIRE(in_buf >= 0 && in_buf < (int)net->bufs.size() && out_buf >= 0 && out_buf < (int)net->bufs.size(),
                "pp_net_forward: bad buffer id");
     PP_REQUIRE(batch > 0 && batch <= net->max_batch, "pp_net_forward: batch %d not in (0,%d]", batch, net->max_batch);
+    PP_REQUIRE(net->bufs[in_buf].pad == 0 && net->bufs[out_buf].pad == 0, "pp_net_forward: input / output buffers must be dense (pad 0)");
     hipStream_t s = net->ctx->stream;
     const hipMemcpyKind kin = mem == PP_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     const hipMemcpyKind kout = mem == PP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;

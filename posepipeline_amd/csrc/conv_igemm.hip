@@ -29,6 +29,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <map>
+#include <mutex>
+#include <vector>
 
 #include "pp_internal.h"
 
@@ -522,7 +524,8 @@ struct TuneTable {
             if (line[0] == '#' || sscanf(line, "%d %d %d %d %d %d %d %d %d %d %d", &k.cin, &k.cout, &k.kh, &k.kw, &k.stride, &k.dil_h,
                                          &k.dil_w, &c.m, &c.ct, &c.pt, &c.variant) < 10)
                 continue;
-            if (c.ct >= 1 && c.ct <= 4 && (c.pt == 1 || c.pt == 2) && c.m > 0) best[k].push_back(c);
+            if (c.ct >= 1 && c.ct <= 4 && (c.pt == 1 || c.pt == 2 || (c.pt == 4 && c.variant == 3 && c.ct >= 3)) && c.m > 0 && c.variant != 2)
+                best[k].push_back(c);
         }
         fclose(f);
         for (auto& kv : best) std::sort(kv.second.begin(), kv.second.end(), [](const Choice& x, const Choice& y) { return x.m < y.m; });
@@ -543,14 +546,58 @@ struct TuneTable {
         return pick;
     }
 };
+// ---- tap tables of the pipelined kernel (variant 3) ---------------------------------------------------------------------------
+struct TapKey {
+    int dev, cin, kh, kw, dil_h, dil_w, win, k;
+    bool operator<(const TapKey& o) const { return memcmp(this, &o, sizeof(TapKey)) < 0; }
+};
+std::mutex g_tap_mutex;
+std::map<TapKey, uint2*> g_tap_tables;
+
+const uint2* tap_table_for(const ConvArgs& a, bool create) {
+    TapKey key;
+    memset(&key, 0, sizeof(key));
+    if (hipGetDevice(&key.dev) != hipSuccess) return nullptr;
+    const int pitch = a.Win + a.x_pad;        // pixels per stored row
+    key.cin = a.Cin; key.kh = a.KH; key.kw = a.KW; key.dil_h = a.dil_h; key.dil_w = a.dil_w; key.win = pitch; key.k = a.K;
+    std::lock_guard<std::mutex> lock(g_tap_mutex);
+    auto it = g_tap_tables.find(key);
+    if (it != g_tap_tables.end()) return it->second;
+    if (!create) return nullptr;
+    const int nsteps = (a.K + 15) / 16;
+    std::vector<uint2> h((size_t)(nsteps + 1) * 4);            // + one spare step: the kernel prefetches one entry ahead
+    for (int s = 0; s <= nsteps; ++s)
+        for (int q = 0; q < 4; ++q) {
+            const int k = 16 * s + 4 * q;
+            // k >= K: a tap no pixel can satisfy (checked kernel) and an offset beyond any tensor < 2 GiB (unchecked kernel):
+            // either way the buffer load returns zeros
+            uint2 e = make_uint2(0x7fff7fffu, 0x80000000u);
+            if (k < a.K) {
+                const int tap = k / a.Cin, c = k - tap * a.Cin;
+                const int kh = tap / a.KW, kw = tap - kh * a.KW;
+                e.x = ((unsigned)(kh * a.dil_h) << 16) | (unsigned)(kw * a.dil_w);
+                e.y = (unsigned)(((kh * a.dil_h * pitch + kw * a.dil_w) * a.Cin + c) * 4);
+            }
+            h[(size_t)s * 4 + q] = e;
+        }
+    uint2* d = nullptr;
+    if (hipMalloc((void**)&d, h.size() * sizeof(uint2)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(uint2), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return nullptr;
+    }
+    g_tap_tables[key] = d;
+    return d;
+}
+
 int g_force_ct = 0, g_force_pt = 0;   // pp_conv_force (autotuner, A/B experiments)
 int g_variant = -1;                   // pp_conv_variant: -1 = default (env POSEPIPE_CONV_VARIANT, else table / built-in)
 
 }  // namespace
 
 extern "C" int pp_conv_variant(int variant) {
-    if (variant < -1 || variant > 1) {
-        pp_set_error("pp_conv_variant: -1 (default), 0 (two-barrier kernel) or 1 (three-stage pipelined kernel)");
+    if (variant < -1 || variant > 3) {      // 2: timing experiment with fake addresses (wrong results), tools/conv_probe.py only
+        pp_set_error("pp_conv_variant: -1 (default), 0 (two-barrier kernel), 1 (three-stage pipelined kernel) or 3 (pipelined + tap table)");
         return PP_ERR_ARG;
     }
     g_variant = variant;
@@ -558,8 +605,8 @@ extern "C" int pp_conv_variant(int variant) {
 }
 
 extern "C" int pp_conv_force(int ct, int pt) {
-    if (ct < 0 || ct > 4 || (pt != 0 && pt != 1 && pt != 2)) {
-        pp_set_error("pp_conv_force: ct in 0..4, pt in {0, 1, 2} (0 = automatic)");
+    if (ct < 0 || ct > 4 || (pt != 0 && pt != 1 && pt != 2 && pt != 4)) {
+        pp_set_error("pp_conv_force: ct in 0..4, pt in {0, 1, 2, 4} (0 = automatic; 4: variant 3 with ct >= 3 only)");
         return PP_ERR_ARG;
     }
     g_force_ct = ct;
@@ -579,8 +626,14 @@ static void magic_u32(unsigned d, unsigned* m, unsigned* s1, unsigned* s2) {
     *s2 = l > 0 ? l - 1 : 0;
 }
 
+int pp_conv_prepare(const ConvArgs& a) {
+    if (a.Cin % 4 != 0 || a.K <= 0) return PP_OK;
+    return tap_table_for(a, true) ? PP_OK : PP_ERR_HIP;
+}
+
 int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
     ConvArgs a = a_in;
+    a.tap_table = nullptr;
     magic_u32((unsigned)a.HWout, &a.div_hw_m, &a.div_hw_s1, &a.div_hw_s2);
     magic_u32((unsigned)a.Wout, &a.div_w_m, &a.div_w_s1, &a.div_w_s2);
     magic_u32((unsigned)a.Cin, &a.div_c_m, &a.div_c_s1, &a.div_c_s2);
@@ -598,7 +651,7 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
     if (a.M <= 0) return PP_OK;
     // The pixel loader addresses the input through one raw buffer descriptor (32-bit byte offsets, out-of-range
     // offsets read as zero), so one launch covers < 4 GiB of input: larger batches are cut into image ranges.
-    const size_t img_bytes = (size_t)a.Hin * a.Win * a.Cin * sizeof(float);
+    const size_t img_bytes = (size_t)(a.Hin + a.x_pad) * (a.Win + a.x_pad) * a.Cin * sizeof(float);
     static const size_t max_bytes_env = (size_t)env_int("POSEPIPE_CONV_MAX_MB", 0) << 20;   // test knob for the split below
     const size_t max_bytes = max_bytes_env ? max_bytes_env : 0xfffffff0u;
     if (img_bytes > max_bytes) {
@@ -607,9 +660,9 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
     }
     if ((size_t)a.N * img_bytes > max_bytes) {
         const int per = (int)(max_bytes / img_bytes);
-        const size_t y_img = (size_t)(a.Hout << a.up_log2) * (a.Wout << a.up_log2) * (a.y_stride ? a.y_stride : a.Cout);
-        const size_t r1_img = (size_t)a.res1_H * a.res1_W * a.Cout;
-        const size_t r2_img = (size_t)(a.Hout << a.up_log2) * (a.Wout << a.up_log2) * a.Cout;
+        const size_t y_img = (size_t)((a.Hout << a.up_log2) + a.y_pad) * ((a.Wout << a.up_log2) + a.y_pad) * (a.y_stride ? a.y_stride : a.Cout);
+        const size_t r1_img = (size_t)(a.res1_H + a.r1_pad) * (a.res1_W + a.r1_pad) * a.Cout;
+        const size_t r2_img = (size_t)((a.Hout << a.up_log2) + a.r2_pad) * ((a.Wout << a.up_log2) + a.r2_pad) * a.Cout;
         for (int n0 = 0; n0 < a.N; n0 += per) {
             ConvArgs p = a_in;
             p.N = std::min(per, a.N - n0);
@@ -669,7 +722,27 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
         if (pt_by_ct[best_ct] && (long)((a.M + 64 * pt_by_ct[best_ct] - 1) / (64 * pt_by_ct[best_ct])) * cblocks >= min_blocks)
             pt = pt_by_ct[best_ct];
     }
-    if (variant == 1) return pp_launch_conv_p3(a, best_ct, pt, stream);
+    a.no_bounds = a.wide_tile = 0;
+    const bool halo = (a.x_pad | a.y_pad | a.r1_pad | a.r2_pad) != 0;
+    if (halo) variant = 3;                   // only the pipelined tap-table kernel knows the halo layout
+    if (variant == 3) {
+        // every tap of every output stays inside the image or inside its zero halo (x_pad columns / rows at the right / below;
+        // left / top overshoot lands in the previous row's / image's halo)
+        a.no_bounds = a.pad_h <= a.x_pad && a.pad_w <= a.x_pad &&
+                      (a.Hout - 1) * a.stride - a.pad_h + (a.KH - 1) * a.dil_h <= a.Hin - 1 + a.x_pad &&
+                      (a.Wout - 1) * a.stride - a.pad_w + (a.KW - 1) * a.dil_w <= a.Win - 1 + a.x_pad && a.x_bytes < 0x7fffff00u;
+        a.tap_table = tap_table_for(a, true);
+        if (!a.tap_table) {
+            pp_set_error("conv: could not build the tap table");
+            return PP_ERR_HIP;
+        }
+        if (pt == 4) {
+            a.wide_tile = best_ct >= 3;
+            pt = 2;
+        }
+    }
+    if (pt == 4) pt = 2;
+    if (variant >= 1) return pp_launch_conv_p3(a, best_ct, pt, stream, variant == 2);
     switch (best_ct) {
         case 4: return launch_ct<4>(a, pt, stream);
         case 3: return launch_ct<3>(a, pt, stream);

@@ -62,8 +62,19 @@ __device__ __forceinline__ float activate(float x, int act) {
 }
 
 // WALK: Cin >= 16, so a 16-k step spans at most two kernel taps and the tap bookkeeping lives on the scalar unit.
-template <int CT, int PT, bool WALK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_p3_kernel(ConvArgs a) {
+// FAKE: timing experiment only (POSEPIPE_CONV_VARIANT=2): the tap walk is replaced by one add per load, so the results are
+// WRONG; the difference in speed is what the address arithmetic of the K loop costs.
+// TAB: the per-step tap bookkeeping comes from a table the launcher built once per layer geometry (ConvArgs::tap_table:
+// [step][k-quad] -> (packed (dh, dw) of the quad's tap or the never-in-range marker, byte offset of the quad from the pixel's
+// (hi0, wi0, channel 0))): one 8-byte load per lane and step, fetched one step ahead, replaces ~40 scalar and ~12 vector
+// instructions of the walk -- measured with the FAKE variant, that arithmetic was 6 % (K = 2304) to 14 % (K = 432 / 864) of
+// the kernel's time (profiles/r02_conv_probe.txt).
+// NOCHK (with TAB): convolutions without padding never leave the image, so the per-quad bounds test is dropped: the byte
+// offset is pixel base + table entry, one add per 16-byte load.  The only out-of-range cases left are rows past M and k past
+// K, and both are made out of range for the BUFFER descriptor instead (base / entry = 0x80000000, tensors < 2 GiB), where the
+// hardware returns zeros.  Covers every 1x1 layer, the RoI head's 7x7 'valid' fc6 / fc7 and VideoPose3D.
+template <int CT, int PT, bool WALK, bool FAKE, bool TAB, bool NOCHK>
+__device__ __forceinline__ void conv_p3_body(const ConvArgs& a) {
     constexpr int BC = 16 * CT;          // output channels per block
     constexpr int BP = 64 * PT;          // pixels per block (4 waves x PT x 16)
     constexpr int NQ = PT;               // pixel quads per thread and step (BP rows x 4 quads / 256 threads)
@@ -103,9 +114,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int ho = (int)udiv((unsigned)rem, a.div_w_m, a.div_w_s1, a.div_w_s2);
         const int wo = rem - ho * a.Wout;
         const int hi0 = ho * a.stride - a.pad_h, wi0 = wo * a.stride - a.pad_w;
-        pbase[i] = WALK ? (unsigned)(((n * a.Hin + hi0) * a.Win + wi0) * a.Cin) * 4u
+        pbase[i] = (WALK || TAB) ? (unsigned)(((n * (a.Hin + a.x_pad) + hi0) * (a.Win + a.x_pad) + wi0) * a.Cin) * 4u
                         : (unsigned)n * (unsigned)(a.Hin * a.Win * a.Cin);
         phw[i] = mok ? ((hi0 << 16) | (wi0 & 0xffff)) : (int)0x80000000;
+        if (NOCHK && !mok) pbase[i] = 0x80000000u;
     }
     // weights: blob rows are [32] floats per 32-k chunk in operand order (element 8 g + s <-> k = 4 s + g); the 16-k step
     // h of a chunk is the float4 at 8 g + 4 h of each row = exactly lane group g's four operands of that step
@@ -119,9 +131,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int kq16 = 16 * kq;
     const unsigned lim = ((unsigned)(a.Hin - 1) << 16) | (unsigned)(a.Win - 1);
 
+    // TAB: this lane's table entry of the step the next load_step call serves
+    const uint2* tap = TAB ? a.tap_table + kq : nullptr;
+    uint2 te = TAB ? tap[0] : make_uint2(0u, 0u);
+
     auto load_step = [&](int k0) {
         const bool kok = k0 + 4 * kq < a.K;
-        if constexpr (WALK) {
+        if constexpr (TAB && NOCHK) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+                xr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(pbase[i] + te.y), 0, 0));
+            tap += 4;
+            te = tap[0];
+        } else if constexpr (TAB) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                const u16x2 hw = __builtin_bit_cast(u16x2, __builtin_bit_cast(i16x2, phw[i]) + __builtin_bit_cast(i16x2, te.x));
+                const bool ok = __builtin_bit_cast(unsigned, __builtin_elementwise_max(hw, __builtin_bit_cast(u16x2, lim))) == lim;
+                const unsigned off = ok ? pbase[i] + te.y : 0xffffffffu;
+                xr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+            }
+            tap += 4;
+            te = tap[0];             // the table has one spare step past the end: no bounds test
+        } else if constexpr (FAKE) {
+#pragma unroll
+            for (int i = 0; i < NQ; ++i)
+                xr[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)(pbase[i] + (unsigned)k0 * 4u + kq16), 0, 0));
+        } else if constexpr (WALK) {
             int kw1 = kw0 + 1, kh1 = kh0;
             if (kw1 == a.KW) {
                 kw1 = 0;
@@ -278,6 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // consumes them: one memory round trip per phase instead of one per 16x16 tile.
         // Loads are batched PB pixel tiles at a time so the live set stays inside the main loop's register budget.
         constexpr int PB = (CT * PT <= 6) ? PT : 1;
+        const bool padded = (a.y_pad | a.r1_pad | a.r2_pad) != 0;      // halo buffers: pixel m is not at m * Cout any more
         bool cok[CT];
         int cos[CT];
         float4 b4[CT];
@@ -291,12 +328,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
         for (int p0 = 0; p0 < PT; p0 += PB) {
             bool mok[PB];
-            size_t moff[PB];
+            size_t moff[PB], r1off[PB], r2off[PB];
 #pragma unroll
             for (int pb = 0; pb < PB; ++pb) {
                 const int m = m0 + wave * (16 * PT) + (p0 + pb) * 16 + lcol;
                 mok[pb] = m < a.M;
-                moff[pb] = (size_t)(mok[pb] ? m : 0) * (size_t)a.Cout;
+                const unsigned mm = mok[pb] ? (unsigned)m : 0u;
+                moff[pb] = r1off[pb] = r2off[pb] = (size_t)mm * (size_t)a.Cout;
+                if (padded) {
+                    const int n = (int)udiv(mm, a.div_hw_m, a.div_hw_s1, a.div_hw_s2);
+                    const int rem = (int)mm - n * a.HWout;
+                    const int ho = (int)udiv((unsigned)rem, a.div_w_m, a.div_w_s1, a.div_w_s2);
+                    const int wo = rem - ho * a.Wout;
+                    auto at = [&](int pad) { return (((size_t)n * (a.Hout + pad) + ho) * (a.Wout + pad) + wo) * (size_t)a.Cout; };
+                    moff[pb] = at(a.y_pad);
+                    r1off[pb] = at(a.r1_pad);
+                    r2off[pb] = at(a.r2_pad);
+                }
             }
             float4 o[CT][PB];
             if (a.res1) {
@@ -304,7 +352,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb)
-                        o[ct][pb] = *reinterpret_cast<const float4*>(a.res1 + moff[pb] + cos[ct]);
+                        o[ct][pb] = *reinterpret_cast<const float4*>(a.res1 + r1off[pb] + cos[ct]);
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct)
@@ -322,7 +370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
                     for (int pb = 0; pb < PB; ++pb)
-                        r2[ct][pb] = *reinterpret_cast<const float4*>(a.res2 + moff[pb] + cos[ct]);
+                        r2[ct][pb] = *reinterpret_cast<const float4*>(a.res2 + r2off[pb] + cos[ct]);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
@@ -367,12 +415,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int dy = 0; dy < f; ++dy) {
                 for (int dx = 0; dx < f; ++dx) {
                     const int h2 = (ho << up) + dy, w2 = (wo << up) + dx;
-                    const size_t opix = ((size_t)n * Ho2 + h2) * Wo2 + w2;
+                    const size_t opix = ((size_t)n * (Ho2 + a.y_pad) + h2) * (Wo2 + a.y_pad) + w2;
                     float o[4] = {v[0], v[1], v[2], v[3]};
                     if (a.res1) {
-                        size_t rpix = opix;
+                        size_t rpix = ((size_t)n * (Ho2 + a.r1_pad) + h2) * (Wo2 + a.r1_pad) + w2;
                         if (!res1_plain) {
-                            rpix = ((size_t)n * a.res1_H + (h2 >> a.res1_shift)) * a.res1_W +
+                            rpix = ((size_t)n * (a.res1_H + a.r1_pad) + (h2 >> a.res1_shift)) * (a.res1_W + a.r1_pad) +
                                    (w2 >> a.res1_shift) + a.res1_off_w;
                         }
                         const float* rp = a.res1 + rpix * a.Cout + co;
@@ -386,7 +434,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         }
                     }
                     if (a.res2) {
-                        const float* rp = a.res2 + opix * a.Cout + co;
+                        const float* rp = a.res2 + (((size_t)n * (Ho2 + a.r2_pad) + h2) * (Wo2 + a.r2_pad) + w2) * a.Cout + co;
                         if (vec4) {
                             const float4 r4 = *reinterpret_cast<const float4*>(rp);
                             o[0] += r4.x; o[1] += r4.y; o[2] += r4.z; o[3] += r4.w;
@@ -420,9 +468,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// 128-pixel tiles and narrower: 4 workgroups per CU (128 registers per lane)
+template <int CT, int PT, bool WALK, bool FAKE = false, bool TAB = false, bool NOCHK = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_p3_kernel(ConvArgs a) {
+    conv_p3_body<CT, PT, WALK, FAKE, TAB, NOCHK>(a);
+}
+
+// 256-pixel tiles (PT = 4): a 64 x 64 register tile per wave -- 8 operand reads for 64 MFMAs instead of 6 for 32, half the
+// barriers and half the weight staging per FLOP -- at 2 workgroups per CU (60 KB of LDS stages, up to 256 registers).  The
+// software pipeline, not occupancy, hides the LDS and global latencies in this kernel.
+template <int CT, bool NOCHK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_p3_wide_kernel(ConvArgs a) {
+    conv_p3_body<CT, 4, true, false, true, NOCHK>(a);
+}
+
 template <int CT, int PT>
-int launch_t(const ConvArgs& a, hipStream_t stream) {
+int launch_t(const ConvArgs& a, hipStream_t stream, bool fake = false) {
     dim3 grid((a.M + 64 * PT - 1) / (64 * PT), (a.CoutPad + 16 * CT - 1) / (16 * CT));
+    if constexpr (PT == 2 && CT >= 3) {
+        if (a.tap_table && !fake && a.wide_tile) {
+            dim3 wgrid((a.M + 255) / 256, grid.y);
+            if (a.no_bounds)
+                hipLaunchKernelGGL((conv_p3_wide_kernel<CT, true>), wgrid, dim3(256), 0, stream, a);
+            else
+                hipLaunchKernelGGL((conv_p3_wide_kernel<CT, false>), wgrid, dim3(256), 0, stream, a);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) {
+                pp_set_error("conv_p3 (wide) launch failed: %s", hipGetErrorString(e));
+                return PP_ERR_HIP;
+            }
+            return PP_OK;
+        }
+    }
+    if (a.tap_table && !fake) {
+        if (a.no_bounds)
+            hipLaunchKernelGGL((conv_p3_kernel<CT, PT, true, false, true, true>), grid, dim3(256), 0, stream, a);
+        else
+            hipLaunchKernelGGL((conv_p3_kernel<CT, PT, true, false, true>), grid, dim3(256), 0, stream, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            pp_set_error("conv_p3 (table) launch failed: %s", hipGetErrorString(e));
+            return PP_ERR_HIP;
+        }
+        return PP_OK;
+    }
+    if constexpr (PT == 2 && CT >= 3) {
+        if (fake && a.Cin >= BK) {
+            hipLaunchKernelGGL((conv_p3_kernel<CT, PT, true, true>), grid, dim3(256), 0, stream, a);
+            return PP_OK;
+        }
+    }
     if (a.Cin >= BK)
         hipLaunchKernelGGL((conv_p3_kernel<CT, PT, true>), grid, dim3(256), 0, stream, a);
     else
@@ -438,11 +533,11 @@ int launch_t(const ConvArgs& a, hipStream_t stream) {
 }  // namespace
 
 // ct in 1..4, pt in {1, 2}: the pipelined kernel for one launch (arguments prepared by pp_launch_conv)
-int pp_launch_conv_p3(const ConvArgs& a, int ct, int pt, hipStream_t stream) {
+int pp_launch_conv_p3(const ConvArgs& a, int ct, int pt, hipStream_t stream, bool fake_addresses) {
     switch (ct * 2 + (pt >= 2 ? 1 : 0)) {
-        case 9: return launch_t<4, 2>(a, stream);
+        case 9: return launch_t<4, 2>(a, stream, fake_addresses);
         case 8: return launch_t<4, 1>(a, stream);
-        case 7: return launch_t<3, 2>(a, stream);
+        case 7: return launch_t<3, 2>(a, stream, fake_addresses);
         case 6: return launch_t<3, 1>(a, stream);
         case 5: return launch_t<2, 2>(a, stream);
         case 4: return launch_t<2, 1>(a, stream);

@@ -33,9 +33,8 @@ int det_enqueue_rpn(hipStream_t s, const DetRpnArgs& a, int n_frames);
 int det_enqueue_gather(hipStream_t s, const float* boxes, const float* scores, int max_n, const int32_t* keep,
                        const int32_t* n_keep, int limit, float* out_box, float* out_score, int32_t* n_out, int out5,
                        int n_frames);
-// order_scratch: [n_frames][max_rois] int32 work area for the locality order of the RoIs (may be null: launch order = index)
 int det_enqueue_roi_align(hipStream_t s, const DetFpnArgs& a, const float* rois, const int32_t* n_rois, int max_rois,
-                          float* out, int n_frames, int32_t* order_scratch);
+                          float* out, int n_frames);
 int det_enqueue_final_decode(hipStream_t s, const float* rois, const int32_t* n_rois, int max_rois, const float* cls,
                              const float* reg, float sfx, float sfy, float score_thr, float* boxes, float* scores,
                              int32_t* n_out, int n_frames);

@@ -361,58 +361,21 @@ __device__ __forceinline__ float4 bilinear4(const float* feat, int H, int W, int
     return o;
 }
 
-// Processing order of a frame's RoIs.  RoIs leave NMS in score order, i.e. spatially random: with 1000 blocks of one frame in
-// flight every XCD's 4 MB L2 saw the whole 45 MB P2 map and 58 % of the requests hit -- 24.7 GB of HBM fetches per launch
-// for 1.9 GB of feature maps (profiles/r02_roi_pmc.txt).  This kernel sorts the RoIs of each frame by (FPN level, Morton
-// code of the 64-pixel tile of their centre); roi_align_kernel then gives every XCD a CONTIGUOUS eighth of that order
-// (workgroup L runs on XCD L % 8), so an XCD works its way through one region of one level at a time.  Outputs are still
-// written at the RoI's own index: results are unchanged.
 __device__ __forceinline__ int roi_level(float x1, float y1, float x2, float y2) {
     const float scale = sqrtf((x2 - x1) * (y2 - y1));
     const int lvl = (int)floor(log2((double)(scale / 56.f + 1e-6f)));
     return min(max(lvl, 0), 3);
 }
 
-__global__ __launch_bounds__(1024) void roi_order_kernel(const float* __restrict__ rois, const int32_t* __restrict__ n_rois,
-                                                         int max_rois, int32_t* __restrict__ order) {
-    __shared__ unsigned key[1024];
-    const int f = blockIdx.x, t = threadIdx.x;
-    unsigned k = 0xffffffffu;
-    if (t < max_rois) {
-        k = 0xfff00000u | (unsigned)t;                       // unused slots: after every real RoI, each exactly once
-        if (t < n_rois[f]) {
-            const float* q = rois + ((size_t)f * max_rois + t) * 4;
-            const int lvl = roi_level(q[0], q[1], q[2], q[3]);
-            const unsigned tx = (unsigned)min(max((int)((q[0] + q[2]) * (0.5f / 64.f)), 0), 31);
-            const unsigned ty = (unsigned)min(max((int)((q[1] + q[3]) * (0.5f / 64.f)), 0), 31);
-            unsigned m = 0;
-            for (int b = 0; b < 5; ++b) m |= (((tx >> b) & 1u) << (2 * b)) | (((ty >> b) & 1u) << (2 * b + 1));
-            k = ((unsigned)lvl << 20) | (m << 10) | (unsigned)t;
-        }
-    }
-    key[t] = k;
-    __syncthreads();
-    for (int size = 2; size <= 1024; size <<= 1)
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const int p = t ^ stride;
-            if (p > t) {
-                const unsigned a = key[t], b = key[p];
-                const bool up = (t & size) == 0;
-                if ((a > b) == up) { key[t] = b; key[p] = a; }
-            }
-            __syncthreads();
-        }
-    if (t < max_rois) order[(size_t)f * max_rois + t] = (int32_t)(key[t] & 1023u);
-}
-
+// (Round 2 measured a locality order for the RoIs -- sorted by FPN level and Morton code of their centre, dealt out to the
+// XCDs in contiguous eighths or in runs of 25: 6.1 - 7.1 ms against 5.5 ms for the score order NMS leaves them in.  L2 hit
+// rate was not what bounds this kernel: with 58 % hits it already moves 63 GB through the L2s per launch (11 TB/s), and
+// concentrating the requests on one region makes them collide on the same L2 channels.  profiles/r02_roi_pmc.txt.)
 __global__ __launch_bounds__(256) void roi_align_kernel(FpnLevels L, int C, const float* __restrict__ rois,
-                                                        const int32_t* __restrict__ n_rois, int max_rois,
-                                                        const int32_t* __restrict__ order, float* __restrict__ out) {
+                                                        const int32_t* __restrict__ n_rois, int max_rois, float* __restrict__ out) {
     // grid (max_rois, frames), block 256 = 4 waves x (C/4 = 64 lanes); out [frame*max_rois + r][7][7][C]
     const int f = blockIdx.y;
-    int pos = blockIdx.x;
-    if ((max_rois & 7) == 0) pos = (pos & 7) * (max_rois >> 3) + (pos >> 3);      // XCD x: positions [x n/8, (x+1) n/8) of the order
-    const int r = order ? order[(size_t)f * max_rois + pos] : pos;
+    const int r = blockIdx.x;
     float* o = out + ((size_t)f * max_rois + r) * 49 * C;
     if (r >= n_rois[f]) {
         for (int i = threadIdx.x; i < 49 * C / 4; i += blockDim.x)
@@ -435,48 +398,14 @@ __global__ __launch_bounds__(256) void roi_align_kernel(FpnLevels L, int C, cons
     for (int bin = wv; bin < 49; bin += 4) {
         const int ph = bin / 7, pw = bin - ph * 7;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (keeping the previous sample's two tap columns in registers -- consecutive samples are <= 1 px apart -- was measured
+        // twice, rounds 1 and 2: the selects cost more than the loads they save, 5.5 -> 7.3 ms; the loads hit L1 / L2 anyway)
         for (int iy = 0; iy < gh; ++iy) {
-            float y = (y1 + (float)ph * bh) + (((float)iy + 0.5f) * bh) / (float)gh;
-            // the row part of `bilinear4` (same tests, same clamps), hoisted out of the sample loop
-            const bool y_in = !(y < -1.0f || y > (float)H);
-            if (y <= 0.f) y = 0.f;
-            int y_low = (int)y, y_high;
-            if (y_low >= H - 1) { y_high = y_low = H - 1; y = (float)y_low; } else y_high = y_low + 1;
-            const float ly = y - (float)y_low, hy = 1.f - ly;
-            const float* row_lo = feat + (size_t)y_low * W * C;
-            const float* row_hi = feat + (size_t)y_high * W * C;
-            // consecutive samples of a row are <= 1 px apart: their taps are the same two columns or share one.  The two
-            // columns of the previous sample stay in registers (values identical to a reload: bit-identical results)
-            int ca = -1, cb = -1;
-            float4 a_lo = make_float4(0.f, 0.f, 0.f, 0.f), a_hi = a_lo, b_lo = a_lo, b_hi = a_lo;
+            const float y = (y1 + (float)ph * bh) + (((float)iy + 0.5f) * bh) / (float)gh;
             for (int ix = 0; ix < gw; ++ix) {
-                float x = (x1 + (float)pw * bw) + (((float)ix + 0.5f) * bw) / (float)gw;
-                if (!y_in || x < -1.0f || x > (float)W) continue;            // bilinear4 returns 0: acc + 0 == acc
-                if (x <= 0.f) x = 0.f;
-                int x_low = (int)x, x_high;
-                if (x_low >= W - 1) { x_high = x_low = W - 1; x = (float)x_low; } else x_high = x_low + 1;
-                const float lx = x - (float)x_low, hx = 1.f - lx;
-                const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-                float4 v1, v2, v3, v4;
-                if (x_low == ca) { v1 = a_lo; v3 = a_hi; }
-                else if (x_low == cb) { v1 = b_lo; v3 = b_hi; }
-                else {
-                    v1 = *reinterpret_cast<const float4*>(row_lo + (size_t)x_low * C);
-                    v3 = *reinterpret_cast<const float4*>(row_hi + (size_t)x_low * C);
-                }
-                if (x_high == x_low) { v2 = v1; v4 = v3; }
-                else if (x_high == cb) { v2 = b_lo; v4 = b_hi; }
-                else if (x_high == ca) { v2 = a_lo; v4 = a_hi; }
-                else {
-                    v2 = *reinterpret_cast<const float4*>(row_lo + (size_t)x_high * C);
-                    v4 = *reinterpret_cast<const float4*>(row_hi + (size_t)x_high * C);
-                }
-                ca = x_low; a_lo = v1; a_hi = v3;
-                cb = x_high; b_lo = v2; b_hi = v4;
-                acc.x += ((w1 * v1.x + w2 * v2.x) + w3 * v3.x) + w4 * v4.x;
-                acc.y += ((w1 * v1.y + w2 * v2.y) + w3 * v3.y) + w4 * v4.y;
-                acc.z += ((w1 * v1.z + w2 * v2.z) + w3 * v3.z) + w4 * v4.z;
-                acc.w += ((w1 * v1.w + w2 * v2.w) + w3 * v3.w) + w4 * v4.w;
+                const float x = (x1 + (float)pw * bw) + (((float)ix + 0.5f) * bw) / (float)gw;
+                const float4 v = bilinear4(feat, H, W, C, 0, y, x);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
         }
         *reinterpret_cast<float4*>(o + bin * C + c) = make_float4(acc.x / count, acc.y / count, acc.z / count, acc.w / count);
@@ -596,19 +525,13 @@ int det_enqueue_gather(hipStream_t s, const float* boxes, const float* scores, i
 }
 
 int det_enqueue_roi_align(hipStream_t s, const DetFpnArgs& a, const float* rois, const int32_t* n_rois, int max_rois,
-                          float* out, int n_frames, int32_t* order_scratch) {
+                          float* out, int n_frames) {
     PP_REQUIRE(a.c == 256, "roi_align: C=%d (kernel launches one thread per channel, C must be 256)", a.c);
     FpnLevels L;
     for (int l = 0; l < 4; ++l) {
         L.feat[l] = a.feat[l]; L.h[l] = a.h[l]; L.w[l] = a.w[l]; L.stride[l] = a.stride[l];
     }
-    static const bool sorted = !getenv("POSEPIPE_ROI_UNSORTED");      // A/B knob: the score-ordered launch of round 1
-    const int32_t* order = nullptr;
-    if (sorted && order_scratch && max_rois <= 1024) {
-        hipLaunchKernelGGL(roi_order_kernel, dim3(n_frames), dim3(1024), 0, s, rois, n_rois, max_rois, order_scratch);
-        order = order_scratch;
-    }
-    hipLaunchKernelGGL(roi_align_kernel, dim3(max_rois, n_frames), dim3(a.c), 0, s, L, a.c, rois, n_rois, max_rois, order, out);
+    hipLaunchKernelGGL(roi_align_kernel, dim3(max_rois, n_frames), dim3(a.c), 0, s, L, a.c, rois, n_rois, max_rois, out);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }

@@ -77,11 +77,19 @@ struct ConvArgs {
     int relu, up_log2, out_nchw;
     int res1_shift, res1_off_w, res1_H, res1_W;
     int y_stride, y_coff;   // channels per pixel of the out buffer, first channel written (0 / 0: y_stride = Cout)
+    // variant 3 (conv_igemm_p3.hip, TAB): per (16-k step, k-quad) {packed tap (dh << 16 | dw) or 0x7fff7fff, byte offset} on the
+    // device, built once per layer geometry by pp_launch_conv; null: the kernel walks the taps itself
+    const uint2* tap_table;
+    int x_pad, y_pad, r1_pad, r2_pad;   // zero halo (right columns / bottom rows) of the input, output and residual buffers (pp_buf.pad)
+    int wide_tile;          // set by pp_launch_conv (pt = 4): 256-pixel tiles, 2 workgroups per CU
+    int no_bounds;          // set by pp_launch_conv: no tap can leave the image (no padding) and the tensor is < 2 GiB
 };
+// builds (and caches per device) the tap tables the pipelined kernel may use for this geometry; call outside graph capture
+int pp_conv_prepare(const ConvArgs& a);
 int pp_conv_out_dim(int in, int k, int stride, int pad, int dil);
 int pp_launch_conv(const ConvArgs& a, hipStream_t stream);
 // software-pipelined variant (conv_igemm_p3.hip): same results; `a` as prepared by pp_launch_conv
-int pp_launch_conv_p3(const ConvArgs& a, int ct, int pt, hipStream_t stream);
+int pp_launch_conv_p3(const ConvArgs& a, int ct, int pt, hipStream_t stream, bool fake_addresses = false);
 
 struct PoolArgs {
     const float* x;

@@ -60,6 +60,10 @@ def crop_rects(boxes_xyxy, scale_factor, img_hw):
     r = b.astype(np.int32)                                    # map(int, bbox): truncation
     r[:, 2] = np.where(r[:, 2] == r[:, 0], r[:, 0] + 1, r[:, 2])
     r[:, 3] = np.where(r[:, 3] == r[:, 1], r[:, 1] + 1, r[:, 3])
+    # a box entirely beyond the right / bottom edge clamps to (w, w + 1): mmtrack would slice an EMPTY crop there and fail in
+    # F.interpolate; here (and in the oracle) such a box takes the last pixel column / row instead
+    r[:, 0], r[:, 2] = np.minimum(r[:, 0], w - 1), np.minimum(r[:, 2], w)
+    r[:, 1], r[:, 3] = np.minimum(r[:, 1], h - 1), np.minimum(r[:, 3], h)
     return r
 
 

@@ -65,6 +65,7 @@ class Program:
     bufs: list                      # physical (h, w, c)
     blob: np.ndarray
     named: dict = field(default_factory=dict)   # name -> physical buffer id
+    buf_pad: list = field(default_factory=list)   # physical zero halo per buffer (pp_buf.pad), [] = all dense
     flops: float = 0.0              # algorithmic FLOPs per sample (2 * MACs of the real, unpadded convs)
     op_flops: list = field(default_factory=list)
     op_names: list = field(default_factory=list)
@@ -245,6 +246,39 @@ class ProgramBuilder:
         return self.depth_to_space(wide, name=name + ".d2s")
 
     # ---- finalize ----------------------------------------------------------------------------
+    def _halo_plan(self):
+        """Zero halo (pp_buf.pad) per virtual buffer.  A buffer that only convolutions touch and that a PADDED convolution reads
+        is stored with `pad` zero columns / rows at the right / bottom of every row / image: the reader's taps then never
+        need a bounds test (the largest share of the K loop's vector instructions, profiles/r02_conv_probe.txt).  Named
+        (pinned) buffers stay dense: other kernels and the host see them.  POSEPIPE_CONV_HALO=0 turns the layout off."""
+        import os
+        n_v = len(self.vbufs)
+        pad = [0] * n_v
+        if os.environ.get("POSEPIPE_CONV_HALO", "1") == "0":
+            return pad
+        ok = [not b.pinned and b.c % 4 == 0 for b in self.vbufs]
+        need = [0] * n_v
+        for op in self.vops:
+            conv = op["type"] == L.PP_OP_CONV
+            for k in ("in_", "out", "res1", "res2"):
+                v = op[k]
+                if v >= 0 and not conv:
+                    ok[v] = False
+            if not conv:
+                continue
+            o = op["out"]
+            if op["out_nchw"] or op["out_c_off"] or self.vbufs[o].c != op["cout"]:
+                ok[o] = False                       # channel slices / NCHW planes: dense
+            h, w, _ = self.dims(op["in_"])
+            eh, ew = op["pad_end"] & 1, (op["pad_end"] >> 1) & 1
+            ho = (h + eh + 2 * op["pad_h"] - op["dil_h"] * (op["kh"] - 1) - 1) // op["stride"] + 1 - ((op["pad_end"] >> 2) & 1)
+            wo = (w + ew + 2 * op["pad_w"] - op["dil_w"] * (op["kw"] - 1) - 1) // op["stride"] + 1 - ((op["pad_end"] >> 3) & 1)
+            over = max(op["pad_h"], op["pad_w"], (ho - 1) * op["stride"] - op["pad_h"] + (op["kh"] - 1) * op["dil_h"] - (h - 1),
+                       (wo - 1) * op["stride"] - op["pad_w"] + (op["kw"] - 1) * op["dil_w"] - (w - 1))
+            if over > 0:
+                need[op["in_"]] = max(need[op["in_"]], over)
+        return [need[v] if ok[v] and 0 < need[v] <= 2 else 0 for v in range(n_v)]
+
     def build(self) -> Program:
         n_v = len(self.vbufs)
         last_use = [-1] * n_v
@@ -256,18 +290,21 @@ class ProgramBuilder:
                     last_use[v] = i
             if first_def[op["out"]] is None:
                 first_def[op["out"]] = i
+        vpad = self._halo_plan()
         phys_dims: list[tuple] = []
+        phys_pad: list[int] = []
         free: dict[tuple, list[int]] = {}
         v2p = [-1] * n_v
         # pinned buffers (inputs, named outputs) first, never recycled
         for v, b in enumerate(self.vbufs):
             if b.pinned:
                 phys_dims.append((b.h, b.w, b.c))
+                phys_pad.append(0)
                 v2p[v] = len(phys_dims) - 1
         for i, op in enumerate(self.vops):
             v = op["out"]
             if v2p[v] < 0:
-                key = self.dims(v)
+                key = self.dims(v) + (vpad[v],)
                 pool = free.get(key, [])
                 # never alias an operand of this very op
                 busy = {v2p[op[k]] for k in ("in_", "res1", "res2") if op[k] >= 0}
@@ -276,13 +313,14 @@ class ProgramBuilder:
                     pool.remove(pick)
                     v2p[v] = pick
                 else:
-                    phys_dims.append(key)
+                    phys_dims.append(key[:3])
+                    phys_pad.append(vpad[v])
                     v2p[v] = len(phys_dims) - 1
             # release operands whose last use is this op
             for key in ("in_", "res1", "res2", "out"):
                 u = op[key]
                 if u >= 0 and last_use[u] == i and not self.vbufs[u].pinned and v2p[u] >= 0:
-                    lst = free.setdefault(self.dims(u), [])
+                    lst = free.setdefault(self.dims(u) + (vpad[u],), [])
                     if v2p[u] not in lst:
                         lst.append(v2p[u])
         ops = []
@@ -297,7 +335,7 @@ class ProgramBuilder:
             ops.append(rec)
         blob = np.concatenate(self.blob_parts) if self.blob_parts else np.zeros(4, np.float32)
         named = {k: v2p[v] for k, v in self.named.items()}
-        return Program(ops=ops, bufs=phys_dims, blob=blob, named=named,
+        return Program(ops=ops, bufs=phys_dims, buf_pad=phys_pad, blob=blob, named=named,
                        flops=float(sum(op["flops"] for op in self.vops)),
                        op_flops=[op["flops"] for op in self.vops], op_names=[op["name"] for op in self.vops])
 
@@ -314,7 +352,8 @@ class Net:
         lib = ctx.lib
         n_ops = len(prog.ops)
         ops = (L.pp_op * n_ops)(*prog.ops)
-        bufs = (L.pp_buf * len(prog.bufs))(*[L.pp_buf(*d) for d in prog.bufs])
+        pads = prog.buf_pad or [0] * len(prog.bufs)
+        bufs = (L.pp_buf * len(prog.bufs))(*[L.pp_buf(*d, p) for d, p in zip(prog.bufs, pads)])
         h = C.c_void_p()
         if blob_dev is not None:
             dptr, n_floats = blob_dev

@@ -42,7 +42,6 @@ def _detector(src_h, src_w, device=0, method="deepsort"):
         if method == "bytetrack":
             from ..models import yolox
             # init_cfg of mot/bytetrack/*-private-half.py:16-20: the COCO YOLOX-X checkpoint of mmdetection
-            import os
             rel = "mmtracking/checkpoints/yolox_x_8x8_300e_coco_20211126_140254-1ef88d67.pth"
             sd = weights.get_state_dict(rel, yolox.yolox_param_shapes(), seed=6)
             if not os.path.exists(os.path.join(weights.model_data_dir(), rel)):

@@ -32,14 +32,14 @@ def test_binding_table_matches_header():
     assert bound <= names, f"bound but not declared: {sorted(bound - names)}"
     # everything the Python host side binds must load
     _lib.load_library()
-    assert _lib.load_library().pp_abi_version() == 4
+    assert _lib.load_library().pp_abi_version() == 5
 
 
 def test_struct_layout_matches_header():
     # pp_op (ABI v2): 22 int32 + 2 int64
     assert ctypes.sizeof(_lib.pp_op) == 104
     assert _lib.pp_op.w_off.offset == 88 and _lib.pp_op.b_off.offset == 96
-    assert ctypes.sizeof(_lib.pp_buf) == 12
+    assert ctypes.sizeof(_lib.pp_buf) == 16            # h, w, c, pad (ABI v5)
 
 
 def test_no_gpu_means_loud_failure():

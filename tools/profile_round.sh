@@ -1,26 +1,27 @@
+# Regenerates the evidence under profiles/ (run on a GPU box: bash tools/profile_round.sh; results in gpurun_out/prof/, copy the
+# small files to profiles/rNN_*).  Counters are collected in their own rocprofv3 passes (--kernel-trace only).
 set -x
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $O/bench_cascade.json 2> $O/bench_cascade.err
 python $R/bench.py --workload c2 > $O/bench_c2.json 2> $O/bench_c2.err
+python $R/bench.py --mode shard --steps 6 --warmup 2 > $O/bench_shard.json 2> $O/bench_shard.err
+python $R/bench.py --persons 4 --steps 6 --warmup 2 --cpu-frames 0 > $O/bench_cascade_p4.json 2> $O/bench_cascade_p4.err
 cd $R
 POSEPIPE_NET_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -- python bench.py --steps 5 --warmup 1 --cpu-frames 0 > $O/serial.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes4 -- python bench.py --steps 5 --warmup 1 --cpu-frames 0 > $O/lanes4.log 2>&1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c2 -- python bench.py --workload c2 --steps 5 --warmup 1 --cpu-frames 0 > $O/c2.log 2>&1
+cp $(ls -t $(find $O/serial -name "*kernel_stats.csv") | head -1) $O/cascade_serial_kernel_stats.csv
+cp $(ls -t $(find $O/lanes4 -name "*kernel_stats.csv") | head -1) $O/cascade_lanes4_kernel_stats.csv
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 2 --warmup 1 --cpu-frames 0 > $O/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 2 --warmup 1 --cpu-frames 0 > $O/pmc_write.log 2>&1
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 375 "cascade chunk 32, 1 person" > $O/pmc_summary.txt 2>&1
+python tools/pmc_traffic_update.py cascade_chunk32_persons1 $O/pmc_summary.txt "tools/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over python bench.py --steps 2 --warmup 1 (FETCH_SIZE x2, gfx950)" $O/pmc_traffic.json
+bash tools/pmc_sq.sh > $O/pmc_sq.log 2>&1; cp gpurun_out/pmc_sq/summary.txt $O/cascade_pmc_sq.txt
+bash tools/pmc_kernel.sh roi_align_kernel roi python bench.py --steps 1 --warmup 1 --cpu-frames 0 > $O/roi_pmc.log 2>&1; cp gpurun_out/pmc_roi/summary.txt $O/roi_pmc.txt
+for w in "w48 64" "det 32" "w32 128"; do set -- $w; python tools/profile_net.py $1 $2 > $O/per_op_$1_b$2.txt 2>&1; done
 # keep only the small files
-find $O -name "*kernel_trace.csv" -delete
-find $O -name "*counter_collection.csv" -delete
-find $O -name "*agent_info.csv" -delete
-du -sh $O; ls -R $O | head -40; cat $O/pmc_summary.txt; tail -2 $O/bench_cascade.json | cut -c1-200
-# ---- ViTPose-H (configs[4]): bench lines, kernel stats and GEMM counters -> gpurun_out/prof/c5_*, gpurun_out/pmc_c5gemm/
-python $R/bench.py --workload c5 > $O/bench_c5.json 2> $O/bench_c5.err
-python $R/bench.py --workload cascade5 > $O/bench_cascade5.json 2> $O/bench_cascade5.err
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -- python bench.py --workload c5 --steps 5 --warmup 1 --cpu-frames 0 > $O/c5.log 2>&1
-cp $(ls -t $(find $O/c5 -name "*kernel_stats.csv") | head -1) $O/c5_kernel_stats.csv
-find $O/c5 -name "*.csv" -delete
-bash tools/pmc_kernel.sh "gemm_bf16_kernel<4, 4, 4, 4, 2, 64>" c5gemm python bench.py --workload c5 --steps 2 --warmup 1 --cpu-frames 0 | tail -12
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*agent_info.csv" -delete
+rm -rf $O/serial $O/lanes4 $O/pmc_fetch $O/pmc_write
+du -sh $O; ls $O; cat $O/pmc_summary.txt; cut -c1-300 $O/bench_cascade.json
