@@ -524,8 +524,7 @@ struct TuneTable {
             if (line[0] == '#' || sscanf(line, "%d %d %d %d %d %d %d %d %d %d %d", &k.cin, &k.cout, &k.kh, &k.kw, &k.stride, &k.dil_h,
                                          &k.dil_w, &c.m, &c.ct, &c.pt, &c.variant) < 10)
                 continue;
-            if (c.ct >= 1 && c.ct <= 4 && (c.pt == 1 || c.pt == 2 || (c.pt == 4 && c.variant == 3 && c.ct >= 3)) && c.m > 0 && c.variant != 2)
-                best[k].push_back(c);
+            if (c.ct >= 1 && c.ct <= 4 && (c.pt == 1 || c.pt == 2) && c.m > 0 && c.variant != 2) best[k].push_back(c);
         }
         fclose(f);
         for (auto& kv : best) std::sort(kv.second.begin(), kv.second.end(), [](const Choice& x, const Choice& y) { return x.m < y.m; });
@@ -605,8 +604,8 @@ extern "C" int pp_conv_variant(int variant) {
 }
 
 extern "C" int pp_conv_force(int ct, int pt) {
-    if (ct < 0 || ct > 4 || (pt != 0 && pt != 1 && pt != 2 && pt != 4)) {
-        pp_set_error("pp_conv_force: ct in 0..4, pt in {0, 1, 2, 4} (0 = automatic; 4: variant 3 with ct >= 3 only)");
+    if (ct < 0 || ct > 4 || (pt != 0 && pt != 1 && pt != 2)) {
+        pp_set_error("pp_conv_force: ct in 0..4, pt in {0, 1, 2} (0 = automatic)");
         return PP_ERR_ARG;
     }
     g_force_ct = ct;
@@ -722,7 +721,7 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
         if (pt_by_ct[best_ct] && (long)((a.M + 64 * pt_by_ct[best_ct] - 1) / (64 * pt_by_ct[best_ct])) * cblocks >= min_blocks)
             pt = pt_by_ct[best_ct];
     }
-    a.no_bounds = a.wide_tile = 0;
+    a.no_bounds = 0;
     const bool halo = (a.x_pad | a.y_pad | a.r1_pad | a.r2_pad) != 0;
     if (halo) variant = 3;                   // only the pipelined tap-table kernel knows the halo layout
     if (variant == 3) {
@@ -736,12 +735,7 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
             pp_set_error("conv: could not build the tap table");
             return PP_ERR_HIP;
         }
-        if (pt == 4) {
-            a.wide_tile = best_ct >= 3;
-            pt = 2;
-        }
     }
-    if (pt == 4) pt = 2;
     if (variant >= 1) return pp_launch_conv_p3(a, best_ct, pt, stream, variant == 2);
     switch (best_ct) {
         case 4: return launch_ct<4>(a, pt, stream);

@@ -474,32 +474,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     conv_p3_body<CT, PT, WALK, FAKE, TAB, NOCHK>(a);
 }
 
-// 256-pixel tiles (PT = 4): a 64 x 64 register tile per wave -- 8 operand reads for 64 MFMAs instead of 6 for 32, half the
-// barriers and half the weight staging per FLOP -- at 2 workgroups per CU (60 KB of LDS stages, up to 256 registers).  The
-// software pipeline, not occupancy, hides the LDS and global latencies in this kernel.
-template <int CT, bool NOCHK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_p3_wide_kernel(ConvArgs a) {
-    conv_p3_body<CT, 4, true, false, true, NOCHK>(a);
-}
-
 template <int CT, int PT>
 int launch_t(const ConvArgs& a, hipStream_t stream, bool fake = false) {
     dim3 grid((a.M + 64 * PT - 1) / (64 * PT), (a.CoutPad + 16 * CT - 1) / (16 * CT));
-    if constexpr (PT == 2 && CT >= 3) {
-        if (a.tap_table && !fake && a.wide_tile) {
-            dim3 wgrid((a.M + 255) / 256, grid.y);
-            if (a.no_bounds)
-                hipLaunchKernelGGL((conv_p3_wide_kernel<CT, true>), wgrid, dim3(256), 0, stream, a);
-            else
-                hipLaunchKernelGGL((conv_p3_wide_kernel<CT, false>), wgrid, dim3(256), 0, stream, a);
-            hipError_t e = hipGetLastError();
-            if (e != hipSuccess) {
-                pp_set_error("conv_p3 (wide) launch failed: %s", hipGetErrorString(e));
-                return PP_ERR_HIP;
-            }
-            return PP_OK;
-        }
-    }
     if (a.tap_table && !fake) {
         if (a.no_bounds)
             hipLaunchKernelGGL((conv_p3_kernel<CT, PT, true, false, true, true>), grid, dim3(256), 0, stream, a);

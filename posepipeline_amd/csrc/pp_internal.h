@@ -81,7 +81,6 @@ struct ConvArgs {
     // device, built once per layer geometry by pp_launch_conv; null: the kernel walks the taps itself
     const uint2* tap_table;
     int x_pad, y_pad, r1_pad, r2_pad;   // zero halo (right columns / bottom rows) of the input, output and residual buffers (pp_buf.pad)
-    int wide_tile;          // set by pp_launch_conv (pt = 4): 256-pixel tiles, 2 workgroups per CU
     int no_bounds;          // set by pp_launch_conv: no tap can leave the image (no padding) and the tensor is < 2 GiB
 };
 // builds (and caches per device) the tap tables the pipelined kernel may use for this geometry; call outside graph capture

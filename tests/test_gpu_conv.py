@@ -64,7 +64,7 @@ def test_conv_every_tile_configuration(ctx, case, variant):
     kw = dict(stride=stride, pad=(0 if h == 1 else pad, pad), dil=(1, dil))
     ref = ref_conv_op(x, wt, b, **kw)
     for ct in (1, 2, 3, 4):
-        for pt in (1, 2) + ((4,) if variant == 3 and ct >= 3 else ()):       # 256-pixel tiles: tap-table kernel only
+        for pt in (1, 2):
             L.check(ctx.lib.pp_conv_force(ct, pt), "pp_conv_force")
             assert np.array_equal(hip_conv_op(ctx, x, wt, b, **kw), ref), (ct, pt)
 
