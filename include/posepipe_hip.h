@@ -31,11 +31,13 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 5   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
+#define PP_ABI_VERSION 6   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
                               3: PP_OP_VIT_ENCODER / PP_OP_DEPTH_TO_SPACE, bf16 building blocks, UDP top-down (post 2)
                               4: pp_memcpy_d2d, pp_net_create_mem (weights already on the device, e.g. an RCCL broadcast)
                               5: pp_buf.pad (zero halo of conv-only buffers), PP_OP_AVGPOOL, pp_crop_resize_bilinear,
-                                 pp_conv_force / pp_conv_variant */
+                                 pp_conv_force / pp_conv_variant
+                              6: pp_conv_exact; pp_conv_variant accepts 4 (fp32 convolutions on the bf16 matrix cores by a
+                                 three-way operand split are the default where a layer is eligible) */
 
 typedef enum {
     PP_OK = 0,
@@ -185,8 +187,19 @@ int pp_net_profile(pp_net* net, int batch, float* ms_per_op);
  * Results do not depend on it; tools/autotune_conv.py uses it to measure every configuration per layer. */
 int pp_conv_force(int ct, int pt);
 /* Kernel variant for all later launches: 0 = two-barrier K step (conv_igemm.hip), 1 = three-stage software pipeline
- * (conv_igemm_p3.hip), -1 = default (tuning table / POSEPIPE_CONV_VARIANT).  Bit-identical results. */
+ * (conv_igemm_p3.hip), 3 = 1 with per-geometry tap tables, 4 = the split kernel below where eligible,
+ * -1 = default (POSEPIPE_CONV_VARIANT, else: the split kernel where eligible, 0 / 3 elsewhere).
+ * 0, 1 and 3 give bit-identical results (the k-ordered float32 FMA chain of oracle/conv_ref.c). */
 int pp_conv_variant(int variant);
+/* Numerics of the convolutions of all later launches (and of nets created later: their split weights are built at creation).
+ * Default (0, or -1 with POSEPIPE_CONV_EXACT unset): 3x3 / stride-1 convolutions and 1x1 convolutions from 1024 input
+ * channels run on v_mfma_f32_32x32x16_bf16 -- every float32 operand is split EXACTLY into three bfloat16 values and the six
+ * partial products down to 2^-16 relative weight are accumulated in float32 (conv_split.hip).  The dropped terms are <= 2^-23
+ * of a product, one float32 rounding; measured against a float64 convolution the result is as accurate as the float32 FMA
+ * chain (tests/test_gpu_split.py), but it is not bit-identical to it.
+ * exact = 1 (or POSEPIPE_CONV_EXACT=1): every layer on the float32 MFMA kernels, bit-identical to oracle/conv_ref.c.
+ * exact = -1: back to the environment's choice. */
+int pp_conv_exact(int exact);
 
 /* single convolution on caller-provided device/host buffers (tests, VideoPose3D, FC layers).
  * x: [n][hin][win][cin]; bias: [cout_pad16]; y per op flags.

@@ -96,6 +96,7 @@ SIGNATURES = {
     "pp_crop_resize_bilinear": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "pp_conv_force": (_i, [_i, _i]),
     "pp_conv_variant": (_i, [_i]),
+    "pp_conv_exact": (_i, [_i]),
     "pp_conv2d": (_i, [_vp, C.POINTER(pp_op), _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i]),
     "pp_crop_affine_normalize": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i]),
     "pp_topdown_create": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp, C.POINTER(_vp)]),

@@ -198,6 +198,9 @@ struct pp_net {
     std::vector<size_t> buf_elems;  // per-sample floats
     float* weights = nullptr;
     size_t n_weights = 0;
+    // conv_split.hip: the eligible convs' weights as bf16 planes in fragment order (built on the device at creation)
+    unsigned char* wsplit = nullptr;
+    std::vector<long long> wsplit_off;   // per op: byte offset into wsplit, -1: the op runs on the fp32-MFMA kernels
     float* arena = nullptr;
     size_t arena_floats = 0;
     int max_batch = 0;
@@ -374,6 +377,8 @@ static ConvArgs net_conv_args(pp_net* net, const pp_op& op, int batch) {
     a.x_pad = bi.pad; a.y_pad = bo.pad;
     a.r1_pad = op.res1 >= 0 ? net->bufs[op.res1].pad : 0;
     a.r2_pad = op.res2 >= 0 ? net->bufs[op.res2].pad : 0;
+    const size_t idx = &op - net->ops.data();
+    a.wsplit = (net->wsplit && idx < net->wsplit_off.size() && net->wsplit_off[idx] >= 0) ? net->wsplit + net->wsplit_off[idx] : nullptr;
     return a;
 }
 
@@ -481,6 +486,27 @@ int pp_net_create_mem(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bu
             return rc;
         }
     }
+    // bf16-split copies of the weights of every conv the split kernel will run
+    net->wsplit_off.assign(n_ops, -1);
+    if (pp_conv_split_enabled()) {
+        size_t bytes = 0;
+        for (int i = 0; i < n_ops; ++i) {
+            if (net->ops[i].type != PP_OP_CONV) continue;
+            const ConvArgs a = net_conv_args(net.get(), net->ops[i], 1);
+            if (!pp_conv_split_eligible(a)) continue;
+            net->wsplit_off[i] = (long long)bytes;
+            bytes += (pp_conv_split_bytes(a) + 255) / 256 * 256;
+        }
+        if (bytes) {
+            PP_HIP_CHECK(hipMalloc((void**)&net->wsplit, bytes));
+            for (int i = 0; i < n_ops; ++i) {
+                if (net->wsplit_off[i] < 0) continue;
+                const ConvArgs a = net_conv_args(net.get(), net->ops[i], 1);
+                int rc = pp_conv_split_weights(a, net->wsplit + net->wsplit_off[i], ctx->stream);
+                if (rc != PP_OK) return rc;
+            }
+        }
+    }
     PP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     // per-geometry tables of the pipelined conv kernel: built here, never inside a launch that may be under graph capture
     for (int i = 0; i < n_ops; ++i)
@@ -521,6 +547,7 @@ void pp_net_destroy(pp_net* net) {
     for (auto* v : net->vits) pp_vit_encoder_destroy(v);
     for (auto* d : net->deconvs) pp_deconv_bf16_destroy(d);
     if (net->weights) (void)hipFree(net->weights);
+    if (net->wsplit) (void)hipFree(net->wsplit);
     if (net->arena) (void)hipFree(net->arena);
     delete net;
 }

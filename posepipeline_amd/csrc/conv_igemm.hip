@@ -595,8 +595,9 @@ int g_variant = -1;                   // pp_conv_variant: -1 = default (env POSE
 }  // namespace
 
 extern "C" int pp_conv_variant(int variant) {
-    if (variant < -1 || variant > 3) {      // 2: timing experiment with fake addresses (wrong results), tools/conv_probe.py only
-        pp_set_error("pp_conv_variant: -1 (default), 0 (two-barrier kernel), 1 (three-stage pipelined kernel) or 3 (pipelined + tap table)");
+    if (variant < -1 || variant > 4) {      // 2: timing experiment with fake addresses (wrong results), tools/conv_probe.py only
+        pp_set_error("pp_conv_variant: -1 (default), 0 (two-barrier kernel), 1 (three-stage pipelined kernel), 3 (pipelined + tap table: "
+                     "the bit-exact default) or 4 (bf16-split kernel where eligible)");
         return PP_ERR_ARG;
     }
     g_variant = variant;
@@ -623,6 +624,26 @@ static void magic_u32(unsigned d, unsigned* m, unsigned* s1, unsigned* s2) {
     *m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
     *s1 = l < 1 ? l : 1;
     *s2 = l > 0 ? l - 1 : 0;
+}
+
+// The split kernel is the default where a layer is eligible; POSEPIPE_CONV_EXACT=1 or an explicit variant 0 / 1 / 3 keeps every
+// layer on the bit-exact fp32-MFMA kernels.
+int g_exact = -1;                     // pp_conv_exact: -1 = POSEPIPE_CONV_EXACT
+bool pp_conv_split_enabled() {
+    static const int env_exact = env_int("POSEPIPE_CONV_EXACT", 0);
+    static const int env_variant = env_int("POSEPIPE_CONV_VARIANT", -1);
+    const int v = g_variant >= 0 ? g_variant : env_variant;
+    const int exact = g_exact >= 0 ? g_exact : env_exact;
+    return v == 4 || (v < 0 && !exact);
+}
+
+extern "C" int pp_conv_exact(int exact) {
+    if (exact < -1 || exact > 1) {
+        pp_set_error("pp_conv_exact: 1 (bit-exact fp32 MFMA kernels), 0 (bf16-split kernels where eligible) or -1 (POSEPIPE_CONV_EXACT)");
+        return PP_ERR_ARG;
+    }
+    g_exact = exact;
+    return PP_OK;
 }
 
 int pp_conv_prepare(const ConvArgs& a) {
@@ -677,6 +698,17 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
     }
     a.x_bytes = (unsigned)((size_t)a.N * img_bytes);
     if (a.y_stride == 0) a.y_stride = a.Cout;
+    if (pp_conv_split_enabled() && pp_conv_split_eligible(a)) {
+        if (a.wsplit) return pp_launch_conv_split(a, stream);
+        void* tmp = nullptr;                 // single-op API: split the weights for this call
+        PP_HIP_CHECK(hipMalloc(&tmp, pp_conv_split_bytes(a)));
+        a.wsplit = tmp;
+        int rc = pp_conv_split_weights(a, tmp, stream);
+        if (rc == PP_OK) rc = pp_launch_conv_split(a, stream);
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(tmp);
+        return rc;
+    }
     static const int force_ct = env_int("POSEPIPE_CONV_CT", 0), force_pt = env_int("POSEPIPE_CONV_PT", 0),
                      min_blocks = env_int("POSEPIPE_CONV_MIN_BLOCKS", 512);
     const int tiles = a.CoutPad / 16;
@@ -704,6 +736,7 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
     }
     if (env_variant >= 0) variant = env_variant;
     if (g_variant >= 0) variant = g_variant;
+    if (variant == 4) variant = 0;           // not eligible for the split kernel: built-in exact default
     if (force_ct) best_ct = force_ct;
     if (g_force_ct) best_ct = g_force_ct;
     const int cblocks = (tiles + best_ct - 1) / best_ct;

@@ -1,0 +1,582 @@
+// fp32 convolution on the bf16 matrix cores: three-way operand split, six MFMA products per term, fp32 accumulation.
+//
+// Why: v_mfma_f32_16x16x4_f32 peaks at 256 FLOP/clk/CU (157 TFLOP/s at 2.4 GHz); conv_igemm(_p3).hip sustain 0.76-0.85 of it and
+// the detector / HRNet chunks are bound by exactly that (profiles/r02_conv_ablation.txt).  v_mfma_f32_32x32x16_bf16 runs 16x
+// that rate.  A float32 value is the EXACT sum of three bfloat16 values (24 significand bits = 8 + 8 + 8, same exponent range):
+//     a = a0 + a1 + a2,   a0 = top 8 bits of a,  a1 = top 8 bits of a - a0,  a2 = a - a0 - a1   (truncation, no rounding)
+// so a*b = sum_{i,j} ai*bj, every ai*bj exact in the MFMA's fp32 product.  Keeping the six terms with i + j <= 2 drops
+// a1*b2 + a2*b1 + a2*b2 <= 2^-23 |a*b| -- the size of ONE float32 rounding of the product, which a float32 FMA chain commits
+// at every step anyway.  The sums are accumulated in the MFMA's float32 accumulators.  Cost: 6 bf16 MFMAs of 16 k for what
+// takes 4 fp32 MFMAs of 4 k = 2.67x the arithmetic peak (419 TFLOP/s fp32-equivalent).
+// Results are NOT bit-identical to oracle/conv_ref.c (different summation order and the dropped 2^-23 terms): the measured
+// deviation is that of a reordered float32 sum (tests/test_gpu_conv_split.py: same error against a float64 convolution as the
+// exact kernel).  POSEPIPE_CONV_EXACT=1 / pp_conv_variant(3) selects the bit-exact fp32-MFMA kernels instead.
+//
+// Structure (3x3, stride 1, pad 1 -- 52 % of the detector's and ~85 % of HRNet's time; 1x1 layers: conv_split_gemm below).
+// An implicit GEMM that gathers per tap re-reads every input element nine times through L1/L2; at 2.67x the MFMA rate that
+// feed (87 GB/s per CU for a 128 x 64 tile) is over what the vector memory path delivers.  Instead a workgroup stages the
+// input PATCH of its output tile once per 16 input channels:
+//   * output tile: 8 pixel blocks of 32 pixels (one MFMA N tile each) arranged as a rectangle, x 64 output channels
+//     (2 MFMA M tiles): 4 waves x (2 pixel blocks x 2 channel blocks) = 4 accumulators of 16 registers per wave;
+//   * patch: (TH + 2) x (TW + 2) pixels x 16 channels, loaded as float32 (coalesced 64 B per pixel), split into the three
+//     bf16 planes in registers (5.5 VALU ops per element, once per element per block) and written to LDS as
+//     [plane][k half][pixel] 16-byte slots: the B fragment of tap (dy, dx) for a pixel block is ONE ds_read_b128 per plane
+//     at slot (pixel + dy * pitch + dx) -- the nine taps are nine address offsets into the same patch;
+//   * weights: pre-split on the device at net creation into MFMA A-fragment order ([16-channel chunk][tap][32 couts][plane]
+//     [lane] x 16 B), read straight from global memory into registers, 1 KB contiguous per wave instruction, one tap ahead;
+//   * one barrier per 16-channel chunk (9 taps x 24 MFMAs = 6912 matrix-pipe cycles per wave); the patch is double-buffered,
+//     the float32 loads of chunk c + 1 are in flight during chunk c and split / written half-way through it.
+// Traffic per 16-channel chunk and block: patch 340 x 64 B + weights 9 x 6 KB (L1 / L2 resident) = 11 B / matrix-pipe cycle.
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <type_traits>
+
+#include "pp_internal.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+namespace {
+
+constexpr int PXB = 2;   // pixel blocks (32 pixels) per wave
+
+struct SplitArgs {
+    const float* x;
+    const uint4* w;          // split weights, fragment order
+    const float* bias;
+    const float* res1;
+    const float* res2;
+    float* y;
+    int N, H, W, Cin, Cout, ncb;          // ncb: 32-channel blocks of the split weights
+    int xp_h, xp_w;                       // stored rows per image / pixels per row of the input (dims + halo)
+    int y_pad, r1_pad, r2_pad, relu;
+    int nchunks;                          // Cin / 16
+    int tiles_x, tiles_y, TH, TW, bw_log2, gx_log2;   // MODE_TILE
+    int PWp;                              // patch pitch (TILE) / stored row pitch of the input (STREAM), in pixels
+    int NP, NPp;                          // patch pixels, padded so that the two k halves are 64 B apart mod 128
+    int mode, stride;
+    long long S;                          // STREAM: positions of the padded input stream, GEMM: output pixels
+    unsigned x_bytes;
+    int xcd_remap;
+};
+
+// truncation split of four floats into the three bf16 planes (4 x 16 bit each)
+__device__ __forceinline__ void split4(const float4 v, uint2& p0, uint2& p1, uint2& p2) {
+    const unsigned a[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    unsigned h0[4], h1[4], h2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h0[i] = a[i] & 0xffff0000u;
+        const float r1 = __uint_as_float(a[i]) - __uint_as_float(h0[i]);     // exact
+        h1[i] = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(h1[i]);                        // exact, <= 8 significant bits
+        h2[i] = __float_as_uint(r2);
+    }
+    // (hi16 of element 2i+1) << 16 | hi16 of element 2i
+    p0 = make_uint2(__builtin_amdgcn_perm(h0[1], h0[0], 0x07060302u), __builtin_amdgcn_perm(h0[3], h0[2], 0x07060302u));
+    p1 = make_uint2(__builtin_amdgcn_perm(h1[1], h1[0], 0x07060302u), __builtin_amdgcn_perm(h1[3], h1[2], 0x07060302u));
+    p2 = make_uint2(__builtin_amdgcn_perm(h2[1], h2[0], 0x07060302u), __builtin_amdgcn_perm(h2[3], h2[2], 0x07060302u));
+}
+
+// ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (+32): lane -> q such that each
+// group is 16 consecutive q.  Pixel blocks narrower than 32 pixels give every group whole rows of the block.
+__device__ __forceinline__ int lane_q(int r) {
+    const int g1 = ((r >= 4 && r < 12) || (r >= 16 && r < 20) || r >= 28) ? 1 : 0;
+    int idx;
+    if (!g1) idx = r < 4 ? r : r < 16 ? r - 8 : r - 12;              // 0-3 -> 0-3, 12-15 -> 4-7, 20-27 -> 8-15
+    else idx = r < 12 ? r - 4 : r < 20 ? r - 8 : r - 16;             // 4-11 -> 0-7, 16-19 -> 8-11, 28-31 -> 12-15
+    return g1 * 16 + idx;
+}
+// position of block pixel q inside a block of width 32 >> bw_log2 ... (bw_log2: 0 = 1 x 32, 1 = 2 x 16, 2 = 4 x 8 pixels)
+__device__ __forceinline__ void block_pixel(int r, int bw_log2, int& iy, int& ix) {
+    if (bw_log2 == 0) {
+        iy = 0;
+        ix = r;
+        return;
+    }
+    const int q = lane_q(r);
+    if (bw_log2 == 1) {
+        iy = q >> 4;
+        ix = q & 15;
+    } else {            // rows 0, 2 in the first lane group, 1, 3 in the second (patch pitch = 4 mod 8: conflict-free)
+        iy = ((q >> 3) & 1) * 2 + (q >> 4);
+        ix = q & 7;
+    }
+}
+
+// MODE_TILE   3x3 / stride 1 / pad 1 on any buffer: rectangular output tile, patch = tile + 1-pixel frame (bounds-tested loads)
+// MODE_STREAM 3x3 / stride 1 / pad 1 on a zero-halo input (pp_buf.pad >= 1): the padded tensor is ONE pixel stream in which tap
+//             (dy, dx) of position s is position s + dy * pitch + dx (the halo supplies every out-of-image zero), so a tile is
+//             256 CONSECUTIVE stream positions whatever the map's width -- no tile quantisation on HRNet's 36 / 18 / 9-pixel rows;
+//             patch = the 256 + 2 pitch + 2 positions around it, loaded without any test; halo positions are not stored
+// MODE_GEMM   1x1 (any stride), and 'valid' convs whose kernel covers the whole input (the RoI head's 7x7 fc6, rewritten by
+//             the launcher as 1x1 over 49 x 256 channels): tile = 256 consecutive output pixels, one "tap"
+enum { MODE_TILE = 0, MODE_STREAM = 1, MODE_GEMM = 2 };
+
+// COB: output-channel blocks (32 channels) per wave and per workgroup
+template <int T, int NSLOT, int COB>
+__global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    unsigned L = blockIdx.x;
+    if (a.xcd_remap) {      // consecutive workgroup ids go round-robin over the 8 XCDs: give every XCD a contiguous run of tiles
+        const unsigned total = gridDim.x;
+        const unsigned xcd = L & 7u, j = L >> 3;
+        const unsigned q = total >> 3, r = total & 7u;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int cb0 = blockIdx.y * COB;
+    const int plane_bytes = 2 * a.NPp * 16;           // [half][pixel] x 16 B
+    const int buf_bytes = 3 * plane_bytes;
+
+    // tile origin
+    int n = 0, x0 = 0, y0 = 0;
+    long long s0 = 0;                                  // STREAM: first stream position, GEMM: first output pixel
+    if (a.mode == MODE_TILE) {
+        const int tx = (int)(L % (unsigned)a.tiles_x);
+        const unsigned L2 = L / (unsigned)a.tiles_x;
+        const int ty = (int)(L2 % (unsigned)a.tiles_y);
+        n = (int)(L2 / (unsigned)a.tiles_y);
+        x0 = tx * a.TW;
+        y0 = ty * a.TH;
+    } else {
+        s0 = (long long)L * 256;
+    }
+
+    // ---- patch loader: slot j of this thread = (patch pixel p, channel quad) -----------------------------------------
+    unsigned goff[NSLOT];
+    // LDS byte offset (plane 0) of slot j: woff0 + 1024 j (64 pixels further, same quad)
+    const int woff0 = ((((tid & 3) >> 1) * a.NPp + (tid >> 2)) * 16 + (tid & 1) * 8);
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+        const int u = tid + 256 * j;
+        const int p = u >> 2, quad = u & 3;
+        const bool in_patch = p < a.NP;
+        unsigned off = 0xffffffffu;
+        if (a.mode == MODE_TILE) {
+            const int pr = p / a.PWp, pc = p - pr * a.PWp;
+            const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
+            if (in_patch && pc < a.TW + 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                off = (unsigned)(((n * a.xp_h + iy) * a.xp_w + ix) * a.Cin) * 4u;
+        } else if (a.mode == MODE_STREAM) {
+            const long long pos = s0 - a.PWp - 1 + p;
+            if (in_patch && pos >= 0 && pos < a.S) off = (unsigned)pos * (unsigned)a.Cin * 4u;
+        } else {
+            const long long m = s0 + p;
+            if (in_patch && m < a.S) {
+                const int img = (int)(m / (a.H * a.W)), rem = (int)(m - (long long)img * (a.H * a.W));
+                const int ho = rem / a.W, wo = rem - ho * a.W;
+                off = (unsigned)(((img * a.xp_h + ho * a.stride) * a.xp_w + wo * a.stride) * a.Cin) * 4u;
+            }
+        }
+        goff[j] = off == 0xffffffffu ? off : off + (unsigned)quad * 16u;
+    }
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+    float4 xr[NSLOT];
+    auto load_patch = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const unsigned off = goff[j] == 0xffffffffu ? 0xffffffffu : goff[j] + (unsigned)c * 64u;
+            xr[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+        }
+    };
+    // split + write slots [j0, j1) of the staged chunk; branch-free (it sits between MFMAs) except for the last slot, the only
+    // one that can be partly outside the patch (NSLOT = ceil(NP / 64))
+    const bool last_ok = (tid >> 2) + 64 * (NSLOT - 1) < a.NP;
+    auto store_patch = [&](int buf, int j0, int j1) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            if (j < j0 || j >= j1) continue;
+            uint2 p0, p1, p2;
+            split4(xr[j], p0, p1, p2);
+            if (j == NSLOT - 1 && !last_ok) continue;
+            unsigned char* d = smem + buf * buf_bytes + woff0 + 1024 * j;
+            *reinterpret_cast<uint2*>(d) = p0;
+            *reinterpret_cast<uint2*>(d + plane_bytes) = p1;
+            *reinterpret_cast<uint2*>(d + 2 * plane_bytes) = p2;
+        }
+    };
+
+    // ---- operand addresses and output pixels -------------------------------------------------------------------------------
+    int aofs[PXB];           // LDS byte offset of this lane's pixel (tap (0,0), plane 0) per pixel block
+    int on[PXB], oy[PXB], ox[PXB];
+    bool ook[PXB];
+    if (a.mode == MODE_TILE) {
+        const int BW = 32 >> a.bw_log2, BH = 1 << a.bw_log2;
+        int by, bx;
+        block_pixel(lane & 31, a.bw_log2, by, bx);
+#pragma unroll
+        for (int pb = 0; pb < PXB; ++pb) {
+            const int b = wave * PXB + pb;
+            const int gy = b >> a.gx_log2, gx = b & ((1 << a.gx_log2) - 1);
+            const int ry = gy * BH + by, rx = gx * BW + bx;
+            aofs[pb] = (((lane >> 5) * a.NPp) + ry * a.PWp + rx) * 16;
+            on[pb] = n;
+            oy[pb] = y0 + ry;
+            ox[pb] = x0 + rx;
+            ook[pb] = oy[pb] < a.H && ox[pb] < a.W;
+        }
+    } else {
+#pragma unroll
+        for (int pb = 0; pb < PXB; ++pb) {
+            const int pl = (wave * PXB + pb) * 32 + (lane & 31);
+            aofs[pb] = (((lane >> 5) * a.NPp) + pl) * 16;
+            const long long s = s0 + pl;
+            const bool in = s < a.S;
+            const long long sc = in ? s : 0;
+            const int per = a.mode == MODE_STREAM ? a.xp_h * a.PWp : a.H * a.W;
+            const int row = a.mode == MODE_STREAM ? a.PWp : a.W;
+            on[pb] = (int)(sc / per);
+            const int rem = (int)(sc - (long long)on[pb] * per);
+            oy[pb] = rem / row;
+            ox[pb] = rem - oy[pb] * row;
+            ook[pb] = in && oy[pb] < a.H && ox[pb] < a.W;
+        }
+    }
+    // weights: fragment (step, channel block cb, plane) at ((step * ncb + cb) * 3 + plane) * 64 + lane, step = chunk * T + tap
+    const uint4* wlane = a.w + (size_t)cb0 * 3 * 64 + lane;
+    const size_t wstep = (size_t)a.ncb * 3 * 64;       // uint4 per step
+
+    f32x16 acc[COB][PXB];
+#pragma unroll
+    for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < PXB; ++pb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
+
+    uint4 wf[2][COB][3];
+    uint4 xf[PXB][3];
+    const uint4* wp = wlane;                           // weights of the next step to fetch (one spare step at the end of the buffer)
+    auto load_w = [&](uint4 (&dst)[COB][3]) {
+#pragma unroll
+        for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) dst[cb][pl] = wp[(cb * 3 + pl) * 64];
+        wp += wstep;
+    };
+    auto load_x = [&](const unsigned char* pbuf, int t, int pb) {
+        const int toff = T == 9 ? ((t / 3) * a.PWp + (t % 3)) * 16 : 0;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) xf[pb][pl] = *reinterpret_cast<const uint4*>(pbuf + pl * plane_bytes + aofs[pb] + toff);
+    };
+
+    // ---- prologue ---------------------------------------------------------------------------------------------------------
+    load_patch(0);
+    load_w(wf[0]);
+    store_patch(0, 0, NSLOT);
+    if (a.nchunks > 1) load_patch(1);
+    __syncthreads();
+#pragma unroll
+    for (int pb = 0; pb < PXB; ++pb) load_x(smem, 0, pb);
+
+    // the six products with i + j <= 2 of one (channel block, pixel block) pair, smallest terms first; `half`: 0 / 1 = the first /
+    // last three, -1 = all six
+    auto mma = [&](const uint4 (&wc)[COB][3], int cb, int pb, int half) {
+        f32x16 c = acc[cb][pb];
+        auto W = [&](int i) { return __builtin_bit_cast(bf16x8, wc[cb][i]); };
+        auto X = [&](int i) { return __builtin_bit_cast(bf16x8, xf[pb][i]); };
+        if (half != 1) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(2), X(0), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(1), X(1), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(2), c, 0, 0, 0);
+        }
+        if (half != 0) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(1), X(0), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(1), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(0), c, 0, 0, 0);
+        }
+        acc[cb][pb] = c;
+    };
+
+    // One 16-channel chunk: T steps.  Weights of step s + 1 are requested (global -> the other register set) before the MFMAs of
+    // step s; a pixel block's fragments of step s + 1 are read from LDS into the SAME registers as soon as its MFMAs of step s
+    // are issued, i.e. while the other pixel block's MFMAs run.  The fences keep the compiler from sinking the loads.
+    auto chunk = [&](auto par, int c) {
+        constexpr int PAR = decltype(par)::value;
+        const unsigned char* pbuf = smem + (c & 1) * buf_bytes;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int cur = (PAR + t) & 1;
+            load_w(wf[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pb = 0; pb < PXB; ++pb) {
+                // the next chunk's patch (loaded one chunk ago) is split and written half-way through the chunk.  As its own
+                // (branched) region: interleaving it with the MFMAs costs ~30 registers (spills with 7-8 patch slots) and
+                // measured slower -- the CU's other workgroup keeps the matrix pipe busy meanwhile
+                if (pb == PXB - 1 && t == T / 2 && c + 1 < a.nchunks) store_patch((c + 1) & 1, 0, NSLOT);
+#pragma unroll
+                for (int cb = 0; cb < COB; ++cb) mma(wf[cur], cb, pb, -1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 1 < T) load_x(pbuf, t + 1, pb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        if (c + 1 < a.nchunks) {
+#pragma unroll
+            for (int pb = 0; pb < PXB; ++pb) load_x(smem + ((c + 1) & 1) * buf_bytes, 0, pb);
+        }
+        if (c + 2 < a.nchunks) load_patch(c + 2);
+    };
+    int c = 0;
+    for (; c + 1 < a.nchunks; c += 2) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        chunk(std::integral_constant<int, 1>{}, c + 1);
+    }
+    if (c < a.nchunks) chunk(std::integral_constant<int, 0>{}, c);
+
+    // ---- epilogue: bias, residuals, ReLU; accumulator register i of a lane = channel 8 (i / 4) + 4 (lane / 32) + i % 4 ---
+#pragma unroll
+    for (int pb = 0; pb < PXB; ++pb) {
+        if (!ook[pb]) continue;
+        const size_t ypix = ((size_t)on[pb] * (a.H + a.y_pad) + oy[pb]) * (a.W + a.y_pad) + ox[pb];
+        const size_t r1pix = ((size_t)on[pb] * (a.H + a.r1_pad) + oy[pb]) * (a.W + a.r1_pad) + ox[pb];
+        const size_t r2pix = ((size_t)on[pb] * (a.H + a.r2_pad) + oy[pb]) * (a.W + a.r2_pad) + ox[pb];
+#pragma unroll
+        for (int cb = 0; cb < COB; ++cb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = (cb0 + cb) * 32 + 8 * g + 4 * (lane >> 5);
+                if (co >= a.Cout) continue;
+                const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
+                const f32x16 cc = acc[cb][pb];
+                float4 v = make_float4(cc[4 * g + 0] + b4.x, cc[4 * g + 1] + b4.y, cc[4 * g + 2] + b4.z, cc[4 * g + 3] + b4.w);
+                if (a.relu == PP_RELU_FIRST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (a.res1) {
+                    const float4 r = *reinterpret_cast<const float4*>(a.res1 + r1pix * a.Cout + co);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (a.res2) {
+                    const float4 r = *reinterpret_cast<const float4*>(a.res2 + r2pix * a.Cout + co);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(a.y + ypix * a.Cout + co) = v;
+            }
+        }
+    }
+}
+
+// ---- weight split: float32 blob rows ([K / 32][CoutPad][32], pack_conv order) -> fragment order, three bf16 planes ---------
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* w, uint4* out, int Cin, int taps, int CoutPad, int ncb,
+                                                            size_t total) {
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;       // (chunk, tap, cb, lane)
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    size_t r = i >> 6;
+    const int cb = (int)(r % ncb);
+    r /= ncb;
+    const int t = (int)(r % taps);
+    const int c = (int)(r / taps);
+    const int cout = cb * 32 + (lane & 31);
+    unsigned short h[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cin = c * 16 + (lane >> 5) * 8 + j;
+        const int k = t * Cin + cin;
+        float v = 0.f;
+        if (cout < CoutPad) v = w[((size_t)(k >> 5) * CoutPad + cout) * 32 + 8 * (k & 3) + ((k & 31) >> 2)];
+        const unsigned b0 = __float_as_uint(v) & 0xffff0000u;
+        const float r1 = v - __uint_as_float(b0);
+        const unsigned b1 = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(b1);
+        h[0][j] = (unsigned short)(b0 >> 16);
+        h[1][j] = (unsigned short)(b1 >> 16);
+        h[2][j] = (unsigned short)(__float_as_uint(r2) >> 16);
+    }
+    const size_t frag = (i >> 6) * 3;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        uint4 o;
+        o.x = h[pl][0] | ((unsigned)h[pl][1] << 16);
+        o.y = h[pl][2] | ((unsigned)h[pl][3] << 16);
+        o.z = h[pl][4] | ((unsigned)h[pl][5] << 16);
+        o.w = h[pl][6] | ((unsigned)h[pl][7] << 16);
+        out[(frag + pl) * 64 + lane] = o;
+    }
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+struct TileGeom {
+    int TH, TW, bw_log2, gx_log2, PWp, NP, NPp, tiles_x, tiles_y;
+    double eff;
+};
+
+// the 256-pixel tile shape (8 blocks of 32 pixels) that wastes the fewest pixels on this map
+TileGeom pick_tile(int H, int W, double big_patch_factor) {
+    static const int force = env_int("POSEPIPE_SPLIT_TILE", -1);
+    TileGeom best{};
+    best.eff = -1.0;
+    // (bw_log2, gx_log2): 8x32, 4x64, 16x16, 32x8
+    const int cand[4][2] = {{0, 0}, {0, 1}, {1, 0}, {2, 0}};
+    for (int i = 0; i < 4; ++i) {
+        if (force >= 0 && i != force) continue;
+        TileGeom g{};
+        g.bw_log2 = cand[i][0];
+        g.gx_log2 = cand[i][1];
+        const int BW = 32 >> g.bw_log2, BH = 1 << g.bw_log2, GX = 1 << g.gx_log2, GY = 8 / GX;
+        g.TW = GX * BW;
+        g.TH = GY * BH;
+        g.PWp = g.TW + 2;
+        if (g.bw_log2 == 2)
+            while (g.PWp % 8 != 4) ++g.PWp;
+        g.NP = (g.TH + 2) * g.PWp;
+        g.NPp = g.NP;
+        while (g.NPp % 8 != 4) ++g.NPp;       // half planes 64 B apart mod 128: conflict-free ds_write_b64
+        g.tiles_x = (W + g.TW - 1) / g.TW;
+        g.tiles_y = (H + g.TH - 1) / g.TH;
+        g.eff = (double)H * W / ((double)g.tiles_x * g.tiles_y * 256.0) * (g.NP > 384 ? big_patch_factor : 1.0) - 1e-4 * g.NP / 256.0;
+        if (g.eff > best.eff) best = g;
+    }
+    return best;
+}
+
+}  // namespace
+
+// how the split kernel sees the layer: taps (9 / 1) and channels per tap (a full-cover 'valid' conv is a 1x1 over KH*KW*Cin)
+static bool split_shape(const ConvArgs& a, int* taps, int* cin, int* mode) {
+    const bool k3 = a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_h == 1 && a.pad_w == 1 && a.dil_h == 1 && a.dil_w == 1 &&
+                    a.Hout == a.Hin && a.Wout == a.Win;
+    const bool k1 = a.KH == 1 && a.KW == 1 && a.pad_h == 0 && a.pad_w == 0;
+    const bool full = a.KH == a.Hin && a.KW == a.Win && a.pad_h == 0 && a.pad_w == 0 && a.dil_h == 1 && a.dil_w == 1 &&
+                      a.x_pad == 0 && a.Hout == 1 && a.Wout == 1 && !k1;
+    if (!(k3 || k1 || full)) return false;
+    *taps = k3 ? 9 : 1;
+    *cin = full ? a.K : a.Cin;
+    *mode = k3 ? MODE_TILE : MODE_GEMM;
+    return true;
+}
+
+bool pp_conv_split_eligible(const ConvArgs& a) {
+    const bool res1_plain = !a.res1 || (a.res1_shift == 0 && a.res1_off_w == 0 && a.res1_H == a.Hout && a.res1_W == a.Wout);
+    int taps, cin, mode;
+    // 1x1 layers: the split kernel wins from ~1024 input channels (fc6 / fc7 of the RoI head +12 %, ResNet's 1024 -> 256 +3..6 %);
+    // below, the layers are bound by their tile count or by HBM and the fp32 kernel's smaller tiles do as well or better
+    // (profiles/r02_conv_split.txt).  POSEPIPE_SPLIT_GEMM_MIN_CIN overrides the threshold.
+    static const int gemm_min_cin = env_int("POSEPIPE_SPLIT_GEMM_MIN_CIN", 1024);
+    if (!split_shape(a, &taps, &cin, &mode)) return false;
+    if (mode == MODE_GEMM && cin < gemm_min_cin) return false;
+    return cin % 16 == 0 && a.Cout % 4 == 0 && a.up_log2 == 0 && !a.out_nchw && res1_plain && a.relu <= PP_RELU_FIRST &&
+           (a.y_stride == 0 || a.y_stride == a.Cout) && a.y_coff == 0;
+}
+
+static int split_ncb(const ConvArgs& a) { return (a.Cout + 31) / 32; }     // odd: one block per workgroup (COB = 1), else two
+
+size_t pp_conv_split_bytes(const ConvArgs& a) {
+    int taps = 1, cin = a.Cin, mode = 0;
+    split_shape(a, &taps, &cin, &mode);
+    return ((size_t)(cin / 16) * taps + 1) * split_ncb(a) * 3 * 64 * sizeof(uint4);      // + one spare step: the kernel fetches one step ahead
+}
+
+int pp_conv_split_weights(const ConvArgs& a, void* out, hipStream_t stream) {
+    int taps = 1, cin = a.Cin, mode = 0;
+    split_shape(a, &taps, &cin, &mode);
+    const int ncb = split_ncb(a);
+    const size_t total = (size_t)(cin / 16) * taps * ncb * 64;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a.w, (uint4*)out, cin,
+                       taps, a.CoutPad, ncb, total);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        pp_set_error("split_weights launch failed: %s", hipGetErrorString(e));
+        return PP_ERR_HIP;
+    }
+    return PP_OK;
+}
+
+int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
+    int taps = 1, cin = a.Cin, mode = 0;
+    if (!split_shape(a, &taps, &cin, &mode)) {
+        pp_set_error("conv_split: layer not eligible");
+        return PP_ERR_ARG;
+    }
+    const bool full = mode == MODE_GEMM && cin != a.Cin;
+    SplitArgs s{};
+    s.x = a.x; s.w = (const uint4*)a.wsplit; s.bias = a.bias; s.res1 = a.res1; s.res2 = a.res2; s.y = a.y;
+    s.N = a.N; s.H = a.Hout; s.W = a.Wout; s.Cin = cin; s.Cout = a.Cout;
+    s.ncb = split_ncb(a);
+    s.xp_h = full ? 1 : a.Hin + a.x_pad;
+    s.xp_w = full ? 1 : a.Win + a.x_pad;
+    s.stride = a.stride;
+    s.y_pad = a.y_pad; s.r1_pad = a.r1_pad; s.r2_pad = a.r2_pad; s.relu = a.relu;
+    s.nchunks = cin / 16;
+    s.x_bytes = a.x_bytes;
+    s.xcd_remap = a.xcd_remap;
+    unsigned gx = 0;
+    int nslot = 0;
+    if (mode == MODE_GEMM) {
+        s.mode = MODE_GEMM;
+        s.S = (long long)a.M;
+        s.NP = 256;
+        s.NPp = 260;
+        gx = (unsigned)((a.M + 255) / 256);
+        nslot = 4;
+    } else {
+        // two channel blocks per wave leave registers for 6 patch slots (384 pixels); beyond, ~20 registers spill (measured cost: a
+        // few percent, less than a badly quantised tile)
+        const double big = 1.0;
+        const int max_np = 512;
+        const TileGeom g = pick_tile(a.Hout, a.Wout, big);
+        static const int stream_env = env_int("POSEPIPE_SPLIT_STREAM", -1);
+        const int snp = 258 + 2 * s.xp_w;
+        const double stream_eff = (double)a.Hout * a.Wout / ((double)s.xp_h * s.xp_w) * (snp > 384 ? big : 1.0);
+        bool use_stream = a.x_pad >= 1 && snp <= max_np && stream_eff > g.eff + 0.02;
+        if (stream_env == 0) use_stream = false;
+        if (stream_env == 1 && a.x_pad >= 1 && snp <= max_np) use_stream = true;
+        if (use_stream) {
+            s.mode = MODE_STREAM;
+            s.PWp = s.xp_w;
+            s.S = (long long)a.N * s.xp_h * s.xp_w;
+            s.NP = snp;
+            s.NPp = snp;
+            while (s.NPp % 8 != 4) ++s.NPp;
+            gx = (unsigned)((s.S + 255) / 256);
+        } else {
+            s.mode = MODE_TILE;
+            s.tiles_x = g.tiles_x; s.tiles_y = g.tiles_y; s.TH = g.TH; s.TW = g.TW; s.bw_log2 = g.bw_log2; s.gx_log2 = g.gx_log2;
+            s.PWp = g.PWp; s.NP = g.NP; s.NPp = g.NPp;
+            gx = (unsigned)(g.tiles_x * g.tiles_y * a.N);
+        }
+        nslot = (s.NP * 4 + 255) / 256;
+    }
+    const int cob = (s.ncb & 1) ? 1 : 2;
+    const dim3 grid(gx, (unsigned)(s.ncb / cob));
+    const size_t lds = (size_t)2 * 3 * 2 * s.NPp * 16;
+#define PP_SPLIT_LAUNCH(T_, NS_)                                                                                        \
+    do {                                                                                                                \
+        static std::once_flag once;                                                                                     \
+        std::call_once(once, [] {     /* > 64 KB of dynamic LDS has to be allowed per kernel */                         \
+            (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
+        });                                                                                                             \
+        if (cob == 2)                                                                                                   \
+            hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 2>), grid, dim3(256), lds, stream, s);                       \
+        else                                                                                                            \
+            hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 1>), grid, dim3(256), lds, stream, s);                       \
+    } while (0)
+    if (mode == MODE_GEMM)
+        PP_SPLIT_LAUNCH(1, 4);
+    else if (nslot <= 5)
+        PP_SPLIT_LAUNCH(9, 5);
+    else if (nslot == 6)
+        PP_SPLIT_LAUNCH(9, 6);
+    else if (nslot == 7)
+        PP_SPLIT_LAUNCH(9, 7);
+    else
+        PP_SPLIT_LAUNCH(9, 8);
+#undef PP_SPLIT_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        pp_set_error("conv_split launch failed: %s", hipGetErrorString(e));
+        return PP_ERR_HIP;
+    }
+    return PP_OK;
+}

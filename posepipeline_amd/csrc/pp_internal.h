@@ -82,7 +82,16 @@ struct ConvArgs {
     const uint2* tap_table;
     int x_pad, y_pad, r1_pad, r2_pad;   // zero halo (right columns / bottom rows) of the input, output and residual buffers (pp_buf.pad)
     int no_bounds;          // set by pp_launch_conv: no tap can leave the image (no padding) and the tensor is < 2 GiB
+    // conv_split.hip: the weights pre-split into bf16 planes in fragment order (pp_conv_split_weights); null: pp_launch_conv
+    // builds a temporary copy when it picks the split kernel (single-op API; never under graph capture)
+    const void* wsplit;
 };
+// fp32 convolution on the bf16 matrix cores (three-way split, six products; conv_split.hip)
+bool pp_conv_split_eligible(const ConvArgs& a);
+size_t pp_conv_split_bytes(const ConvArgs& a);
+int pp_conv_split_weights(const ConvArgs& a, void* out, hipStream_t stream);
+int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream);   // `a` as prepared by pp_launch_conv, a.wsplit set
+bool pp_conv_split_enabled();       // false: POSEPIPE_CONV_EXACT=1 or an explicit exact variant
 // builds (and caches per device) the tap tables the pipelined kernel may use for this geometry; call outside graph capture
 int pp_conv_prepare(const ConvArgs& a);
 int pp_conv_out_dim(int in, int k, int stride, int pad, int dil);

@@ -19,3 +19,24 @@ def ctx():
     c = _lib.Context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(autouse=True)
+def _conv_numerics(request):
+    """GPU tests run the float32-MFMA convolution kernels, which are bit-identical to oracle/conv_ref.c, so that `==` against
+    the oracle is meaningful.  The library's DEFAULT (three-way bf16 split on the bf16 matrix cores: float32-accurate but
+    not bit-identical) is what tests/test_gpu_split.py covers: it switches with pp_conv_exact(0)."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    from posepipeline_amd import _lib
+    lib = _lib.load_library()
+    lib.pp_conv_exact(1)
+    old = os.environ.get("POSEPIPE_CONV_EXACT")
+    os.environ["POSEPIPE_CONV_EXACT"] = "1"          # worker processes a test starts (sharded ranks, env-knob probes)
+    yield
+    lib.pp_conv_exact(1)
+    if old is None:
+        os.environ.pop("POSEPIPE_CONV_EXACT", None)
+    else:
+        os.environ["POSEPIPE_CONV_EXACT"] = old
