@@ -29,6 +29,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (v_mfma_f32_32x32x16_bf16: 32 cycles / SIMD, 1024 CUs x SIMDs at 2.4 GHz)
+SPLIT_PRODUCTS = 6              # conv_split.hip: bf16 MFMAs per float32 term -> fp32-equivalent peak = 2500 / 6 = 416.7
 METRIC = "frames/sec (whole node), detect->2D->3D cascade on 1080p; MPJPE vs reference"
 
 
@@ -52,7 +54,8 @@ def kernel_source_sha():
     """fingerprint of what decides the conv kernels' memory traffic: their sources and the tile table"""
     import hashlib
     h = hashlib.sha256()
-    for rel in ("posepipeline_amd/csrc/conv_igemm.hip", "posepipeline_amd/csrc/conv_igemm_p3.hip", "posepipeline_amd/conv_tuning.txt"):
+    for rel in ("posepipeline_amd/csrc/conv_igemm.hip", "posepipeline_amd/csrc/conv_igemm_p3.hip", "posepipeline_amd/csrc/conv_split.hip",
+                "posepipeline_amd/conv_tuning.txt"):
         try:
             with open(os.path.join(ROOT, rel), "rb") as f:
                 h.update(f.read())
@@ -75,18 +78,77 @@ def pmc_traffic(key):
     return e["traffic_bytes_per_launch"], e.get("source", "")
 
 
-def algorithmic_bytes(prog, batch):
-    """HBM bytes the conv launches of a program would move if every operand were read / written exactly once: per op, input
-    activations + weights + bias + residuals + output, float32 (the figure `traffic` is to be compared with)"""
-    total = 0
+def algorithmic_bytes_per_op(prog, batch):
+    """HBM bytes each conv launch of a program would move if every operand were read / written exactly once: input
+    activations + weights + bias + residuals + output, float32 (the figure `traffic` is to be compared with); 0 for other ops"""
+    per_op = []
     for op in prog.ops:
         if op.type != 1:      # PP_OP_CONV
+            per_op.append(0)
             continue
         elems = lambda b: prog.bufs[b][0] * prog.bufs[b][1] * prog.bufs[b][2]
         act = elems(op.in_) + sum(elems(r) for r in (op.res1, op.res2) if r >= 0)
         out = (prog.bufs[op.out][0] * prog.bufs[op.out][1]) * op.cout
-        total += 4 * (batch * (act + out) + op.kh * op.kw * op.cin * op.cout + op.cout)
-    return total
+        per_op.append(4 * (batch * (act + out) + op.kh * op.kw * op.cin * op.cout + op.cout))
+    return per_op
+
+
+def algorithmic_bytes(prog, batch):
+    return sum(algorithmic_bytes_per_op(prog, batch))
+
+
+def kernel_families(nets_batches, reps=3):
+    """Per kernel family (1 = float32 MFMA kernels, 2 = bf16-split kernel): launches, FLOPs, algorithmic bytes and the summed
+    HIP-event durations of ONE pass of the given (net, batch) programs, serial on one stream (pp_net_profile: events around
+    every op -- the same per-launch durations rocprofv3 --kernel-trace reports for the serial profile)."""
+    fam = {1: dict(launches=0, flops=0.0, bytes=0.0, ms=0.0), 2: dict(launches=0, flops=0.0, bytes=0.0, ms=0.0)}
+    for net, batch in nets_batches:
+        net.profile(batch)
+        ms = np.median(np.stack([net.profile(batch) for _ in range(reps)]), axis=0)
+        kinds = net.conv_kinds()
+        ab = algorithmic_bytes_per_op(net.prog, batch)
+        for i, k in enumerate(kinds):
+            if k in fam:
+                f = fam[int(k)]
+                f["launches"] += 1
+                f["flops"] += net.prog.op_flops[i] * batch
+                f["bytes"] += ab[i]
+                f["ms"] += float(ms[i])
+    return fam
+
+
+def roofline_families(fam):
+    """roofline object of the dominant kernel family (+ the other family beside it), see kernel_families"""
+    split_peak = BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS
+
+    def line(f, peak):
+        if not f["launches"] or f["ms"] <= 0:
+            return None
+        a = f["flops"] / (f["ms"] * 1e-3) / 1e12
+        return {"launches_per_step": f["launches"], "achieved": a, "peak": peak, "unit": "TFLOP/s", "frac": a / peak,
+                "flops_per_launch": f["flops"] / f["launches"], "avg_launch_ms": f["ms"] / f["launches"],
+                "algorithmic_bytes": f["bytes"] / f["launches"], "ms_per_step_serial": f["ms"]}
+    split_line, fp32_line = line(fam[2], split_peak), line(fam[1], FP32_MFMA_PEAK_TFLOPS)
+    if split_line and fam[2]["ms"] >= fam[1]["ms"]:
+        roof = dict(split_line)
+        roof.update({"bound": "mfma", "kernel": "conv_split_kernel (3x3 stride-1 convolutions, 1x1 from 1024 channels, fc6: float32 operands "
+                                                "split exactly into 3 bf16 planes, 6 v_mfma_f32_32x32x16_bf16 per term, float32 accumulate)",
+                     "peak_note": "2500 TFLOP/s dense bf16 / 6 MFMA products per float32 term; `achieved` counts float32 (algorithmic) "
+                                  "FLOPs, the matrix cores execute 6x that in bf16",
+                     "executed_bf16_tflops": SPLIT_PRODUCTS * split_line["achieved"], "peak_bf16": BF16_MFMA_PEAK_TFLOPS,
+                     "fp32_mfma_kernels": fp32_line})
+    else:
+        roof = dict(fp32_line or {})
+        roof.update({"bound": "mfma", "kernel": "conv_igemm_kernel / conv_p3_kernel (v_mfma_f32_16x16x4_f32)", "split_kernel": split_line})
+    roof["measurement"] = ("HIP events around every launch of one pass of the step's conv programs, serial on one stream "
+                           "(pp_net_profile), median of 3 passes; outside the timed region")
+    roof["algorithmic_bytes_note"] = ("per launch: every conv operand (input, weights, bias, residuals) read once and every output "
+                                      "written once, float32; `traffic` / this = the re-read factor")
+    return roof
+
+
+DTYPE_NOTE = ("; eligible float32 convolutions are evaluated as exact 3-way bf16 splits on the bf16 matrix cores with float32 "
+              "accumulation (float32-accurate, not bit-identical: tests/test_gpu_split.py)")
 
 
 class Dist:
@@ -283,12 +345,40 @@ def run_cascade(args, D):
         flops_conv = flops_step
     achieved = flops_conv / (conv_ms * 1e-3) / 1e12
     traffic, traffic_note = pmc_traffic("cascade_chunk%d_persons%d" % (B, P))
-    alg_bytes = algorithmic_bytes(cas.detector.prog_a, B) + algorithmic_bytes(cas.detector.prog_b, B * cas.detector.MAX_ROIS) + \
-        (0 if vit else algorithmic_bytes(cas.pose_net.prog, 2 * B * P))
+    # per kernel family, measured live (outside the timed region) with HIP events around every launch of one pass of the conv
+    # programs at the step's batch sizes, on one stream
+    progs = [(cas.detector.net_a, B), (cas.detector.net_b, B * cas.detector.MAX_ROIS)] + ([] if vit else [(cas.pose_net, 2 * B * P)])
+    fam = kernel_families(progs)
+    programs = {"achieved": achieved, "launches_per_step": n_launch, "avg_launch_ms": conv_ms / n_launch,
+                "note": "all conv programs of the step inside the timed region (4 HIP streams): FLOPs / wall time of the programs",
+                "serial": {"avg_launch_ms": serial_conv_ms / n_launch, "achieved": flops_conv / (serial_conv_ms * 1e-3) / 1e12,
+                           "note": "same step, one stream (pp_net_set_lanes 0): comparable with rocprofv3 --stats AverageNs "
+                                   "of profiles/*_serial_kernel_stats.csv"}}
+    roof = roofline_families(fam)
+    roof.update({"traffic": traffic, "traffic_source": traffic_note, "stage_ms": stage, "conv_programs": programs})
+    # the same workload on the bit-exact float32-MFMA kernels only (pp_conv_exact(1)): reported beside `value` (N = 1 leg)
+    exact_mode = None
+    if D.world == 1:
+        _lib.check(ctx.lib.pp_conv_exact(1), "pp_conv_exact")
+        step()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        n_exact = max(2, K // 2)
+        for _ in range(n_exact):
+            step()
+        ctx.synchronize()
+        dt_exact = time.perf_counter() - t0
+        _lib.check(ctx.lib.pp_conv_exact(-1), "pp_conv_exact")
+        exact_mode = {"value": B * n_exact / dt_exact, "unit": "frames/s", "steps": n_exact,
+                      "note": "POSEPIPE_CONV_EXACT=1 / pp_conv_exact(1): every convolution on v_mfma_f32_16x16x4_f32, results "
+                              "bit-identical to oracle/conv_ref.c"}
     out = {
         "metric": METRIC, "value": D.world * B * K / dt, "unit": "frames/s", "n_gpus": D.world, "steps": K,
         "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (detector, lifting) + bf16 (ViT encoder)" if vit else "f32", "data": "synthetic",
+        "vs_baseline": None,
+        "dtype": ("f32 (detector, lifting) + bf16 (ViT encoder)" if vit else "f32") +
+                 DTYPE_NOTE + "; `bit_exact_mode` = the same step on the float32 MFMA kernels only",
+        "data": "synthetic",
         "config": {"workload": ("configs[4]-style cascade on one GPU per rank: 1080p detect (Faster-RCNN R50-FPN) -> SORT -> "
                                 "ViTPose-H 256x192 (bf16 MFMA encoder) flip_test + UDP decode -> VideoPose3D 243-frame lifting") if vit else
                                ("configs[3] on one GPU per rank: 1080p detect (Faster-RCNN R50-FPN) -> SORT -> HRNet-W48 "
@@ -296,20 +386,8 @@ def run_cascade(args, D):
                    "frames_per_step_per_gpu": B, "persons_per_frame": P,
                    "gflop_per_frame": flops_step / B / 1e9,
                    "detector_boxes": "detector runs on every frame; downstream boxes are replayed synthetic GT (random-weight detector)"},
-        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (%d launches per step: detector image + RoI-head programs, HRNet-W48)" % n_launch,
-                     "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": traffic, "traffic_source": traffic_note,
-                     "algorithmic_bytes": alg_bytes / n_launch,
-                     "algorithmic_bytes_note": "per launch: every conv operand (input, weights, bias, residuals) read once and "
-                                               "every output written once, float32; `traffic` / this = the re-read factor",
-                     "flops_per_launch": flops_conv / n_launch, "avg_launch_ms": conv_ms / n_launch, "stage_ms": stage,
-                     "launch_overlap": "programs run on 4 HIP streams; avg_launch_ms = wall time of the conv programs / launches "
-                                       "(rocprof per-kernel durations overlap and sum to more)",
-                     "serial": {"avg_launch_ms": serial_conv_ms / n_launch,
-                                "achieved": flops_conv / (serial_conv_ms * 1e-3) / 1e12,
-                                "note": "same step, one stream (pp_net_set_lanes 0): comparable with rocprofv3 --stats AverageNs "
-                                        "of profiles/*_serial_kernel_stats.csv"}},
+        "roofline": roof,
+        "bit_exact_mode": exact_mode,
     }
     if D.world > 1:
         out["per_rank_ms_per_step"] = per_rank
@@ -335,7 +413,6 @@ def run_cascade(args, D):
                                          "staging buffers by a reader thread and uploaded on a copy stream while the previous "
                                          "chunk computes (posepipeline_amd/streaming.py)" % n_seen}
     if vit:
-        out["roofline"]["kernel"] = out["roofline"]["kernel"].replace(", HRNet-W48", "")
         out["roofline"]["vit_stage"] = {"backbone_ms": stage["pose_backbone"], "program_tflops": pose_flops / (stage["pose_backbone"] * 1e-3) / 1e12,
                                         "note": "ViTPose-H program (bf16 GEMMs + fp32 patch embedding / head); roofline line: --workload c5"}
     n_cpu = 1 if args.cpu_frames is None else args.cpu_frames
@@ -402,6 +479,11 @@ def run_cascade_sharded(args, D, ctx, cas):
     }), flush=True)
 
 
+def _lib_check(rc):
+    if rc != 0:
+        raise RuntimeError("libposepipe_hip call failed: %d" % rc)
+
+
 def cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frame_bgr, gt_box, cas, ctx):
     """CPU restatement of the reference wrapper path (oracle/) for ONE 1080p frame: detector, then the
     top-down stage on the frame's (replayed) person box, then one 243-frame lifting window -- the per-frame bodies of
@@ -426,17 +508,25 @@ def cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frame_bgr, gt_box, cas, ctx):
     kn = normalize_screen_coordinates(kp[:, :, :2].astype(np.float64), 1920, 1080).astype(np.float32)
     k3 = onets.VideoPose3DRef(lift_sd).forward(onets.videopose3d_windows(kn, 121))
     dt = time.perf_counter() - t0
-    # the same frame through the GPU path (detector boxes NOT replayed) for a parity readout
-    g = cas.detector.run(frame_bgr[None])[0]
-    kg, _ = cas.topdown.run(frame_bgr[None], np.zeros(1, np.int32), bb[None])
+    # the same frame through the GPU path (detector boxes NOT replayed) for a parity readout: on the bit-exact kernels and on
+    # the default (bf16-split) kernels
     from posepipeline_amd.wrappers.videopose3d import lift
-    k3g = lift(cas.lift_net, cas.lift_spec, normalize_screen_coordinates(kg[:, :, :2].astype(np.float64), 1920, 1080))
+    readout = {}
+    for mode, exact in (("bit_exact_mode", 1), ("default", -1)):
+        _lib_check(ctx.lib.pp_conv_exact(exact))
+        g = cas.detector.run(frame_bgr[None])[0]
+        kg, _ = cas.topdown.run(frame_bgr[None], np.zeros(1, np.int32), bb[None])
+        k3g = lift(cas.lift_net, cas.lift_spec, normalize_screen_coordinates(kg[:, :, :2].astype(np.float64), 1920, 1080))
+        same_n = g.shape == dets.shape
+        readout[mode] = {"detections_equal": bool(same_n and np.array_equal(g, dets)),
+                         "max_abs_diff_boxes_px": float(np.abs(g[:, :4] - dets[:, :4]).max()) if same_n and len(g) else None,
+                         "max_abs_diff_2d_px": float(np.abs(kg[0, :, :2] - kp[0, :, :2]).max()),
+                         "max_abs_diff_3d": float(np.abs(k3g - k3).max())}
+    _lib_check(ctx.lib.pp_conv_exact(-1))
     return {"value": 1.0 / dt, "unit": "frames/s", "cores": clib.N_THREADS, "kind": "port",
             "sample": "1 synthetic 1080p frame through the CPU restatement of detect + top-down 2D (W48, flip) + one lifting window "
                       "(%.1f s, detector %.1f s)" % (dt, t_det),
-            "parity_vs_gpu": {"detections_equal": bool(g.shape == dets.shape and np.array_equal(g, dets)),
-                              "max_abs_diff_2d_px": float(np.abs(kg[0, :, :2] - kp[0, :, :2]).max()),
-                              "max_abs_diff_3d": float(np.abs(k3g - k3).max())}}
+            "parity_vs_gpu": readout}
 
 
 def run_c2(args, D):
@@ -479,14 +569,15 @@ def run_c2(args, D):
     out = {
         "metric": METRIC, "value": D.world * n * args.steps / dt, "unit": "frames/s", "n_gpus": D.world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32" + DTYPE_NOTE, "data": "synthetic",
         "config": {"workload": "configs[1]: HRNet-W32 256x192 top-down 2D, pre-cropped persons, flip_test, decode 'default'",
                    "frames_per_step_per_gpu": n, "backbone_samples_per_step": 2 * n,
                    "not_in_this_line": "detector, tracker, 3D lifting (see --workload cascade)"},
-        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (all %d conv launches of the backbone program)" % n_launch,
-                     "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": pmc_traffic("c2_batch%d" % n)[0], "algorithmic_bytes": algorithmic_bytes(prog, 2 * n) / n_launch,
-                     "flops_per_launch": flops_step / n_launch, "avg_launch_ms": net_ms / n_launch,
+        "roofline": {**roofline_families(kernel_families([(net, 2 * n)])),
+                     "traffic": pmc_traffic("c2_batch%d" % n)[0],
+                     "program": {"achieved": achieved, "launches": n_launch, "flops_per_launch": flops_step / n_launch,
+                                 "avg_launch_ms": net_ms / n_launch,
+                                 "note": "whole backbone program inside the timed region (4 HIP streams): FLOPs / wall time"},
                      "stage_ms": {"pre": t_pre / args.steps, "backbone": net_ms, "decode": t_dec / args.steps}},
     }
     n_cpu = 6 if args.cpu_frames is None else args.cpu_frames
@@ -518,9 +609,6 @@ def cpu_baseline_c2(sd, x, cs, kp_gpu):
     return {"value": m / dt, "unit": "frames/s", "cores": clib.N_THREADS, "kind": "port",
             "sample": "%d of the same pre-cropped frames, batch-1 loop, C/OpenMP fmaf-chain convs + numpy decode (%.1f s)" % (m, dt),
             "max_abs_diff_px_vs_gpu": float(np.abs(np.array(kps) - kp_gpu[:m]).max())}
-
-
-BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def run_c5(args, D):

@@ -36,7 +36,7 @@ extern "C" {
                               4: pp_memcpy_d2d, pp_net_create_mem (weights already on the device, e.g. an RCCL broadcast)
                               5: pp_buf.pad (zero halo of conv-only buffers), PP_OP_AVGPOOL, pp_crop_resize_bilinear,
                                  pp_conv_force / pp_conv_variant
-                              6: pp_conv_exact; pp_conv_variant accepts 4 (fp32 convolutions on the bf16 matrix cores by a
+                              6: pp_conv_exact, pp_net_conv_kinds; pp_conv_variant accepts 4 (fp32 convolutions on the bf16 matrix cores by a
                                  three-way operand split are the default where a layer is eligible) */
 
 typedef enum {
@@ -181,6 +181,10 @@ int pp_net_set_lanes(pp_net* net, int enable);
 int pp_net_capture(pp_net* net, int batch);
 /* per-op elapsed time of the last profiled run (HIP events around each op), ms; NULL-safe */
 int pp_net_profile(pp_net* net, int batch, float* ms_per_op);
+/* which kernel family each op launches under the CURRENT numerics setting: 0 = not a convolution, 1 = float32 MFMA kernels
+ * (conv_igemm*.hip), 2 = bf16-split kernel (conv_split.hip).  kinds: n_ops ints.  (bench.py prices the two families
+ * against their own peaks.) */
+int pp_net_conv_kinds(pp_net* net, int* kinds);
 
 /* Tile configuration of the convolution kernel for all later launches of this process: ct = output-channel tile / 16
  * (1..4), pt = pixel tile / 64 (1, 2); 0 = automatic (posepipeline_amd/conv_tuning.txt, then the built-in heuristic).

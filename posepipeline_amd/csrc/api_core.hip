@@ -531,6 +531,19 @@ int pp_net_create_mem(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bu
     return PP_OK;
 }
 
+int pp_net_conv_kinds(pp_net* net, int* kinds) {
+    PP_REQUIRE(net && kinds, "pp_net_conv_kinds: NULL argument");
+    const bool split = pp_conv_split_enabled();
+    for (size_t i = 0; i < net->ops.size(); ++i) {
+        if (net->ops[i].type != PP_OP_CONV) {
+            kinds[i] = 0;
+            continue;
+        }
+        kinds[i] = (split && net->wsplit && net->wsplit_off[i] >= 0) ? 2 : 1;
+    }
+    return PP_OK;
+}
+
 void pp_net_destroy(pp_net* net) {
     if (!net) return;
     if (net->ctx && net->ctx->stream) (void)hipStreamSynchronize(net->ctx->stream);

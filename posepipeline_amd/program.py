@@ -414,6 +414,12 @@ class Net:
         self.ctx.d2h(out, dptr)
         return out
 
+    def conv_kinds(self) -> np.ndarray:
+        """per op: 0 not a conv, 1 float32 MFMA kernels, 2 bf16-split kernel (under the current pp_conv_exact setting)"""
+        kinds = np.zeros(len(self.prog.ops), dtype=np.int32)
+        L.check(self.ctx.lib.pp_net_conv_kinds(self.handle, L.ptr(kinds)), "pp_net_conv_kinds")
+        return kinds
+
     def profile(self, batch) -> np.ndarray:
         ms = np.zeros(len(self.prog.ops), dtype=np.float32)
         L.check(self.ctx.lib.pp_net_profile(self.handle, batch, L.ptr(ms)), "pp_net_profile")
