@@ -39,7 +39,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
 
-constexpr int PXB = 2;   // pixel blocks (32 pixels) per wave
 
 struct SplitArgs {
     const float* x;
@@ -114,8 +113,10 @@ __device__ __forceinline__ void block_pixel(int r, int bw_log2, int& iy, int& ix
 //             the launcher as 1x1 over 49 x 256 channels): tile = 256 consecutive output pixels, one "tap"
 enum { MODE_TILE = 0, MODE_STREAM = 1, MODE_GEMM = 2 };
 
-// COB: output-channel blocks (32 channels) per wave and per workgroup
-template <int T, int NSLOT, int COB>
+// COB: output-channel blocks (32 channels) per wave and per workgroup; PXB: pixel blocks (32 pixels) per wave.  PXB = 1
+// (128-pixel tiles, ~150 registers, three workgroups per CU) was measured for the layers whose grid does not fill the chip
+// twice: 24x18 x 192 channels +9 %, 12x9 x 384 -20 %, 40x68 x 256 -17 % alone; no gain in the 4-stream program -- not instantiated.
+template <int T, int NSLOT, int COB, int PXB = 2>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
         x0 = tx * a.TW;
         y0 = ty * a.TH;
     } else {
-        s0 = (long long)L * 256;
+        s0 = (long long)L * (128 * PXB);
     }
 
     // ---- patch loader: slot j of this thread = (patch pixel p, channel quad) -----------------------------------------
@@ -273,23 +274,16 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
 #pragma unroll
     for (int pb = 0; pb < PXB; ++pb) load_x(smem, 0, pb);
 
-    // the six products with i + j <= 2 of one (channel block, pixel block) pair, smallest terms first; `half`: 0 / 1 = the first /
-    // last three, -1 = all six
-    auto mma = [&](const uint4 (&wc)[COB][3], int cb, int pb, int half) {
-        f32x16 c = acc[cb][pb];
-        auto W = [&](int i) { return __builtin_bit_cast(bf16x8, wc[cb][i]); };
-        auto X = [&](int i) { return __builtin_bit_cast(bf16x8, xf[pb][i]); };
-        if (half != 1) {
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(2), X(0), c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(1), X(1), c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(2), c, 0, 0, 0);
-        }
-        if (half != 0) {
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(1), X(0), c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(1), c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W(0), X(0), c, 0, 0, 0);
-        }
-        acc[cb][pb] = c;
+    // the six products with i + j <= 2 (smallest terms first) of one pixel block against every channel block; consecutive MFMAs
+    // go to different accumulators (no back-to-back dependency on the matrix pipe)
+    auto mma = [&](const uint4 (&wc)[COB][3], int pb) {
+        constexpr int WI[6] = {2, 1, 0, 1, 0, 0}, XI[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb)
+                acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wc[cb][WI[p]]),
+                                                                      __builtin_bit_cast(bf16x8, xf[pb][XI[p]]), acc[cb][pb], 0, 0, 0);
     };
 
     // One 16-channel chunk: T steps.  Weights of step s + 1 are requested (global -> the other register set) before the MFMAs of
@@ -309,8 +303,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
                 // (branched) region: interleaving it with the MFMAs costs ~30 registers (spills with 7-8 patch slots) and
                 // measured slower -- the CU's other workgroup keeps the matrix pipe busy meanwhile
                 if (pb == PXB - 1 && t == T / 2 && c + 1 < a.nchunks) store_patch((c + 1) & 1, 0, NSLOT);
-#pragma unroll
-                for (int cb = 0; cb < COB; ++cb) mma(wf[cur], cb, pb, -1);
+                mma(wf[cur], pb);
                 __builtin_amdgcn_sched_barrier(0);
                 if (t + 1 < T) load_x(pbuf, t + 1, pb);
                 __builtin_amdgcn_sched_barrier(0);
@@ -412,18 +405,19 @@ struct TileGeom {
 };
 
 // the 256-pixel tile shape (8 blocks of 32 pixels) that wastes the fewest pixels on this map
-TileGeom pick_tile(int H, int W, double big_patch_factor) {
+TileGeom pick_tile(int H, int W, double big_patch_factor, int pxb) {
     static const int force = env_int("POSEPIPE_SPLIT_TILE", -1);
     TileGeom best{};
     best.eff = -1.0;
-    // (bw_log2, gx_log2): 8x32, 4x64, 16x16, 32x8
+    // (bw_log2, gx_log2): 8x32, 4x64, 16x16, 32x8 pixel tiles (pxb = 2); 4x32, 2x64, 8x16, 16x8 (pxb = 1)
     const int cand[4][2] = {{0, 0}, {0, 1}, {1, 0}, {2, 0}};
+    const int nblk = 4 * pxb;
     for (int i = 0; i < 4; ++i) {
         if (force >= 0 && i != force) continue;
         TileGeom g{};
         g.bw_log2 = cand[i][0];
         g.gx_log2 = cand[i][1];
-        const int BW = 32 >> g.bw_log2, BH = 1 << g.bw_log2, GX = 1 << g.gx_log2, GY = 8 / GX;
+        const int BW = 32 >> g.bw_log2, BH = 1 << g.bw_log2, GX = 1 << g.gx_log2, GY = nblk / GX;
         g.TW = GX * BW;
         g.TH = GY * BH;
         g.PWp = g.TW + 2;
@@ -434,7 +428,7 @@ TileGeom pick_tile(int H, int W, double big_patch_factor) {
         while (g.NPp % 8 != 4) ++g.NPp;       // half planes 64 B apart mod 128: conflict-free ds_write_b64
         g.tiles_x = (W + g.TW - 1) / g.TW;
         g.tiles_y = (H + g.TH - 1) / g.TH;
-        g.eff = (double)H * W / ((double)g.tiles_x * g.tiles_y * 256.0) * (g.NP > 384 ? big_patch_factor : 1.0) - 1e-4 * g.NP / 256.0;
+        g.eff = (double)H * W / ((double)g.tiles_x * g.tiles_y * 128.0 * pxb) * (g.NP > 384 ? big_patch_factor : 1.0) - 1e-4 * g.NP / 256.0;
         if (g.eff > best.eff) best = g;
     }
     return best;
@@ -510,27 +504,22 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     s.nchunks = cin / 16;
     s.x_bytes = a.x_bytes;
     s.xcd_remap = a.xcd_remap;
+    const int cob = (s.ncb & 1) ? 1 : 2;
+    static const int stream_env = env_int("POSEPIPE_SPLIT_STREAM", -1);
     unsigned gx = 0;
-    int nslot = 0;
     if (mode == MODE_GEMM) {
         s.mode = MODE_GEMM;
         s.S = (long long)a.M;
         s.NP = 256;
         s.NPp = 260;
         gx = (unsigned)((a.M + 255) / 256);
-        nslot = 4;
     } else {
-        // two channel blocks per wave leave registers for 6 patch slots (384 pixels); beyond, ~20 registers spill (measured cost: a
-        // few percent, less than a badly quantised tile)
-        const double big = 1.0;
-        const int max_np = 512;
-        const TileGeom g = pick_tile(a.Hout, a.Wout, big);
-        static const int stream_env = env_int("POSEPIPE_SPLIT_STREAM", -1);
+        const TileGeom g = pick_tile(a.Hout, a.Wout, 1.0, 2);
         const int snp = 258 + 2 * s.xp_w;
-        const double stream_eff = (double)a.Hout * a.Wout / ((double)s.xp_h * s.xp_w) * (snp > 384 ? big : 1.0);
-        bool use_stream = a.x_pad >= 1 && snp <= max_np && stream_eff > g.eff + 0.02;
+        const double stream_eff = (double)a.Hout * a.Wout / ((double)s.xp_h * s.xp_w);
+        bool use_stream = a.x_pad >= 1 && snp <= 512 && stream_eff > g.eff + 0.02;
         if (stream_env == 0) use_stream = false;
-        if (stream_env == 1 && a.x_pad >= 1 && snp <= max_np) use_stream = true;
+        if (stream_env == 1 && a.x_pad >= 1 && snp <= 512) use_stream = true;
         if (use_stream) {
             s.mode = MODE_STREAM;
             s.PWp = s.xp_w;
@@ -545,9 +534,8 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
             s.PWp = g.PWp; s.NP = g.NP; s.NPp = g.NPp;
             gx = (unsigned)(g.tiles_x * g.tiles_y * a.N);
         }
-        nslot = (s.NP * 4 + 255) / 256;
     }
-    const int cob = (s.ncb & 1) ? 1 : 2;
+    const int nslot = (s.NP + 63) / 64;          // exactly: only the last patch slot of a thread can be partly outside the patch
     const dim3 grid(gx, (unsigned)(s.ncb / cob));
     const size_t lds = (size_t)2 * 3 * 2 * s.NPp * 16;
 #define PP_SPLIT_LAUNCH(T_, NS_)                                                                                        \

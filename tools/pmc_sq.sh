@@ -12,17 +12,18 @@ timeout 900 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIV
 python - <<'PY' > $O/summary.txt 2>&1
 import csv, glob, os
 O = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out/pmc_sq")
+KERNEL = os.environ.get("PMC_KERNEL", "conv_split_kernel")
 tot = {}
 n = {}
 for p in ("p1", "p2", "p3"):
     for path in glob.glob(os.path.join(O, p, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(path, newline="")):
-            if "conv_igemm_kernel" not in row["Kernel_Name"]:
+            if KERNEL not in row["Kernel_Name"]:
                 continue
             k = row["Counter_Name"]
             tot[k] = tot.get(k, 0.0) + float(row["Counter_Value"])
             n[k] = n.get(k, 0) + 1
-print("# SQ counters summed over all conv_igemm_kernel launches of: python bench.py --steps 2 --warmup 1 --cpu-frames 0 (cascade, 32 frames/step)")
+print(f"# SQ counters summed over all {KERNEL} launches of: python bench.py --steps 2 --warmup 1 --cpu-frames 0 (cascade, 32 frames/step)")
 for k in sorted(tot):
     print(f"{k:32s} {tot[k]:.4e}  over {n[k]} launches")
 g = tot.get
