@@ -355,6 +355,184 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
     }
 }
 
+// ---- 1x1 / full-cover layers with >= 128 output channels: 8 waves, 256 x 256 (or 512 x 128) output tile --------------------------
+// A product Y[M][N] = X[M][K] W[K][N] moves 4 / (2 BN) bytes of X and 6 / (2 BM) bytes of split W per float32 FLOP through the
+// vector memory path.  With the tap kernel's 256 x 64 tile that is 0.043 B/FLOP -- 10.7 TB/s at the 250 TFLOP/s the matrix pipes
+// could do, and the measured ~115 TFLOP/s of that form on ResNet's 1x1 layers is exactly ~5 TB/s of it.  A 256 x 256 tile needs
+// 0.0195 B/FLOP, which takes 128 accumulator registers per lane: 8 waves (wave tile 128 pixels x 64 channels), one workgroup per
+// CU, BOTH operands staged through LDS (X split once per workgroup and shared by the waves along N, W copied verbatim in fragment
+// order and shared by the waves along M), two LDS stages of 16 input channels, one barrier per stage (3072 matrix-pipe cycles).
+template <int WM, int WN>
+__global__ __launch_bounds__(512, 1) void conv_split_gemm_kernel(SplitArgs a) {
+    constexpr int BM = 128 * WM, BN = 64 * WN;
+    constexpr int XS = BM * 4 / 512;                 // float4 patch slots per thread and stage
+    constexpr int WU = BN * 6;                       // 16-byte units of split weights per stage: BN / 32 blocks x 3 planes x 64 lanes
+    constexpr int NPp = BM + 4;
+    constexpr int XPLANE = 2 * NPp * 16;
+    constexpr int XBYTES = 3 * XPLANE, STAGE = XBYTES + WU * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const int cbB = blockIdx.y * (BN / 32);          // first channel block of the workgroup
+    const int cb0 = cbB + wn * 2;                    // ... of this wave
+
+    // ---- loaders -------------------------------------------------------------------------------------------------------------
+    unsigned goff[XS];
+#pragma unroll
+    for (int j = 0; j < XS; ++j) {
+        const int u = tid + 512 * j;
+        const long long m = m0 + (u >> 2);
+        unsigned off = 0xffffffffu;
+        if (m < a.S) {
+            const int img = (int)(m / (a.H * a.W)), rem = (int)(m - (long long)img * (a.H * a.W));
+            const int ho = rem / a.W, wo = rem - ho * a.W;
+            off = (unsigned)(((img * a.xp_h + ho * a.stride) * a.xp_w + wo * a.stride) * a.Cin) * 4u + (unsigned)(u & 3) * 16u;
+        }
+        goff[j] = off;
+    }
+    const int woff0 = ((((tid & 3) >> 1) * NPp + (tid >> 2)) * 16 + (tid & 1) * 8);      // + 2048 j: 128 pixels further
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+    const size_t wstep = (size_t)a.ncb * 192;
+    float4 xr[XS];
+    auto load_x = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < XS; ++j) {
+            const unsigned off = goff[j] == 0xffffffffu ? 0xffffffffu : goff[j] + (unsigned)c * 64u;
+            xr[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+        }
+    };
+    auto store_x = [&](int buf) {
+        unsigned char* base = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < XS; ++j) {
+            uint2 p0, p1, p2;
+            split4(xr[j], p0, p1, p2);
+            unsigned char* d = base + woff0 + 2048 * j;
+            *reinterpret_cast<uint2*>(d) = p0;
+            *reinterpret_cast<uint2*>(d + XPLANE) = p1;
+            *reinterpret_cast<uint2*>(d + 2 * XPLANE) = p2;
+        }
+    };
+    // split weights of a stage: copied verbatim global -> LDS by the DMA path (global_load_lds_dwordx4: no staging registers, no
+    // ds_write); wave w moves the 1 KB fragments w, w + 8, ... of the stage's BN / 32 x 3 fragments
+    constexpr int NSLAB = WU / 64;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    auto issue_w = [&](int c, int buf) {
+        const uint4* src = a.w + (size_t)c * wstep + (size_t)cbB * 192 + lane;
+#pragma unroll
+        for (int i = 0; i < (NSLAB + 7) / 8; ++i) {
+            const int slab = i * 8 + wave;
+            if (NSLAB % 8 == 0 || slab < NSLAB)
+            {
+                // raw instruction: through the builtin the compiler treats the DMA as a possible alias of EVERY later LDS read and
+                // inserts s_waitcnt vmcnt(0) in front of the stage's first ds_read (the DMA writes the OTHER stage; completion is
+                // awaited explicitly before the barrier below)
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * STAGE + XBYTES + slab * 1024));
+                const uint4* g = src + slab * 64;
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory", "m0");
+            }
+        }
+    };
+
+    const int xofs = ((lane >> 5) * NPp + wm * 128 + (lane & 31)) * 16;                 // + plane * XPLANE + pb * 512
+    const int wofs = XBYTES + ((wn * 2) * 192 + lane) * 16;                             // + (cb * 3 + plane) * 1024
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
+
+    // vmcnt counts in issue order: a stage issues its weight DMA first and its pixel loads (for the stage after next) after it, so
+    // "all but the XS youngest" = the DMA has landed while the pixel loads keep flying across the barrier
+    issue_w(0, 0);
+    load_x(0);
+    store_x(0);
+    if (a.nchunks > 1) load_x(1);
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XS) : "memory");
+    if (a.nchunks <= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    for (int c = 0; c < a.nchunks; ++c) {
+        const unsigned char* sb = smem + (c & 1) * STAGE;
+        uint4 wf[2][3], xf[2][3];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wf[cb][pl] = *reinterpret_cast<const uint4*>(sb + wofs + (cb * 3 + pl) * 1024);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) xf[0][pl] = *reinterpret_cast<const uint4*>(sb + xofs + pl * XPLANE);
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            if (pb < 3) {
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) xf[(pb + 1) & 1][pl] = *reinterpret_cast<const uint4*>(sb + xofs + pl * XPLANE + (pb + 1) * 512);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the next stage's pixels (loaded during the previous stage) are split and written to the other buffer in the shadow
+            // of the MFMAs; then its weights are requested (DMA) and the pixels of the stage after it -- in this order: the
+            // compiler's vmcnt bookkeeping does not see the raw DMA, so nothing it waits for may be older than an in-flight DMA
+            if (pb == 1 && c + 1 < a.nchunks) {
+                store_x((c + 1) & 1);
+                issue_w(c + 1, (c + 1) & 1);
+                if (c + 2 < a.nchunks) load_x(c + 2);
+            }
+            constexpr int WI[6] = {2, 1, 0, 1, 0, 0}, XI[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+            for (int p = 0; p < 6; ++p)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+                    acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[cb][WI[p]]),
+                                                                          __builtin_bit_cast(bf16x8, xf[pb & 1][XI[p]]), acc[cb][pb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c + 2 < a.nchunks)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XS) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- epilogue (as conv_split_kernel) -----------------------------------------------------------------------------------------
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) {
+        const long long m = m0 + wm * 128 + pb * 32 + (lane & 31);
+        if (m >= a.S) continue;
+        const int img = (int)(m / (a.H * a.W)), rem = (int)(m - (long long)img * (a.H * a.W));
+        const int oy = rem / a.W, ox = rem - oy * a.W;
+        const size_t ypix = ((size_t)img * (a.H + a.y_pad) + oy) * (a.W + a.y_pad) + ox;
+        const size_t r1pix = ((size_t)img * (a.H + a.r1_pad) + oy) * (a.W + a.r1_pad) + ox;
+        const size_t r2pix = ((size_t)img * (a.H + a.r2_pad) + oy) * (a.W + a.r2_pad) + ox;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = (cb0 + cb) * 32 + 8 * g + 4 * (lane >> 5);
+                if (co >= a.Cout) continue;
+                const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
+                const f32x16 cc = acc[cb][pb];
+                float4 v = make_float4(cc[4 * g + 0] + b4.x, cc[4 * g + 1] + b4.y, cc[4 * g + 2] + b4.z, cc[4 * g + 3] + b4.w);
+                if (a.relu == PP_RELU_FIRST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (a.res1) {
+                    const float4 r = *reinterpret_cast<const float4*>(a.res1 + r1pix * a.Cout + co);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (a.res2) {
+                    const float4 r = *reinterpret_cast<const float4*>(a.res2 + r2pix * a.Cout + co);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(a.y + ypix * a.Cout + co) = v;
+            }
+        }
+    }
+}
+
 // ---- weight split: float32 blob rows ([K / 32][CoutPad][32], pack_conv order) -> fragment order, three bf16 planes ---------
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* w, uint4* out, int Cin, int taps, int CoutPad, int ncb,
                                                             size_t total) {
@@ -450,15 +628,25 @@ static bool split_shape(const ConvArgs& a, int* taps, int* cin, int* mode) {
     return true;
 }
 
+// 8-wave product kernel for 1x1 / full-cover layers: 1 = 256 x 256 tile (Cout % 256 == 0), 2 = 512 x 128 (Cout % 128 == 0), 0 = no
+static int gemm8_cfg(const ConvArgs& a, int mode, int cin) {
+    // Measured (profiles/r02_conv_split_layers.txt, 32 frames): fc6 (K = 12544) 130 (fp32 kernel) -> 216 TFLOP/s, fc7 126 -> 171,
+    // 1024 -> 256 at 40x68 126 -> 155, 512 -> 256 at 80x136 120 -> 139; a tie at 256 input channels (256 -> 1024: 109 / 110) and a
+    // loss below (64 -> 256: 63 -> 55, 128 -> 512: 87 -> 79: four or eight 16-channel stages do not amortise a 256 x 256 tile's
+    // start-up and 256 KB epilogue at one workgroup per CU).  Hence: from 512 input channels.
+    static const int on = env_int("POSEPIPE_SPLIT_GEMM8", 1), min_c = env_int("POSEPIPE_SPLIT_GEMM8_MIN_C", 512);
+    if (!on || mode != MODE_GEMM || cin < min_c) return 0;
+    return a.Cout % 256 == 0 ? 1 : a.Cout % 128 == 0 ? 2 : 0;
+}
+
 bool pp_conv_split_eligible(const ConvArgs& a) {
     const bool res1_plain = !a.res1 || (a.res1_shift == 0 && a.res1_off_w == 0 && a.res1_H == a.Hout && a.res1_W == a.Wout);
     int taps, cin, mode;
-    // 1x1 layers: the split kernel wins from ~1024 input channels (fc6 / fc7 of the RoI head +12 %, ResNet's 1024 -> 256 +3..6 %);
-    // below, the layers are bound by their tile count or by HBM and the fp32 kernel's smaller tiles do as well or better
-    // (profiles/r02_conv_split.txt).  POSEPIPE_SPLIT_GEMM_MIN_CIN overrides the threshold.
+    // 1x1 layers with Cout % 128 == 0: the 8-wave product kernel.  Others: the tap kernel's one-tap form wins from ~1024 input
+    // channels only (its 256 x 64 tile re-reads X Cout / 64 times; below, the fp32 kernel's smaller tiles do as well or better).
     static const int gemm_min_cin = env_int("POSEPIPE_SPLIT_GEMM_MIN_CIN", 1024);
     if (!split_shape(a, &taps, &cin, &mode)) return false;
-    if (mode == MODE_GEMM && cin < gemm_min_cin) return false;
+    if (mode == MODE_GEMM && cin < gemm_min_cin && !gemm8_cfg(a, mode, cin)) return false;
     return cin % 16 == 0 && a.Cout % 4 == 0 && a.up_log2 == 0 && !a.out_nchw && res1_plain && a.relu <= PP_RELU_FIRST &&
            (a.y_stride == 0 || a.y_stride == a.Cout) && a.y_coff == 0;
 }
@@ -504,6 +692,28 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     s.nchunks = cin / 16;
     s.x_bytes = a.x_bytes;
     s.xcd_remap = a.xcd_remap;
+    if (const int g8 = gemm8_cfg(a, mode, cin)) {
+        s.mode = MODE_GEMM;
+        s.S = (long long)a.M;
+        const int BM = g8 == 1 ? 256 : 512, BN = g8 == 1 ? 256 : 128;
+        const dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)(a.Cout / BN));
+        const size_t lds = (size_t)2 * (3 * 2 * (BM + 4) * 16 + BN * 6 * 16);
+        static std::once_flag once;
+        std::call_once(once, [] {
+            (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        });
+        if (g8 == 1)
+            hipLaunchKernelGGL((conv_split_gemm_kernel<2, 4>), grid, dim3(512), lds, stream, s);
+        else
+            hipLaunchKernelGGL((conv_split_gemm_kernel<4, 2>), grid, dim3(512), lds, stream, s);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            pp_set_error("conv_split_gemm launch failed: %s", hipGetErrorString(e));
+            return PP_ERR_HIP;
+        }
+        return PP_OK;
+    }
     const int cob = (s.ncb & 1) ? 1 : 2;
     static const int stream_env = env_int("POSEPIPE_SPLIT_STREAM", -1);
     unsigned gx = 0;
