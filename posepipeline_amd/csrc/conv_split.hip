@@ -362,10 +362,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
 // 0.0195 B/FLOP, which takes 128 accumulator registers per lane: 8 waves (wave tile 128 pixels x 64 channels), one workgroup per
 // CU, BOTH operands staged through LDS (X split once per workgroup and shared by the waves along N, W copied verbatim in fragment
 // order and shared by the waves along M), two LDS stages of 16 input channels, one barrier per stage (3072 matrix-pipe cycles).
+// WM x WN = 8 waves: one workgroup per CU; 4 waves (256 x 128 tile): two workgroups per CU, for layers with few 16-channel stages,
+// where one workgroup's start-up and epilogue hide under the other's K loop.
 template <int WM, int WN>
-__global__ __launch_bounds__(512, 1) void conv_split_gemm_kernel(SplitArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split_gemm_kernel(SplitArgs a) {
+    constexpr int NT = 64 * WM * WN, NWAVE = WM * WN;
     constexpr int BM = 128 * WM, BN = 64 * WN;
-    constexpr int XS = BM * 4 / 512;                 // float4 patch slots per thread and stage
+    constexpr int XS = BM * 4 / NT;                  // float4 patch slots per thread and stage
     constexpr int WU = BN * 6;                       // 16-byte units of split weights per stage: BN / 32 blocks x 3 planes x 64 lanes
     constexpr int NPp = BM + 4;
     constexpr int XPLANE = 2 * NPp * 16;
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_gemm_kernel(SplitArgs a) {
     unsigned goff[XS];
 #pragma unroll
     for (int j = 0; j < XS; ++j) {
-        const int u = tid + 512 * j;
+        const int u = tid + NT * j;
         const long long m = m0 + (u >> 2);
         unsigned off = 0xffffffffu;
         if (m < a.S) {
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_gemm_kernel(SplitArgs a) {
         }
         goff[j] = off;
     }
-    const int woff0 = ((((tid & 3) >> 1) * NPp + (tid >> 2)) * 16 + (tid & 1) * 8);      // + 2048 j: 128 pixels further
+    const int woff0 = ((((tid & 3) >> 1) * NPp + (tid >> 2)) * 16 + (tid & 1) * 8);      // + (NT / 4) * 16 j: NT / 4 pixels further
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
     const size_t wstep = (size_t)a.ncb * 192;
     float4 xr[XS];
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_gemm_kernel(SplitArgs a) {
         for (int j = 0; j < XS; ++j) {
             uint2 p0, p1, p2;
             split4(xr[j], p0, p1, p2);
-            unsigned char* d = base + woff0 + 2048 * j;
+            unsigned char* d = base + woff0 + (NT / 4) * 16 * j;
             *reinterpret_cast<uint2*>(d) = p0;
             *reinterpret_cast<uint2*>(d + XPLANE) = p1;
             *reinterpret_cast<uint2*>(d + 2 * XPLANE) = p2;
@@ -423,9 +426,9 @@ __global__ __launch_bounds__(512, 1) void conv_split_gemm_kernel(SplitArgs a) {
     auto issue_w = [&](int c, int buf) {
         const uint4* src = a.w + (size_t)c * wstep + (size_t)cbB * 192 + lane;
 #pragma unroll
-        for (int i = 0; i < (NSLAB + 7) / 8; ++i) {
-            const int slab = i * 8 + wave;
-            if (NSLAB % 8 == 0 || slab < NSLAB)
+        for (int i = 0; i < (NSLAB + NWAVE - 1) / NWAVE; ++i) {
+            const int slab = i * NWAVE + wave;
+            if (NSLAB % NWAVE == 0 || slab < NSLAB)
             {
                 // raw instruction: through the builtin the compiler treats the DMA as a possible alias of EVERY later LDS read and
                 // inserts s_waitcnt vmcnt(0) in front of the stage's first ds_read (the DMA writes the OTHER stage; completion is
@@ -633,9 +636,12 @@ static int gemm8_cfg(const ConvArgs& a, int mode, int cin) {
     // Measured (profiles/r02_conv_split_layers.txt, 32 frames): fc6 (K = 12544) 130 (fp32 kernel) -> 216 TFLOP/s, fc7 126 -> 171,
     // 1024 -> 256 at 40x68 126 -> 155, 512 -> 256 at 80x136 120 -> 139; a tie at 256 input channels (256 -> 1024: 109 / 110) and a
     // loss below (64 -> 256: 63 -> 55, 128 -> 512: 87 -> 79: four or eight 16-channel stages do not amortise a 256 x 256 tile's
-    // start-up and 256 KB epilogue at one workgroup per CU).  Hence: from 512 input channels.
-    static const int on = env_int("POSEPIPE_SPLIT_GEMM8", 1), min_c = env_int("POSEPIPE_SPLIT_GEMM8_MIN_C", 512);
-    if (!on || mode != MODE_GEMM || cin < min_c) return 0;
+    // start-up and 256 KB epilogue at one workgroup per CU).  Hence: from 512 input channels; at 256 input channels the 4-wave form
+    // (256 x 128 tile, two workgroups per CU: 256 -> 1024 97 -> 108, others even); below, the fp32 kernel (64 -> 256: 62 vs 47).
+    static const int on = env_int("POSEPIPE_SPLIT_GEMM8", 1), min_c = env_int("POSEPIPE_SPLIT_GEMM8_MIN_C", 512),
+                     min_c4 = env_int("POSEPIPE_SPLIT_GEMM4_MIN_C", 256);
+    if (!on || mode != MODE_GEMM) return 0;
+    if (cin < min_c) return (cin >= min_c4 && a.Cout % 128 == 0) ? 3 : 0;       // 3: 4 waves, 256 x 128 tile, two workgroups per CU
     return a.Cout % 256 == 0 ? 1 : a.Cout % 128 == 0 ? 2 : 0;
 }
 
@@ -695,18 +701,21 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     if (const int g8 = gemm8_cfg(a, mode, cin)) {
         s.mode = MODE_GEMM;
         s.S = (long long)a.M;
-        const int BM = g8 == 1 ? 256 : 512, BN = g8 == 1 ? 256 : 128;
+        const int BM = g8 == 2 ? 512 : 256, BN = g8 == 1 ? 256 : 128;
         const dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)(a.Cout / BN));
         const size_t lds = (size_t)2 * (3 * 2 * (BM + 4) * 16 + BN * 6 * 16);
         static std::once_flag once;
         std::call_once(once, [] {
             (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         });
         if (g8 == 1)
             hipLaunchKernelGGL((conv_split_gemm_kernel<2, 4>), grid, dim3(512), lds, stream, s);
-        else
+        else if (g8 == 2)
             hipLaunchKernelGGL((conv_split_gemm_kernel<4, 2>), grid, dim3(512), lds, stream, s);
+        else
+            hipLaunchKernelGGL((conv_split_gemm_kernel<2, 2>), grid, dim3(256), lds, stream, s);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             pp_set_error("conv_split_gemm launch failed: %s", hipGetErrorString(e));
