@@ -370,7 +370,7 @@ __device__ __forceinline__ int roi_level(float x1, float y1, float x2, float y2)
 // (Round 2 measured a locality order for the RoIs -- sorted by FPN level and Morton code of their centre, dealt out to the
 // XCDs in contiguous eighths or in runs of 25: 6.1 - 7.1 ms against 5.5 ms for the score order NMS leaves them in.  L2 hit
 // rate was not what bounds this kernel: with 58 % hits it already moves 63 GB through the L2s per launch (11 TB/s), and
-// concentrating the requests on one region makes them collide on the same L2 channels.  profiles/r02_roi_pmc.txt.)
+// concentrating the requests on one region makes them collide on the same L2 channels.  profiles/r02_roi_pmc_before.txt.)
 __global__ __launch_bounds__(256) void roi_align_kernel(FpnLevels L, int C, const float* __restrict__ rois,
                                                         const int32_t* __restrict__ n_rois, int max_rois, float* __restrict__ out) {
     // grid (max_rois, frames), block 256 = 4 waves x (C/4 = 64 lanes); out [frame*max_rois + r][7][7][C]
