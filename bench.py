@@ -290,10 +290,13 @@ def run_cascade(args, D):
     stage = dict(det_pre=0.0, det_image=0.0, det_rpn=0.0, det_roialign=0.0, det_roihead=0.0, det_final=0.0,
                  pose_pre=0.0, pose_backbone=0.0, pose_decode=0.0)
 
-    def step(accumulate=False):
-        res = cas.step(None, frames_dev=(dptr, B), replay=replay_boxes())
+    def step(accumulate=False, more=False):
+        # more: another step follows immediately -> its detector pass (same resident chunk) starts under this step's 2D / 3D
+        # stages on the detector's own stream (Cascade overlap_detector).  The last step of every timed / warm-up loop passes
+        # more=False, so each loop contains exactly as many detector passes as steps and nothing is carried across its ends.
+        res = cas.step(None, frames_dev=(dptr, B), replay=replay_boxes(), prefetch=(None, (dptr, B)) if more else None)
         if accumulate:
-            t = cas.detector.timing()
+            t = cas.det_timing
             for k_, v in zip(("det_pre", "det_image", "det_rpn", "det_roialign", "det_roihead", "det_final"), t.values()):
                 stage[k_] += v
             a, b_, c = cas.topdown.timing()
@@ -302,12 +305,12 @@ def run_cascade(args, D):
             stage["pose_decode"] += c
         return res
 
-    for _ in range(args.warmup):
-        res = step()
+    for i in range(args.warmup):
+        res = step(more=i + 1 < args.warmup)
     D.barrier(ctx)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step(True)
+    for i in range(args.steps):
+        res = step(True, more=i + 1 < args.steps)
     D.barrier(ctx)
     dt_own = time.perf_counter() - t0
     dt = D.max_time(dt_own)
@@ -315,7 +318,15 @@ def run_cascade(args, D):
     if D.rank != 0:
         return
     K = args.steps
-    stage = {k: v / K for k, v in stage.items()}
+    # stage times: inside the timed region the next chunk's detector pass runs UNDER this chunk's 2D stage, so per-stage event
+    # times overlap and sum to more than the step; the breakdown reported is from three extra steps without that overlap
+    overlapped = {k: v / K for k, v in stage.items()}
+    for k_ in stage:
+        stage[k_] = 0.0
+    step()
+    for _ in range(3):
+        step(True)
+    stage = {k: v / 3 for k, v in stage.items()}
     conv_ms = stage["det_image"] + stage["det_roihead"] + stage["pose_backbone"]
     # serial leg (outside the timed region): the same step with every launch on one stream, so that the per-kernel
     # durations rocprofv3 reports are additive and comparable (POSEPIPE_NET_LANES=1 profile under profiles/)
@@ -350,12 +361,16 @@ def run_cascade(args, D):
     progs = [(cas.detector.net_a, B), (cas.detector.net_b, B * cas.detector.MAX_ROIS)] + ([] if vit else [(cas.pose_net, 2 * B * P)])
     fam = kernel_families(progs)
     programs = {"achieved": achieved, "launches_per_step": n_launch, "avg_launch_ms": conv_ms / n_launch,
-                "note": "all conv programs of the step inside the timed region (4 HIP streams): FLOPs / wall time of the programs",
+                "note": "all conv programs of a step (4 HIP streams per program, no detector look-ahead): FLOPs / wall time of the programs",
                 "serial": {"avg_launch_ms": serial_conv_ms / n_launch, "achieved": flops_conv / (serial_conv_ms * 1e-3) / 1e12,
                            "note": "same step, one stream (pp_net_set_lanes 0): comparable with rocprofv3 --stats AverageNs "
                                    "of profiles/*_serial_kernel_stats.csv"}}
     roof = roofline_families(fam)
-    roof.update({"traffic": traffic, "traffic_source": traffic_note, "stage_ms": stage, "conv_programs": programs})
+    roof.update({"traffic": traffic, "traffic_source": traffic_note, "stage_ms": stage,
+                 "stage_ms_note": "per-stage HIP-event times of steps run WITHOUT the detector look-ahead (outside the timed region); in the "
+                                  "timed region chunk k + 1's detector pass overlaps chunk k's 2D stage: step = %.1f ms against the %.1f ms "
+                                  "these stages sum to" % (dt / K * 1e3, sum(stage.values())),
+                 "stage_ms_overlapped": overlapped, "conv_programs": programs})
     # the same workload on the bit-exact float32-MFMA kernels only (pp_conv_exact(1)): reported beside `value` (N = 1 leg)
     exact_mode = None
     if D.world == 1:
@@ -364,8 +379,8 @@ def run_cascade(args, D):
         ctx.synchronize()
         t0 = time.perf_counter()
         n_exact = max(2, K // 2)
-        for _ in range(n_exact):
-            step()
+        for i in range(n_exact):
+            step(more=i + 1 < n_exact)
         ctx.synchronize()
         dt_exact = time.perf_counter() - t0
         _lib.check(ctx.lib.pp_conv_exact(-1), "pp_conv_exact")
@@ -399,19 +414,23 @@ def run_cascade(args, D):
         host_clip = ArrayVideo(np.concatenate([frames] * n_chunks))
         cas.reset()
         rb = replay_boxes()
-        n_seen, t1 = 0, None
-        for o in cas.run_video(host_clip, replay_fn=lambda first, n: rb[:n]):
-            if t1 is None:
-                t1 = time.perf_counter()      # steady state: staging-buffer allocation and the first upload are start-up
-            else:
-                n_seen += len(o["tracks"])
-            t_last = time.perf_counter()      # step() returns host results, so the chunk is complete here; tear-down
-                                              # of the staging buffers (hipHostFree) is not part of the steady state
+        # the staging buffers are page-locked before the clock starts (start-up), then the WHOLE clip is timed: every chunk's
+        # read, upload, detector pass and 2D / 3D stages lie inside the window (with the detector pass of chunk k + 1 running
+        # under chunk k's 2D stage a window that opened after the first chunk would hold one detector pass too few); the
+        # clock stops when the last chunk's results are on the host (flush included), before the staging buffers are freed
+        from posepipeline_amd.streaming import FrameStreamer
+        streamer = FrameStreamer(ctx, host_clip, B)
+        n_seen = 0
+        t1 = time.perf_counter()
+        for o in cas.run_video(host_clip, replay_fn=lambda first, n: rb[:n], streamer=streamer):
+            n_seen += len(o["tracks"])
+            t_last = time.perf_counter()
         dt_stream = t_last - t1
         out["pcie_inclusive"] = {"value": n_seen / dt_stream, "unit": "frames/s",
-                                 "note": "steady state over %d frames read once from host memory, copied into page-locked "
-                                         "staging buffers by a reader thread and uploaded on a copy stream while the previous "
-                                         "chunk computes (posepipeline_amd/streaming.py)" % n_seen}
+                                 "note": "%d frames read once from host memory, copied into page-locked staging buffers by a "
+                                         "reader thread and uploaded on a copy stream while the previous chunks compute "
+                                         "(posepipeline_amd/streaming.py); whole clip timed, first (unoverlapped) upload and "
+                                         "final flush included" % n_seen}
     if vit:
         out["roofline"]["vit_stage"] = {"backbone_ms": stage["pose_backbone"], "program_tflops": pose_flops / (stage["pose_backbone"] * 1e-3) / 1e12,
                                         "note": "ViTPose-H program (bf16 GEMMs + fp32 patch embedding / head); roofline line: --workload c5"}

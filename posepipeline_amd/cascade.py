@@ -16,6 +16,8 @@ t+121 has its key points, `flush()` emits the rest at the end of the clip.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import _lib as L
@@ -41,11 +43,21 @@ class Cascade:
 
     def __init__(self, ctx: L.Context, det_sd, pose_sd: dict, lift_sd: dict, src_h: int, src_w: int,
                  chunk: int = 8, max_persons: int = 1, pose_spec=None, post="unbiased", blur_kernel=17,
-                 tracking: str = "MMTrack_deepsort", keep_tracks=None, flip_pairs=None, blob_fn=None, reid_sd=None):
+                 tracking: str = "MMTrack_deepsort", keep_tracks=None, flip_pairs=None, blob_fn=None, reid_sd=None,
+                 overlap_detector: bool = True):
         """blob_fn(name, program) -> (device pointer, n_floats) or None, name in "det_a", "det_b", "pose", "lift" (called in
         that order): a weight blob that is already resident on the device -- parallel.broadcast_blob_device delivers rank
-        0's over RCCL; the *_sd arguments then only define the program structure (ops, buffers, blob offsets)."""
+        0's over RCCL; the *_sd arguments then only define the program structure (ops, buffers, blob offsets).
+        overlap_detector: the detector gets its own context (HIP stream + lanes) and `step(..., prefetch=next chunk)` runs
+        its pass over the NEXT chunk on a worker thread while this chunk's tracking / 2D / 3D stages run -- the detector's
+        big convolutions fill the CUs that HRNet's small maps leave idle, RoIAlign (HBM-bound) overlaps MFMA-bound work.
+        Results are unchanged (same kernels, same order per stage).  Not with the ReID branch (it reads the detector's
+        resident input tensor of the CURRENT chunk)."""
         self.ctx = ctx
+        self.det_ctx = ctx
+        self._pending = None          # (chunk key, Future of _det_job) started by step(prefetch=...)
+        self.det_timing = None        # per-stage times of the detector pass this step consumed
+        self._pool = None
         self.src = (src_h, src_w)
         self.chunk = chunk
         self.max_persons = max_persons
@@ -59,7 +71,8 @@ class Cascade:
             self.encoder = mars.MarsEncoder(ctx, det_sd[1], src_h, src_w, max_patches=max(64, chunk * max_persons))
         else:
             assert tracking == "MMTrack_deepsort", tracking
-            self.detector = fr.Detector(ctx, det_sd, src_h, src_w, max_frames=chunk, blob_fn=blob_fn)
+            self.det_ctx = L.Context(ctx.device) if (overlap_detector and reid_sd is None and os.environ.get("POSEPIPE_OVERLAP_DETECTOR", "1") != "0") else ctx
+            self.detector = fr.Detector(self.det_ctx, det_sd, src_h, src_w, max_frames=chunk, blob_fn=blob_fn)
             if reid_sd is not None:
                 from .models import reid_r50
                 self.reid = reid_r50.ReidEncoder(ctx, reid_sd, self.detector, max_crops=max(64, chunk * max_persons), blob_fn=blob_fn)
@@ -86,7 +99,18 @@ class Cascade:
         self._cur = None              # (frames, frames_dev, first frame) of the chunk being processed
         self.reset()
 
+    def _drop_prefetch(self):
+        if self._pending is not None:
+            try:
+                self._pending[1].result()
+            finally:
+                self._pending = None
+
     def close(self):
+        self._drop_prefetch()
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
         if self.tail_dev is not None and getattr(self.ctx, "handle", None):
             self.ctx.free(self.tail_dev)
         self.tail_dev = None
@@ -98,6 +122,7 @@ class Cascade:
             pass
 
     def reset(self):
+        self._drop_prefetch()
         if self.tracking == "DeepSortYOLOv4":
             self.tracker = Tracker(mode=0, feat_dim=128, max_cosine_distance=0.3)       # parser.py:35-47
         elif getattr(self, "reid", None) is not None:
@@ -121,8 +146,38 @@ class Cascade:
                 self.max_persons * self.lift_net.prog.flops / self.lift_spec.chunk)
 
     # ---- stage 1: detect + associate ------------------------------------------------------------------------
-    def _track_chunk(self, frames, frames_dev, replay):
+    @staticmethod
+    def _chunk_key(frames, frames_dev):
+        return ("dev", int(frames_dev[0]), int(frames_dev[1])) if frames_dev is not None else ("host", id(frames))
+
+    def _detect(self, frames, frames_dev):
+        """the detector's pass over this chunk: the prefetched one if step(prefetch=) of the previous call started it"""
+        if self._pending is not None:
+            key, fut = self._pending
+            self._pending = None
+            dets, timing = fut.result()
+            if key == self._chunk_key(frames, frames_dev):
+                self.det_timing = timing
+                return dets
+        dets, self.det_timing = self._det_job(frames, frames_dev)
+        return dets
+
+    def _det_job(self, frames, frames_dev):
+        """detector pass + its per-stage HIP-event times (read on the thread that ran it: the next pass re-records the events)"""
         dets = self.detector.run(frames, frames_dev=frames_dev)
+        timing = self.detector.timing() if hasattr(self.detector, "timing") else None
+        return dets, timing
+
+    def _prefetch(self, frames, frames_dev):
+        if self.det_ctx is self.ctx:
+            return                       # no second stream: nothing to overlap with
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="posepipe-detector")
+        self._pending = (self._chunk_key(frames, frames_dev),
+                         self._pool.submit(self._det_job, frames, frames_dev))
+
+    def _track_chunk(self, frames, frames_dev, replay, dets):
         chunk_tracks = []
         if self.tracking == "DeepSortYOLOv4":
             # wrappers/deep_sort_yolov4/parser.py:52-86 per frame: persons -> appearance features -> NMS(1.0) -> DeepSORT
@@ -199,16 +254,21 @@ class Cascade:
                     self.tail_host = np.zeros((FILL_LIMIT, *self.src, 3), np.uint8)
                 self.tail_host[slot] = frames[t - n0]
 
-    def step(self, frames, frames_dev=None, replay=None):
+    def step(self, frames, frames_dev=None, replay=None, prefetch=None):
         """One chunk.  frames: numpy [B][H][W][3] u8 BGR, or frames_dev=(device pointer, B).
         replay: optional per-frame [n][5] boxes that stand in for the detector's output downstream (bench
         with random-weight detectors) -- the detector still runs.
+        prefetch: (frames, frames_dev) of the NEXT chunk (already resident / valid until that step): its detector pass starts
+        now and runs under this chunk's remaining stages (see overlap_detector).
         Returns dict(tracks = per-frame tracker rows of the chunk,
                      keypoints / keypoints_frames = {track_id: (n,K,3) / (n,) frame numbers} decided in this step,
                      keypoints_3d / keypoints_3d_frames = {track_id: (m,17,3) / (m,)} emitted in this step)."""
         b = frames_dev[1] if frames_dev is not None else frames.shape[0]
         self._live_sets = None
-        chunk_tracks = self._track_chunk(frames, frames_dev, replay)
+        dets_now = self._detect(frames, frames_dev)
+        if prefetch is not None:
+            self._prefetch(*prefetch)
+        chunk_tracks = self._track_chunk(frames, frames_dev, replay, dets_now)
         n0 = self.persons.n_frames
         self.persons.ingest(chunk_tracks, self._live_sets)
         self._cur = (frames, frames_dev, n0)
@@ -227,16 +287,21 @@ class Cascade:
         out["tracks"] = []
         return out
 
-    def run_video(self, video, replay_fn=None, max_frames=None):
+    def run_video(self, video, replay_fn=None, max_frames=None, streamer=None):
         """Whole clip, read once: frames stream through page-locked staging buffers and the copy stream
         (streaming.FrameStreamer) while the previous chunk computes.  video: video.open_video() object.
-        replay_fn(first, n) -> per-frame replay boxes (see step).  Yields step() results, one per chunk, then flush()'s."""
+        replay_fn(first, n) -> per-frame replay boxes (see step).  Yields step() results, one per chunk, then flush()'s.
+        streamer: a FrameStreamer built by the caller over the same video (bench: staging-buffer allocation outside the timed
+        window); it is closed here."""
         from .streaming import FrameStreamer
         assert (video.height, video.width) == self.src, ((video.height, video.width), self.src)
-        streamer = FrameStreamer(self.ctx, video, self.chunk, max_frames=max_frames)
+        if streamer is None:
+            streamer = FrameStreamer(self.ctx, video, self.chunk, max_frames=max_frames)
         try:
             for dev_ptr, n, first in streamer:
-                out = self.step(None, frames_dev=(dev_ptr, n), replay=None if replay_fn is None else replay_fn(first, n))
+                nxt = streamer.ahead          # chunk k + 1, already resident: the detector may start on it
+                out = self.step(None, frames_dev=(dev_ptr, n), replay=None if replay_fn is None else replay_fn(first, n),
+                                prefetch=None if nxt is None else (None, (nxt[0], nxt[1])))
                 streamer.release()
                 out["first_frame"] = first
                 yield out

@@ -28,7 +28,7 @@ class FrameStreamer:
         cascade.step(None, frames_dev=(dev_ptr, n)); streamer.release()
     """
 
-    N_DEV = 2     # device buffers: one computing, one uploading
+    N_DEV = 3     # device buffers: one computing, one resident ahead (`ahead`: the detector may already run on it), one uploading
     N_PIN = 3     # staging buffers: one uploading, one being filled, one ready
 
     def __init__(self, ctx: L.Context, video, chunk: int, max_frames: int | None = None):
@@ -50,6 +50,7 @@ class FrameStreamer:
         for i in range(self.N_PIN):
             self.free_q.put(i)
         self.error = None
+        self.ahead = None
         self._stop = False
         self.thread = threading.Thread(target=self._read_loop, name="posepipe-frame-reader", daemon=True)
         self.thread.start()
@@ -84,20 +85,35 @@ class FrameStreamer:
                                              n * self.frame_bytes), "pp_upload_begin")
         return (i, n, first, d)
 
+    def _wait(self, flight):
+        """order the compute stream after the (last begun) upload, wait for it on the host, hand the staging buffer back"""
+        i, n, first, d = flight
+        L.check(self.ctx.lib.pp_upload_wait(self.ctx.handle, 1), "pp_upload_wait")
+        self.free_q.put(i)
+        return self.dev[d], n, first
+
     def __iter__(self):
-        item = self.ready_q.get()
+        """yields (dev_ptr, n, first) of chunk k; meanwhile `self.ahead` = the same triple of chunk k + 1, already resident
+        (None at the end of the clip), and chunk k + 2 is uploading behind the caller's compute"""
         d = 0
-        flight = self._begin(item, d) if item is not None else None
-        while flight is not None:
-            i, n, first, dcur = flight
-            # upload of this chunk: order the compute stream after it, and wait on the host so that the staging buffer
-            # can go back to the reader
-            L.check(self.ctx.lib.pp_upload_wait(self.ctx.handle, 1), "pp_upload_wait")
-            self.free_q.put(i)
+
+        def begin():
+            nonlocal d
             item = self.ready_q.get()
-            d ^= 1
-            flight = self._begin(item, d) if item is not None else None   # overlaps the caller's compute on dcur
-            yield self.dev[dcur], n, first
+            if item is None:
+                return None
+            fl = self._begin(item, d)
+            d = (d + 1) % self.N_DEV
+            return fl
+        fl = begin()
+        cur = self._wait(fl) if fl is not None else None
+        fl = begin() if cur is not None else None
+        self.ahead = self._wait(fl) if fl is not None else None
+        while cur is not None:
+            flight = begin() if self.ahead is not None else None       # overlaps the caller's compute on `cur`
+            yield cur
+            cur = self.ahead
+            self.ahead = self._wait(flight) if flight is not None else None
         if self.error is not None:
             raise self.error
 
