@@ -34,6 +34,12 @@
 
 #include "pp_internal.h"
 
+// timing experiments only (tools/build_variant.sh; WRONG results): 1 no weight loads, 2 no patch staging, 4 no barrier,
+// 8 no fragment reads from LDS, 16 no MFMAs in the K loop of conv_split_kernel
+#ifndef PP_SPLIT_ABLATE
+#define PP_SPLIT_ABLATE 0
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -116,8 +122,16 @@ enum { MODE_TILE = 0, MODE_STREAM = 1, MODE_GEMM = 2 };
 // COB: output-channel blocks (32 channels) per wave and per workgroup; PXB: pixel blocks (32 pixels) per wave.  PXB = 1
 // (128-pixel tiles, ~150 registers, three workgroups per CU) was measured for the layers whose grid does not fill the chip
 // twice: 24x18 x 192 channels +9 %, 12x9 x 384 -20 %, 40x68 x 256 -17 % alone; no gain in the 4-stream program -- not instantiated.
-template <int T, int NSLOT, int COB, int PXB = 2>
-__global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
+//
+// NW = 8 (512 threads, one workgroup per CU, 512-pixel tiles) is the form for layers with enough tiles: there the split weights go
+// through LDS -- a 4-slot ring of per-tap fragment sets filled by the DMA path (global_load_lds_dwordx4, one 1 KB fragment per
+// wave and tap), one barrier per tap.  Why: with per-wave fragment loads straight from global memory (NW = 4) every wave of a
+// workgroup pulls the same 6 KB per tap through the texture-address path; an ablation build without those loads runs the
+// 256 -> 256 layer at 307 instead of 228 TFLOP/s (profiles/r02_conv_split_ablation.txt), i.e. they are the largest single loss.
+template <int T, int NSLOT, int COB, int PXB = 2, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(SplitArgs a) {
+    constexpr int NT = 64 * NW;
+    constexpr bool WLDS = NW == 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -144,16 +158,16 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
         x0 = tx * a.TW;
         y0 = ty * a.TH;
     } else {
-        s0 = (long long)L * (128 * PXB);
+        s0 = (long long)L * (32 * PXB * NW);
     }
 
     // ---- patch loader: slot j of this thread = (patch pixel p, channel quad) -----------------------------------------
     unsigned goff[NSLOT];
-    // LDS byte offset (plane 0) of slot j: woff0 + 1024 j (64 pixels further, same quad)
+    // LDS byte offset (plane 0) of slot j: woff0 + (NT / 4) * 16 j (NT / 4 pixels further, same quad)
     const int woff0 = ((((tid & 3) >> 1) * a.NPp + (tid >> 2)) * 16 + (tid & 1) * 8);
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
-        const int u = tid + 256 * j;
+        const int u = tid + NT * j;
         const int p = u >> 2, quad = u & 3;
         const bool in_patch = p < a.NP;
         unsigned off = 0xffffffffu;
@@ -185,8 +199,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
         }
     };
     // split + write slots [j0, j1) of the staged chunk; branch-free (it sits between MFMAs) except for the last slot, the only
-    // one that can be partly outside the patch (NSLOT = ceil(NP / 64))
-    const bool last_ok = (tid >> 2) + 64 * (NSLOT - 1) < a.NP;
+    // one that can be partly outside the patch (NSLOT = ceil(NP / (NT / 4)))
+    const bool last_ok = (tid >> 2) + (NT / 4) * (NSLOT - 1) < a.NP;
     auto store_patch = [&](int buf, int j0, int j1) {
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
@@ -194,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
             uint2 p0, p1, p2;
             split4(xr[j], p0, p1, p2);
             if (j == NSLOT - 1 && !last_ok) continue;
-            unsigned char* d = smem + buf * buf_bytes + woff0 + 1024 * j;
+            unsigned char* d = smem + buf * buf_bytes + woff0 + (NT / 4) * 16 * j;
             *reinterpret_cast<uint2*>(d) = p0;
             *reinterpret_cast<uint2*>(d + plane_bytes) = p1;
             *reinterpret_cast<uint2*>(d + 2 * plane_bytes) = p2;
@@ -265,14 +279,16 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
         for (int pl = 0; pl < 3; ++pl) xf[pb][pl] = *reinterpret_cast<const uint4*>(pbuf + pl * plane_bytes + aofs[pb] + toff);
     };
 
-    // ---- prologue ---------------------------------------------------------------------------------------------------------
-    load_patch(0);
-    load_w(wf[0]);
-    store_patch(0, 0, NSLOT);
-    if (a.nchunks > 1) load_patch(1);
-    __syncthreads();
+    // ---- prologue (4 waves; the 8-wave form has its own below) -------------------------------------------------------------
+    if constexpr (!WLDS) {
+        load_patch(0);
+        load_w(wf[0]);
+        store_patch(0, 0, NSLOT);
+        if (a.nchunks > 1) load_patch(1);
+        __syncthreads();
 #pragma unroll
-    for (int pb = 0; pb < PXB; ++pb) load_x(smem, 0, pb);
+        for (int pb = 0; pb < PXB; ++pb) load_x(smem, 0, pb);
+    }
 
     // the six products with i + j <= 2 (smallest terms first) of one pixel block against every channel block; consecutive MFMAs
     // go to different accumulators (no back-to-back dependency on the matrix pipe)
@@ -286,6 +302,100 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
                                                                       __builtin_bit_cast(bf16x8, xf[pb][XI[p]]), acc[cb][pb], 0, 0, 0);
     };
 
+    if constexpr (WLDS) {
+        // ---- 8 waves: split weights through a 4-slot LDS ring, one barrier per tap ---------------------------------------------
+        // step s = chunk * T + tap.  Ring slot s & 3 holds the COB x 3 fragments of step s.  During step s: the fragments of step
+        // s + 1 are read into the other register set (they landed before the barrier that ended step s - 1), the DMA of step
+        // s + 3 is issued into the slot step s - 1 used, and before the closing barrier the DMA of step s + 2 is awaited -- by
+        // counting: vmcnt is in issue order, so "all but the DMA of s + 3 and the patch loads issued after it" have landed.
+        constexpr int WSLOT = COB * 3 * 1024;
+        const unsigned wring = (unsigned)(2 * buf_bytes);
+        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+        const int myslab = wave % (COB * 3);           // one 1 KB fragment per wave and step (waves past COB * 3 copy a duplicate)
+        const uint4* wsrc = a.w + (size_t)cb0 * 192 + myslab * 64 + lane;
+        const int nsteps = a.nchunks * T;
+        auto issue_w = [&](int step) {
+            if (step >= nsteps) return;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + wring + (unsigned)((step & 3) * WSLOT + myslab * 1024));
+            const uint4* g = wsrc + (size_t)step * wstep;
+            // raw instruction, see conv_split_gemm_kernel: the builtin makes the compiler order every later ds_read behind vmcnt(0)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory", "m0");
+        };
+        auto read_w = [&](int step, uint4 (&dst)[COB][3]) {
+            const unsigned char* base = smem + wring + (step & 3) * WSLOT + lane * 16;
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) dst[cb][pl] = *reinterpret_cast<const uint4*>(base + (cb * 3 + pl) * 1024);
+        };
+        // allow `n` (0, 1, NSLOT, NSLOT + 1) of the youngest vector-memory operations to stay in flight
+        auto wait_all_but = [&](int n) {
+            // (no lgkmcnt: a wave's patch writes and fragment reads are complete long before the barriers that matter for them --
+            // the patch of chunk c + 1 is written four taps before its first read, a ring slot is reused two barriers after its
+            // last read was consumed)
+            if (n == NSLOT + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSLOT + 1) : "memory");
+            else if (n == NSLOT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSLOT) : "memory");
+            else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        issue_w(0);
+        issue_w(1);
+        issue_w(2);
+        load_patch(0);
+        store_patch(0, 0, NSLOT);                      // waits for patch 0, hence (in order) for the three DMAs before it
+        if (a.nchunks > 1) load_patch(1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_w(0, wf[0]);
+#pragma unroll
+        for (int pb = 0; pb < PXB; ++pb) load_x(smem, 0, pb);
+
+        auto chunk8 = [&](auto par, int c) {
+            constexpr int PAR = decltype(par)::value;
+            const unsigned char* pbuf = smem + (c & 1) * buf_bytes;
+            const int st0 = c * T;
+            const bool more_patch = c + 1 < a.nchunks;            // patch c + 1 is staged in this chunk
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int cur = (PAR + t) & 1;
+                const int st = st0 + t;
+                if (st + 1 < nsteps) read_w(st + 1, wf[cur ^ 1]);
+                if (t != T / 2) issue_w(st + 3);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pb = 0; pb < PXB; ++pb) {
+                    if (pb == PXB - 1 && t == T / 2) {
+                        // patch c + 1: split and written half-way through the chunk; the DMA of this step is issued AFTER it, so
+                        // that the compiler's wait for the patch loads (it does not see the DMAs) covers no DMA younger than a tap
+                        if (more_patch) store_patch((c + 1) & 1, 0, NSLOT);
+                        issue_w(st + 3);
+                    }
+                    mma(wf[cur], pb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 1 < T) load_x(pbuf, t + 1, pb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // closing barrier of the step: the DMA of step st + 2 has landed (younger: the DMA of st + 3 if there is one, and at
+                // the first tap of a chunk the patch loads issued at its start); LDS writes of store_patch are complete
+                {
+                    const int younger = (st + 3 < nsteps ? 1 : 0) + ((t == 0 && c + 1 < a.nchunks) ? NSLOT : 0);
+                    wait_all_but(younger);
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            if (c + 1 < a.nchunks) {
+#pragma unroll
+                for (int pb = 0; pb < PXB; ++pb) load_x(smem + ((c + 1) & 1) * buf_bytes, 0, pb);
+            }
+            if (c + 2 < a.nchunks) load_patch(c + 2);
+        };
+        int c8 = 0;
+        for (; c8 + 1 < a.nchunks; c8 += 2) {
+            chunk8(std::integral_constant<int, 0>{}, c8);
+            chunk8(std::integral_constant<int, 1>{}, c8 + 1);
+        }
+        if (c8 < a.nchunks) chunk8(std::integral_constant<int, 0>{}, c8);
+    } else {
     // One 16-channel chunk: T steps.  Weights of step s + 1 are requested (global -> the other register set) before the MFMAs of
     // step s; a pixel block's fragments of step s + 1 are read from LDS into the SAME registers as soon as its MFMAs of step s
     // are issued, i.e. while the other pixel block's MFMAs run.  The fences keep the compiler from sinking the loads.
@@ -295,26 +405,40 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const int cur = (PAR + t) & 1;
+#if !(PP_SPLIT_ABLATE & 1)
             load_w(wf[cur ^ 1]);
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pb = 0; pb < PXB; ++pb) {
                 // the next chunk's patch (loaded one chunk ago) is split and written half-way through the chunk.  As its own
                 // (branched) region: interleaving it with the MFMAs costs ~30 registers (spills with 7-8 patch slots) and
                 // measured slower -- the CU's other workgroup keeps the matrix pipe busy meanwhile
+#if !(PP_SPLIT_ABLATE & 2)
                 if (pb == PXB - 1 && t == T / 2 && c + 1 < a.nchunks) store_patch((c + 1) & 1, 0, NSLOT);
-                mma(wf[cur], pb);
+#endif
+#if !(PP_SPLIT_ABLATE & 16)
+                mma(wf[(PP_SPLIT_ABLATE & 1) ? 0 : cur], pb);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
+#if !(PP_SPLIT_ABLATE & 8)
                 if (t + 1 < T) load_x(pbuf, t + 1, pb);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#if !(PP_SPLIT_ABLATE & 4)
         __syncthreads();
+#endif
+#if !(PP_SPLIT_ABLATE & 8)
         if (c + 1 < a.nchunks) {
 #pragma unroll
             for (int pb = 0; pb < PXB; ++pb) load_x(smem + ((c + 1) & 1) * buf_bytes, 0, pb);
         }
+#endif
+#if !(PP_SPLIT_ABLATE & 2)
         if (c + 2 < a.nchunks) load_patch(c + 2);
+#endif
     };
     int c = 0;
     for (; c + 1 < a.nchunks; c += 2) {
@@ -322,6 +446,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitArgs a) {
         chunk(std::integral_constant<int, 1>{}, c + 1);
     }
     if (c < a.nchunks) chunk(std::integral_constant<int, 0>{}, c);
+    }   // !WLDS
 
     // ---- epilogue: bias, residuals, ReLU; accumulator register i of a lane = channel 8 (i / 4) + 4 (lane / 32) + i % 4 ---
 #pragma unroll
@@ -586,11 +711,11 @@ struct TileGeom {
 };
 
 // the 256-pixel tile shape (8 blocks of 32 pixels) that wastes the fewest pixels on this map
-TileGeom pick_tile(int H, int W, double big_patch_factor, int pxb) {
+TileGeom pick_tile(int H, int W, int max_np, int pxb) {
     static const int force = env_int("POSEPIPE_SPLIT_TILE", -1);
     TileGeom best{};
     best.eff = -1.0;
-    // (bw_log2, gx_log2): 8x32, 4x64, 16x16, 32x8 pixel tiles (pxb = 2); 4x32, 2x64, 8x16, 16x8 (pxb = 1)
+    // (bw_log2, gx_log2): 8x32, 4x64, 16x16, 32x8 pixel tiles (pxb = 2, 4 waves); 16x32, 8x64, 32x16, 64x8 (pxb = 4: 8 waves)
     const int cand[4][2] = {{0, 0}, {0, 1}, {1, 0}, {2, 0}};
     const int nblk = 4 * pxb;
     for (int i = 0; i < 4; ++i) {
@@ -609,7 +734,8 @@ TileGeom pick_tile(int H, int W, double big_patch_factor, int pxb) {
         while (g.NPp % 8 != 4) ++g.NPp;       // half planes 64 B apart mod 128: conflict-free ds_write_b64
         g.tiles_x = (W + g.TW - 1) / g.TW;
         g.tiles_y = (H + g.TH - 1) / g.TH;
-        g.eff = (double)H * W / ((double)g.tiles_x * g.tiles_y * 128.0 * pxb) * (g.NP > 384 ? big_patch_factor : 1.0) - 1e-4 * g.NP / 256.0;
+        if (g.NP > max_np) continue;
+        g.eff = (double)H * W / ((double)g.tiles_x * g.tiles_y * 128.0 * pxb) - 1e-4 * g.NP / 256.0;
         if (g.eff > best.eff) best = g;
     }
     return best;
@@ -725,20 +851,29 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     }
     const int cob = (s.ncb & 1) ? 1 : 2;
     static const int stream_env = env_int("POSEPIPE_SPLIT_STREAM", -1);
+    static const int nw8_min_blocks = env_int("POSEPIPE_SPLIT_NW8_MIN_BLOCKS", 512), nw8_min_chunks = env_int("POSEPIPE_SPLIT_NW8_MIN_CHUNKS", 16);
     unsigned gx = 0;
-    if (mode == MODE_GEMM) {
-        s.mode = MODE_GEMM;
-        s.S = (long long)a.M;
-        s.NP = 256;
-        s.NPp = 260;
-        gx = (unsigned)((a.M + 255) / 256);
-    } else {
-        const TileGeom g = pick_tile(a.Hout, a.Wout, 1.0, 2);
-        const int snp = 258 + 2 * s.xp_w;
+    int nw = 8;
+    // geometry for the 8-wave form (512-pixel tiles, one workgroup per CU); if that gives fewer than ~2 workgroups per CU (or
+    // the layer is a one-tap product), the 4-wave form (256-pixel tiles, two per CU)
+    for (;;) {
+        const int tile_px = 64 * nw, pxb = nw / 2;
+        if (mode == MODE_GEMM) {
+            nw = 4;
+            s.mode = MODE_GEMM;
+            s.S = (long long)a.M;
+            s.NP = 256;
+            s.NPp = 260;
+            gx = (unsigned)((a.M + 255) / 256);
+            break;
+        }
+        const int max_np = nw == 8 ? 768 : 512;
+        const TileGeom g = pick_tile(a.Hout, a.Wout, max_np, pxb);
+        const int snp = tile_px + 2 + 2 * s.xp_w;
         const double stream_eff = (double)a.Hout * a.Wout / ((double)s.xp_h * s.xp_w);
-        bool use_stream = a.x_pad >= 1 && snp <= 512 && stream_eff > g.eff + 0.02;
-        if (stream_env == 0) use_stream = false;
-        if (stream_env == 1 && a.x_pad >= 1 && snp <= 512) use_stream = true;
+        bool use_stream = a.x_pad >= 1 && snp <= max_np && (g.eff < 0 || stream_eff > g.eff + 0.02);
+        if (stream_env == 0 && g.eff >= 0) use_stream = false;
+        if (stream_env == 1 && a.x_pad >= 1 && snp <= max_np) use_stream = true;
         if (use_stream) {
             s.mode = MODE_STREAM;
             s.PWp = s.xp_w;
@@ -746,40 +881,47 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
             s.NP = snp;
             s.NPp = snp;
             while (s.NPp % 8 != 4) ++s.NPp;
-            gx = (unsigned)((s.S + 255) / 256);
+            gx = (unsigned)((s.S + tile_px - 1) / tile_px);
         } else {
             s.mode = MODE_TILE;
             s.tiles_x = g.tiles_x; s.tiles_y = g.tiles_y; s.TH = g.TH; s.TW = g.TW; s.bw_log2 = g.bw_log2; s.gx_log2 = g.gx_log2;
             s.PWp = g.PWp; s.NP = g.NP; s.NPp = g.NPp;
             gx = (unsigned)(g.tiles_x * g.tiles_y * a.N);
         }
+        // measured on real activations (zeros clock ~15 % higher and mislead): 256 -> 256 at 160x272 207 -> 227 TFLOP/s, at 40x68
+        // 186 -> 199; but 128 -> 128 189 -> 182 and HRNet's 48 / 96-channel layers -8 %: the per-tap barrier and the three-DMA
+        // start-up want >= 16 chunks to pay off
+        if (nw == 4 || ((long)gx * (s.ncb / cob) >= nw8_min_blocks && s.nchunks >= nw8_min_chunks)) break;
+        nw = 4;
     }
-    const int nslot = (s.NP + 63) / 64;          // exactly: only the last patch slot of a thread can be partly outside the patch
+    const int nslot = (s.NP + 16 * nw - 1) / (16 * nw);     // exactly: only the last patch slot of a thread can be partly outside
     const dim3 grid(gx, (unsigned)(s.ncb / cob));
-    const size_t lds = (size_t)2 * 3 * 2 * s.NPp * 16;
-#define PP_SPLIT_LAUNCH(T_, NS_)                                                                                        \
+    const size_t lds = (size_t)2 * 3 * 2 * s.NPp * 16 + (nw == 8 ? (size_t)4 * cob * 3072 : 0);
+#define PP_SPLIT_LAUNCH(T_, NS_, NW_)                                                                                   \
     do {                                                                                                                \
         static std::once_flag once;                                                                                     \
         std::call_once(once, [] {     /* > 64 KB of dynamic LDS has to be allowed per kernel */                         \
-            (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
-            (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 2, 2, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (NW_ == 8 ? 160 : 100) * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 1, 2, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (NW_ == 8 ? 160 : 100) * 1024); \
         });                                                                                                             \
         if (cob == 2)                                                                                                   \
-            hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 2>), grid, dim3(256), lds, stream, s);                       \
+            hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 2, 2, NW_>), grid, dim3(64 * NW_), lds, stream, s);          \
         else                                                                                                            \
-            hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 1>), grid, dim3(256), lds, stream, s);                       \
+            hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 1, 2, NW_>), grid, dim3(64 * NW_), lds, stream, s);          \
     } while (0)
     if (mode == MODE_GEMM)
-        PP_SPLIT_LAUNCH(1, 4);
-    else if (nslot <= 5)
-        PP_SPLIT_LAUNCH(9, 5);
+        PP_SPLIT_LAUNCH(1, 4, 4);
+    else if (nw == 8) {
+        if (nslot <= 5) PP_SPLIT_LAUNCH(9, 5, 8);
+        else PP_SPLIT_LAUNCH(9, 6, 8);
+    } else if (nslot <= 5)
+        PP_SPLIT_LAUNCH(9, 5, 4);
     else if (nslot == 6)
-        PP_SPLIT_LAUNCH(9, 6);
+        PP_SPLIT_LAUNCH(9, 6, 4);
     else if (nslot == 7)
-        PP_SPLIT_LAUNCH(9, 7);
+        PP_SPLIT_LAUNCH(9, 7, 4);
     else
-        PP_SPLIT_LAUNCH(9, 8);
-#undef PP_SPLIT_LAUNCH
+        PP_SPLIT_LAUNCH(9, 8, 4);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         pp_set_error("conv_split launch failed: %s", hipGetErrorString(e));
