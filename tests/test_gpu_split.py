@@ -112,6 +112,36 @@ def test_split_1x1_and_full_cover_layers(ctx, lib):
     check_layer(lib, ctx, xr, wf, rng.standard_normal(128).astype(np.float32), 0, relu=L.PP_RELU_LAST)
 
 
+def test_split_eight_wave_forms(ctx, lib):
+    """layers with >= 16 channel chunks and >= 512 workgroups take the 8-wave form (512-pixel tiles, weights through an LDS ring
+    filled by the DMA path): tile form with two channel blocks per wave, with one (Cout = 96), ragged maps, and the stream form
+    on zero-halo buffers -- each against the bit-exact kernel (the float64 comparison of the small cases covers the arithmetic)"""
+    rng = np.random.default_rng(21)
+    for n, h, w, cin, cout in ((8, 96, 96, 256, 256), (10, 96, 96, 256, 96), (9, 90, 100, 272, 128)):
+        x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+        wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        r = rng.standard_normal((n, h, w, cout)).astype(np.float32)
+        exact, split = both(lib, lambda: hip_conv_op(ctx, x, wt, b, pad=(1, 1), relu=L.PP_RELU_LAST, res1=r))
+        scale = np.abs(exact).max()
+        assert np.isfinite(split).all() and not np.array_equal(exact, split)
+        assert np.abs(split - exact).max() <= 1e-5 * scale, (n, h, w, cin, cout, np.abs(split - exact).max() / scale)
+    # stream form: conv -> conv on a halo buffer, 40x40 maps, 48 images
+    c = 256
+    pb = ProgramBuilder()
+    xin_b = pb.buf(40, 40, c, name="input")
+    w = [(rng.standard_normal((c, c, 3, 3)) / np.sqrt(9 * c)).astype(np.float32) for _ in range(2)]
+    bb = [rng.standard_normal(c).astype(np.float32) for _ in range(2)]
+    y1 = pb.conv(xin_b, w[0], bb[0], pad=1, relu=L.PP_RELU_LAST)
+    out = pb.buf(40, 40, c, name="output")
+    pb.conv(y1, w[1], bb[1], pad=1, relu=L.PP_RELU_LAST, out=out)
+    prog = pb.build()
+    assert max(prog.buf_pad) > 0
+    xin = rng.standard_normal((48, 40, 40, c)).astype(np.float32)
+    exact, split = both(lib, lambda: Net(ctx, prog, max_batch=48).forward(xin))
+    assert not np.array_equal(exact, split) and np.abs(split - exact).max() <= 1e-5 * np.abs(exact).max()
+
+
 @pytest.mark.parametrize("halo", ["1", "0"])
 def test_split_chain_on_zero_halo_buffers(ctx, lib, monkeypatch, halo):
     """conv -> conv -> conv + residual through a layer program: with the planner's zero-halo buffers the 3x3 layers run the
