@@ -9,10 +9,13 @@
 // at every step anyway.  The sums are accumulated in the MFMA's float32 accumulators.  Cost: 6 bf16 MFMAs of 16 k for what
 // takes 4 fp32 MFMAs of 4 k = 2.67x the arithmetic peak (419 TFLOP/s fp32-equivalent).
 // Results are NOT bit-identical to oracle/conv_ref.c (different summation order and the dropped 2^-23 terms): the measured
-// deviation is that of a reordered float32 sum (tests/test_gpu_conv_split.py: same error against a float64 convolution as the
-// exact kernel).  POSEPIPE_CONV_EXACT=1 / pp_conv_variant(3) selects the bit-exact fp32-MFMA kernels instead.
+// deviation is that of a reordered float32 sum (tests/test_gpu_split.py: same error against a float64 convolution as the
+// exact kernel, and a control with the bit-exact kernels on the transposed network).  POSEPIPE_CONV_EXACT=1 / pp_conv_variant(3) selects the bit-exact fp32-MFMA kernels instead.
 //
-// Structure (3x3, stride 1, pad 1 -- 52 % of the detector's and ~85 % of HRNet's time; 1x1 layers: conv_split_gemm below).
+// Kernels: conv_split_kernel (3x3, stride 1, pad 1 -- 52 % of the detector's and ~85 % of HRNet's time; 4 waves with per-wave
+// weight loads, or 8 waves with the weights through an LDS ring for long-K layers; also a one-tap form) and
+// conv_split_gemm_kernel (1x1 layers from 256 input channels with Cout % 128 == 0, the RoI head's fc6 / fc7).
+// Structure of conv_split_kernel:
 // An implicit GEMM that gathers per tap re-reads every input element nine times through L1/L2; at 2.67x the MFMA rate that
 // feed (87 GB/s per CU for a 128 x 64 tile) is over what the vector memory path delivers.  Instead a workgroup stages the
 // input PATCH of its output tile once per 16 input channels:

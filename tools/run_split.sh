@@ -1,4 +1,7 @@
-unset POSEPIPE_LIB
-timeout 600 python -m pytest tests/test_gpu_split.py tests/test_gpu_conv.py -q -x 2>&1 | tail -3
-timeout 300 python tools/split_net_check.py det 32 2>&1 | grep -A40 "variant -1" | grep "k3 s1\|variant"
-timeout 600 python bench.py --steps 10 --warmup 3 --cpu-frames 0 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['roofline']['achieved'], d['roofline']['frac'], d['roofline']['stage_ms'])"
+# bf16-split convolution kernels on a GPU box: accuracy against float64, the float32-reordering control, per-layer tables of the
+# detector / HRNet-W48 programs (default vs bit-exact kernels), bench line
+python tools/split_check.py
+python -m pytest tests/test_gpu_split.py -q -s -k reordering | grep "heat-maps\|joints\|passed\|failed"
+python tools/split_net_check.py det 32
+python tools/split_net_check.py w48 64
+python bench.py --steps 8 --warmup 3 --cpu-frames 0
