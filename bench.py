@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cascade", choices=["cascade", "c2", "c5", "cascade5", "track0", "cascade0"])
-    ap.add_argument("--chunk", type=int, default=32, help="cascade: frames per step per GPU")
+    ap.add_argument("--chunk", type=int, default=64, help="cascade: frames per step per GPU (32: -4 %; 128: as 64)")
     ap.add_argument("--persons", type=int, default=1, help="cascade: tracked persons per frame")
     ap.add_argument("--batch", type=int, default=64, help="c2 / c5: person-frames per step per GPU")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the CPU-baseline sample (0 = skip)")

@@ -16,9 +16,9 @@ cp $(ls -t $(find $O/serial -name "*kernel_stats.csv") | head -1) $O/cascade_ser
 cp $(ls -t $(find $O/lanes4 -name "*kernel_stats.csv") | head -1) $O/cascade_lanes4_kernel_stats.csv
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 2 --warmup 1 --cpu-frames 0 > $O/pmc_fetch.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 2 --warmup 1 --cpu-frames 0 > $O/pmc_write.log 2>&1
-python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 264 "cascade chunk 32, 1 person" conv_split > $O/pmc_summary.txt 2>&1
-python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 109 "cascade chunk 32, 1 person" conv_p3_kernel > $O/pmc_summary_fp32.txt 2>&1
-python tools/pmc_traffic_update.py cascade_chunk32_persons1 $O/pmc_summary.txt "tools/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over python bench.py --steps 2 --warmup 1 (FETCH_SIZE x2, gfx950)" $O/pmc_traffic.json
+python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 264 "cascade chunk 64, 1 person" conv_split > $O/pmc_summary.txt 2>&1
+python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 109 "cascade chunk 64, 1 person" conv_p3_kernel > $O/pmc_summary_fp32.txt 2>&1
+python tools/pmc_traffic_update.py cascade_chunk64_persons1 $O/pmc_summary.txt "tools/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over python bench.py --steps 2 --warmup 1 (FETCH_SIZE x2, gfx950); all conv_split_* launches" $O/pmc_traffic.json
 bash tools/pmc_sq.sh > $O/pmc_sq.log 2>&1; cp gpurun_out/pmc_sq/summary.txt $O/cascade_pmc_sq.txt
 bash tools/pmc_kernel.sh roi_align_kernel roi python bench.py --steps 1 --warmup 1 --cpu-frames 0 > $O/roi_pmc.log 2>&1; cp gpurun_out/pmc_roi/summary.txt $O/roi_pmc.txt
 for w in "w48 64" "det 32" "w32 128"; do set -- $w; python tools/profile_net.py $1 $2 > $O/per_op_$1_b$2.txt 2>&1; POSEPIPE_CONV_EXACT=1 python tools/profile_net.py $1 $2 > $O/per_op_$1_b$2_exact.txt 2>&1; done
