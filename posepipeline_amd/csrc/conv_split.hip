@@ -38,7 +38,7 @@
 #include "pp_internal.h"
 
 // timing experiments only (tools/build_variant.sh; WRONG results): 1 no weight loads, 2 no patch staging, 4 no barrier,
-// 8 no fragment reads from LDS, 16 no MFMAs in the K loop of conv_split_kernel
+// 8 no fragment reads from LDS, 16 no MFMAs in the K loop of conv_split_kernel, 32 no epilogue (one store per lane)
 #ifndef PP_SPLIT_ABLATE
 #define PP_SPLIT_ABLATE 0
 #endif
@@ -452,6 +452,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     }   // !WLDS
 
     // ---- epilogue: bias, residuals, ReLU; accumulator register i of a lane = channel 8 (i / 4) + 4 (lane / 32) + i % 4 ---
+#if (PP_SPLIT_ABLATE & 32)
+    if (a.relu != 77) {       // keep the accumulators alive with one store per lane
+        if (ook[0]) a.y[(((size_t)on[0] * (a.H + a.y_pad) + oy[0]) * (a.W + a.y_pad) + ox[0]) * a.Cout + (lane >> 5)] = acc[0][0][0] + acc[COB - 1][PXB - 1][15];
+        return;
+    }
+#endif
 #pragma unroll
     for (int pb = 0; pb < PXB; ++pb) {
         if (!ook[pb]) continue;
