@@ -87,6 +87,21 @@ __device__ __forceinline__ void split4(const float4 v, uint2& p0, uint2& p1, uin
     p2 = make_uint2(__builtin_amdgcn_perm(h2[1], h2[0], 0x07060302u), __builtin_amdgcn_perm(h2[3], h2[2], 0x07060302u));
 }
 
+// Activations of the DeepSortYOLOv4 / YOLOX programs, as conv_igemm_p3.hip: every transcendental is evaluated in double precision
+// and rounded to float once (what oracle/yolo.py restates); applied like PP_RELU_FIRST: y = res + act(conv + bias).
+__device__ __forceinline__ float split_activate(float x, int act) {
+    if (act == PP_ACT_LEAKY) return x >= 0.f ? x : 0.1f * x;
+    if (act == PP_ACT_MISH) {
+        if (x > 20.f) return x;
+        const double n = exp((double)x);
+        const double t = n * (n + 2.0);
+        return x * (float)(t / (t + 2.0));
+    }
+    if (act == PP_ACT_ELU) return x > 0.f ? x : (float)expm1((double)x);
+    if (act == PP_ACT_SWISH) return x * (float)(1.0 / (1.0 + exp(-(double)x)));
+    return x;
+}
+
 // ds_read_b128 is serviced in the lane groups {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} (+32): lane -> q such that each
 // group is 16 consecutive q.  Pixel blocks narrower than 32 pixels give every group whole rows of the block.
 __device__ __forceinline__ int lane_q(int r) {
@@ -474,6 +489,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
                 const f32x16 cc = acc[cb][pb];
                 float4 v = make_float4(cc[4 * g + 0] + b4.x, cc[4 * g + 1] + b4.y, cc[4 * g + 2] + b4.z, cc[4 * g + 3] + b4.w);
                 if (a.relu == PP_RELU_FIRST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (a.relu >= PP_ACT_LEAKY) { v.x = split_activate(v.x, a.relu); v.y = split_activate(v.y, a.relu); v.z = split_activate(v.z, a.relu); v.w = split_activate(v.w, a.relu); }
                 if (a.res1) {
                     const float4 r = *reinterpret_cast<const float4*>(a.res1 + r1pix * a.Cout + co);
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -655,6 +671,7 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
                 const f32x16 cc = acc[cb][pb];
                 float4 v = make_float4(cc[4 * g + 0] + b4.x, cc[4 * g + 1] + b4.y, cc[4 * g + 2] + b4.z, cc[4 * g + 3] + b4.w);
                 if (a.relu == PP_RELU_FIRST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (a.relu >= PP_ACT_LEAKY) { v.x = split_activate(v.x, a.relu); v.y = split_activate(v.y, a.relu); v.z = split_activate(v.z, a.relu); v.w = split_activate(v.w, a.relu); }
                 if (a.res1) {
                     const float4 r = *reinterpret_cast<const float4*>(a.res1 + r1pix * a.Cout + co);
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -788,7 +805,7 @@ bool pp_conv_split_eligible(const ConvArgs& a) {
     static const int gemm_min_cin = env_int("POSEPIPE_SPLIT_GEMM_MIN_CIN", 1024);
     if (!split_shape(a, &taps, &cin, &mode)) return false;
     if (mode == MODE_GEMM && cin < gemm_min_cin && !gemm8_cfg(a, mode, cin)) return false;
-    return cin % 16 == 0 && a.Cout % 4 == 0 && a.up_log2 == 0 && !a.out_nchw && res1_plain && a.relu <= PP_RELU_FIRST &&
+    return cin % 16 == 0 && a.Cout % 4 == 0 && a.up_log2 == 0 && !a.out_nchw && res1_plain && a.relu <= PP_ACT_SWISH &&
            (a.y_stride == 0 || a.y_stride == a.Cout) && a.y_coff == 0;
 }
 

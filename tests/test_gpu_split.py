@@ -112,6 +112,21 @@ def test_split_1x1_and_full_cover_layers(ctx, lib):
     check_layer(lib, ctx, xr, wf, rng.standard_normal(128).astype(np.float32), 0, relu=L.PP_RELU_LAST)
 
 
+def test_split_activation_epilogues(ctx, lib):
+    """LeakyReLU / Mish / ELU / Swish epilogues (YOLOv4, mars-small128, YOLOX): same double-precision evaluation as the fp32
+    kernels, on the split kernel's sums"""
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((2, 26, 26, 64)).astype(np.float32)
+    wt = (rng.standard_normal((128, 64, 3, 3)) / 24).astype(np.float32)
+    b = rng.standard_normal(128).astype(np.float32)
+    r = rng.standard_normal((2, 26, 26, 128)).astype(np.float32)
+    for act in (L.PP_ACT_LEAKY, L.PP_ACT_MISH, L.PP_ACT_ELU, L.PP_ACT_SWISH):
+        for res in (None, r):
+            exact, split = both(lib, lambda: hip_conv_op(ctx, x, wt, b, pad=(1, 1), relu=act, res1=res))
+            assert np.isfinite(split).all() and not np.array_equal(exact, split)
+            assert np.abs(split - exact).max() <= 1e-5 * np.abs(exact).max(), act
+
+
 def test_split_eight_wave_forms(ctx, lib):
     """layers with >= 16 channel chunks and >= 512 workgroups take the 8-wave form (512-pixel tiles, weights through an LDS ring
     filled by the DMA path): tile form with two channel blocks per wave, with one (Cout = 96), ragged maps, and the stream form
