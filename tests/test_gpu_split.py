@@ -198,8 +198,9 @@ def _rel(a, b):
 
 
 def test_split_backbones_agree_with_the_bit_exact_kernels(ctx, lib):
-    """HRNet-W32 / W48, the detector's image program (ResNet-50 + FPN + RPN head) and its RoI head, the ReID ResNet-50:
-    every named output within 2e-5 of the output range of the bit-exact run (measured 2..7e-6)"""
+    """HRNet-W32 / W48, the detector's image program (ResNet-50 + FPN + RPN head) and its RoI head, the ReID ResNet-50, YOLOv4
+    (Mish / LeakyReLU), mars-small128 (ELU), YOLOX (Swish): every named output within 2e-5 of the output range of the bit-exact
+    run (measured 2..7e-6)"""
     from posepipeline_amd.models import reid_r50
     rng = np.random.default_rng(1)
     progs = {}
@@ -209,6 +210,10 @@ def test_split_backbones_agree_with_the_bit_exact_kernels(ctx, lib):
     progs["det"] = (fr.build_image_program(dsd, 160, 288), "input", 2)
     progs["roi"] = (fr.build_roi_program(dsd), "roi_in", 600)
     progs["reid"] = (reid_r50.build_reid_program(synth.synth_state_dict(reid_r50.reid_param_shapes(), seed=7)), "input", 4)
+    from posepipeline_amd.models import mars, yolov4, yolox
+    progs["yolov4"] = (yolov4.build_yolov4_program(yolov4.synth_params(yolov4.yolov4_param_shapes(), seed=4), size=224), "input", 2)
+    progs["mars"] = (mars.build_mars_program(yolov4.synth_params(mars.mars_param_shapes(), seed=5)), "input", 16)
+    progs["yolox"] = (yolox.build_yolox_program(synth.synth_state_dict(yolox.yolox_param_shapes(), seed=6), 160, 256), "input", 1)
     for name, (prog, in_name, batch) in progs.items():
         x = rng.standard_normal((batch,) + tuple(prog.bufs[prog.named[in_name]])).astype(np.float32)
         outs = [k for k in prog.named if k != in_name]
