@@ -31,11 +31,14 @@ def _conv_numerics(request):
         return
     from posepipeline_amd import _lib
     lib = _lib.load_library()
-    lib.pp_conv_exact(1)
+    # POSEPIPE_TEST_NUMERICS=default: run the suite on the default kernels instead (the `==` assertions then fail by design; used
+    # to check that nothing else -- shapes, ids, error paths, graph capture, streaming -- depends on the numerics mode)
+    exact = -1 if os.environ.get("POSEPIPE_TEST_NUMERICS") == "default" else 1
+    lib.pp_conv_exact(exact)
     old = os.environ.get("POSEPIPE_CONV_EXACT")
-    os.environ["POSEPIPE_CONV_EXACT"] = "1"          # worker processes a test starts (sharded ranks, env-knob probes)
+    os.environ["POSEPIPE_CONV_EXACT"] = "1" if exact == 1 else "0"     # worker processes a test starts (sharded ranks, env-knob probes)
     yield
-    lib.pp_conv_exact(1)
+    lib.pp_conv_exact(exact)
     if old is None:
         os.environ.pop("POSEPIPE_CONV_EXACT", None)
     else:
