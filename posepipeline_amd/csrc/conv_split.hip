@@ -473,36 +473,73 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         return;
     }
 #endif
+    // all bias / residual loads are issued back to back from clamped (always valid) addresses before anything consumes them: one
+    // memory round trip per operand instead of one per (pixel block, channel group) -- the epilogue was 17 % of W48's 48-channel
+    // layers (profiles/r02_conv_split_ablation.txt)
+    bool cok[COB][4];
+    int cos[COB][4];
+    float4 b4[COB][4];
+#pragma unroll
+    for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = (cb0 + cb) * 32 + 8 * g + 4 * (lane >> 5);
+            cok[cb][g] = co < a.Cout;
+            cos[cb][g] = cok[cb][g] ? co : 0;
+            b4[cb][g] = *reinterpret_cast<const float4*>(a.bias + cos[cb][g]);
+        }
+    size_t ypix[PXB], r1pix[PXB], r2pix[PXB];
 #pragma unroll
     for (int pb = 0; pb < PXB; ++pb) {
-        if (!ook[pb]) continue;
-        const size_t ypix = ((size_t)on[pb] * (a.H + a.y_pad) + oy[pb]) * (a.W + a.y_pad) + ox[pb];
-        const size_t r1pix = ((size_t)on[pb] * (a.H + a.r1_pad) + oy[pb]) * (a.W + a.r1_pad) + ox[pb];
-        const size_t r2pix = ((size_t)on[pb] * (a.H + a.r2_pad) + oy[pb]) * (a.W + a.r2_pad) + ox[pb];
+        const int n_ = ook[pb] ? on[pb] : 0, y_ = ook[pb] ? oy[pb] : 0, x_ = ook[pb] ? ox[pb] : 0;
+        ypix[pb] = ((size_t)n_ * (a.H + a.y_pad) + y_) * (a.W + a.y_pad) + x_;
+        r1pix[pb] = ((size_t)n_ * (a.H + a.r1_pad) + y_) * (a.W + a.r1_pad) + x_;
+        r2pix[pb] = ((size_t)n_ * (a.H + a.r2_pad) + y_) * (a.W + a.r2_pad) + x_;
+    }
+    float4 rv[PXB][COB][4];
+    if (a.res1) {
 #pragma unroll
-        for (int cb = 0; cb < COB; ++cb) {
+        for (int pb = 0; pb < PXB; ++pb)
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) rv[pb][cb][g] = *reinterpret_cast<const float4*>(a.res1 + r1pix[pb] * a.Cout + cos[cb][g]);
+    }
+#pragma unroll
+    for (int pb = 0; pb < PXB; ++pb)
+#pragma unroll
+        for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int co = (cb0 + cb) * 32 + 8 * g + 4 * (lane >> 5);
-                if (co >= a.Cout) continue;
-                const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
                 const f32x16 cc = acc[cb][pb];
-                float4 v = make_float4(cc[4 * g + 0] + b4.x, cc[4 * g + 1] + b4.y, cc[4 * g + 2] + b4.z, cc[4 * g + 3] + b4.w);
+                const float4 b = b4[cb][g];
+                float4 v = make_float4(cc[4 * g + 0] + b.x, cc[4 * g + 1] + b.y, cc[4 * g + 2] + b.z, cc[4 * g + 3] + b.w);
                 if (a.relu == PP_RELU_FIRST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 else if (a.relu >= PP_ACT_LEAKY) { v.x = split_activate(v.x, a.relu); v.y = split_activate(v.y, a.relu); v.z = split_activate(v.z, a.relu); v.w = split_activate(v.w, a.relu); }
-                if (a.res1) {
-                    const float4 r = *reinterpret_cast<const float4*>(a.res1 + r1pix * a.Cout + co);
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                }
-                if (a.res2) {
-                    const float4 r = *reinterpret_cast<const float4*>(a.res2 + r2pix * a.Cout + co);
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                }
-                if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<float4*>(a.y + ypix * a.Cout + co) = v;
+                if (a.res1) { v.x += rv[pb][cb][g].x; v.y += rv[pb][cb][g].y; v.z += rv[pb][cb][g].z; v.w += rv[pb][cb][g].w; }
+                rv[pb][cb][g] = v;
             }
-        }
+    if (a.res2) {
+#pragma unroll
+        for (int pb = 0; pb < PXB; ++pb)
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 r = *reinterpret_cast<const float4*>(a.res2 + r2pix[pb] * a.Cout + cos[cb][g]);
+                    rv[pb][cb][g].x += r.x; rv[pb][cb][g].y += r.y; rv[pb][cb][g].z += r.z; rv[pb][cb][g].w += r.w;
+                }
     }
+#pragma unroll
+    for (int pb = 0; pb < PXB; ++pb)
+#pragma unroll
+        for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v = rv[pb][cb][g];
+                if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (ook[pb] && cok[cb][g]) *reinterpret_cast<float4*>(a.y + ypix[pb] * a.Cout + cos[cb][g]) = v;
+            }
 }
 
 // ---- 1x1 / full-cover layers with >= 128 output channels: 8 waves, 256 x 256 (or 512 x 128) output tile --------------------------
