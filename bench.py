@@ -400,7 +400,8 @@ def run_cascade(args, D):
                                 "384x288 flip_test + DARK decode -> VideoPose3D 243-frame lifting"),
                    "frames_per_step_per_gpu": B, "persons_per_frame": P,
                    "gflop_per_frame": flops_step / B / 1e9,
-                   "detector_boxes": "detector runs on every frame; downstream boxes are replayed synthetic GT (random-weight detector)"},
+                   "detector_boxes": "detector runs on every frame; downstream boxes are replayed synthetic GT (random-weight detector)",
+                   "detector_lookahead": bool(getattr(cas, "det_ctx", ctx) is not ctx)},
         "roofline": roof,
         "bit_exact_mode": exact_mode,
     }

@@ -44,7 +44,7 @@ class Cascade:
     def __init__(self, ctx: L.Context, det_sd, pose_sd: dict, lift_sd: dict, src_h: int, src_w: int,
                  chunk: int = 8, max_persons: int = 1, pose_spec=None, post="unbiased", blur_kernel=17,
                  tracking: str = "MMTrack_deepsort", keep_tracks=None, flip_pairs=None, blob_fn=None, reid_sd=None,
-                 overlap_detector: bool = True):
+                 overlap_detector: bool | None = None):
         """blob_fn(name, program) -> (device pointer, n_floats) or None, name in "det_a", "det_b", "pose", "lift" (called in
         that order): a weight blob that is already resident on the device -- parallel.broadcast_blob_device delivers rank
         0's over RCCL; the *_sd arguments then only define the program structure (ops, buffers, blob offsets).
@@ -52,7 +52,9 @@ class Cascade:
         its pass over the NEXT chunk on a worker thread while this chunk's tracking / 2D / 3D stages run -- the detector's
         big convolutions fill the CUs that HRNet's small maps leave idle, RoIAlign (HBM-bound) overlaps MFMA-bound work.
         Results are unchanged (same kernels, same order per stage).  Not with the ReID branch (it reads the detector's
-        resident input tensor of the CURRENT chunk)."""
+        resident input tensor of the CURRENT chunk).  None = automatic: on when the host has at least 4 cores per local rank
+        (the worker thread spends its time inside a synchronous GPU call, and HIP's waits spin), POSEPIPE_OVERLAP_DETECTOR=0/1
+        overrides."""
         self.ctx = ctx
         self.det_ctx = ctx
         self._pending = None          # (chunk key, Future of _det_job) started by step(prefetch=...)
@@ -71,7 +73,11 @@ class Cascade:
             self.encoder = mars.MarsEncoder(ctx, det_sd[1], src_h, src_w, max_patches=max(64, chunk * max_persons))
         else:
             assert tracking == "MMTrack_deepsort", tracking
-            self.det_ctx = L.Context(ctx.device) if (overlap_detector and reid_sd is None and os.environ.get("POSEPIPE_OVERLAP_DETECTOR", "1") != "0") else ctx
+            if overlap_detector is None:
+                env = os.environ.get("POSEPIPE_OVERLAP_DETECTOR")
+                ranks = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+                overlap_detector = (env != "0") if env is not None else (os.cpu_count() or 1) >= 4 * ranks
+            self.det_ctx = L.Context(ctx.device) if (overlap_detector and reid_sd is None) else ctx
             self.detector = fr.Detector(self.det_ctx, det_sd, src_h, src_w, max_frames=chunk, blob_fn=blob_fn)
             if reid_sd is not None:
                 from .models import reid_r50
