@@ -196,8 +196,9 @@ int pp_conv_force(int ct, int pt);
  * 0, 1 and 3 give bit-identical results (the k-ordered float32 FMA chain of oracle/conv_ref.c). */
 int pp_conv_variant(int variant);
 /* Numerics of the convolutions of all later launches (and of nets created later: their split weights are built at creation).
- * Default (0, or -1 with POSEPIPE_CONV_EXACT unset): 3x3 / stride-1 convolutions and 1x1 convolutions from 1024 input
- * channels run on v_mfma_f32_32x32x16_bf16 -- every float32 operand is split EXACTLY into three bfloat16 values and the six
+ * Default (0, or -1 with POSEPIPE_CONV_EXACT unset): 3x3 / stride-1 convolutions, 1x1 convolutions from 256 input channels with
+ * a multiple of 128 output channels (any from 1024), and full-cover 'valid' convolutions (the RoI head's FCs) run on
+ * v_mfma_f32_32x32x16_bf16 -- every float32 operand is split EXACTLY into three bfloat16 values and the six
  * partial products down to 2^-16 relative weight are accumulated in float32 (conv_split.hip).  The dropped terms are <= 2^-23
  * of a product, one float32 rounding; measured against a float64 convolution the result is as accurate as the float32 FMA
  * chain (tests/test_gpu_split.py), but it is not bit-identical to it.
