@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--persons", type=int, default=1, help="cascade: tracked persons per frame")
     ap.add_argument("--batch", type=int, default=64, help="c2 / c5: person-frames per step per GPU")
     ap.add_argument("--cpu-frames", type=int, default=None, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--profile-serial", action="store_true",
+                    help="cascade: the run to put under `rocprofv3 --kernel-trace --stats`: every launch on one stream, no detector "
+                         "look-ahead, no bit-exact / PCIe / CPU legs -- per-kernel durations are then additive and AverageNs of "
+                         "conv_split_* x launches_per_step reproduces roofline.ms_per_step_serial")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "shard"],
                     help="N > 1: independent frame shards per rank (default, no data-path collective) or ONE clip sharded over "
                          "the ranks with the detection / 2D all_gathers of posepipeline_amd/parallel.py")
@@ -248,6 +252,11 @@ def synth_1080p(rng, n_frames, persons, h=1080, w=1920):
 
 
 def run_cascade(args, D):
+    if args.profile_serial:
+        os.environ["POSEPIPE_NET_LANES"] = "1"
+        os.environ["POSEPIPE_OVERLAP_DETECTOR"] = "0"
+        if args.cpu_frames is None:
+            args.cpu_frames = 0
     from posepipeline_amd import _lib
     from posepipeline_amd.cascade import Cascade
     from posepipeline_amd.models import faster_rcnn as fr, hrnet, synth
@@ -371,22 +380,27 @@ def run_cascade(args, D):
                                   "timed region chunk k + 1's detector pass overlaps chunk k's 2D stage: step = %.1f ms against the %.1f ms "
                                   "these stages sum to" % (dt / K * 1e3, sum(stage.values())),
                  "stage_ms_overlapped": overlapped, "conv_programs": programs})
-    # the same workload on the bit-exact float32-MFMA kernels only (pp_conv_exact(1)): reported beside `value` (N = 1 leg)
+    # the same workload on the bit-exact float32-MFMA kernels only: a second cascade whose programs are CREATED exact (a net's
+    # numerics are fixed at creation, ABI 7); reported beside `value` (N = 1 leg)
     exact_mode = None
-    if D.world == 1:
-        _lib.check(ctx.lib.pp_conv_exact(1), "pp_conv_exact")
-        step()
+    cas_exact = None
+    if D.world == 1 and not args.profile_serial:
+        with _lib.default_numerics("exact"):
+            cas_exact = Cascade(ctx, det_sd, pose_sd, lift_sd, 1080, 1920, chunk=B, max_persons=P, pose_spec=pose_spec)
+
+        def step_exact(more=False):
+            return cas_exact.step(None, frames_dev=(dptr, B), replay=replay_boxes(), prefetch=(None, (dptr, B)) if more else None)
+        step_exact()
         ctx.synchronize()
         t0 = time.perf_counter()
         n_exact = max(2, K // 2)
         for i in range(n_exact):
-            step(more=i + 1 < n_exact)
+            step_exact(more=i + 1 < n_exact)
         ctx.synchronize()
         dt_exact = time.perf_counter() - t0
-        _lib.check(ctx.lib.pp_conv_exact(-1), "pp_conv_exact")
         exact_mode = {"value": B * n_exact / dt_exact, "unit": "frames/s", "steps": n_exact,
-                      "note": "POSEPIPE_CONV_EXACT=1 / pp_conv_exact(1): every convolution on v_mfma_f32_16x16x4_f32, results "
-                              "bit-identical to oracle/conv_ref.c"}
+                      "note": "the same cascade with its programs created PP_NET_NUMERICS_EXACT (POSEPIPE_CONV_EXACT=1): every "
+                              "convolution on v_mfma_f32_16x16x4_f32, results bit-identical to oracle/conv_ref.c"}
     out = {
         "metric": METRIC, "value": D.world * B * K / dt, "unit": "frames/s", "n_gpus": D.world, "steps": K,
         "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -401,13 +415,15 @@ def run_cascade(args, D):
                    "frames_per_step_per_gpu": B, "persons_per_frame": P,
                    "gflop_per_frame": flops_step / B / 1e9,
                    "detector_boxes": "detector runs on every frame; downstream boxes are replayed synthetic GT (random-weight detector)",
-                   "detector_lookahead": bool(getattr(cas, "det_ctx", ctx) is not ctx)},
+                   "detector_lookahead": bool(getattr(cas, "det_ctx", ctx) is not ctx),
+                   "host_cores_per_rank": (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", D.world))),
+                   "profile_serial": bool(args.profile_serial)},
         "roofline": roof,
         "bit_exact_mode": exact_mode,
     }
     if D.world > 1:
         out["per_rank_ms_per_step"] = per_rank
-    if D.world == 1:
+    if D.world == 1 and not args.profile_serial:
         # PCIe-inclusive leg (reported beside `value`, never as it): the same chunks streamed from host memory through
         # page-locked staging buffers and the copy stream (posepipeline_amd/streaming.py), upload overlapped with compute
         from posepipeline_amd.video import ArrayVideo
@@ -435,9 +451,9 @@ def run_cascade(args, D):
     if vit:
         out["roofline"]["vit_stage"] = {"backbone_ms": stage["pose_backbone"], "program_tflops": pose_flops / (stage["pose_backbone"] * 1e-3) / 1e12,
                                         "note": "ViTPose-H program (bf16 GEMMs + fp32 patch embedding / head); roofline line: --workload c5"}
-    n_cpu = 1 if args.cpu_frames is None else args.cpu_frames
+    n_cpu = 8 if args.cpu_frames is None else args.cpu_frames
     if n_cpu > 0 and D.world == 1 and not vit:          # the CPU baseline is a rank-0, N=1 leg (c5 carries the ViT one)
-        out["cpu_baseline"] = cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames[0], gt[0][0], cas, ctx)
+        out["cpu_baseline"] = cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames, gt, n_cpu, {"bit_exact_mode": cas_exact, "default": cas})
     print(json.dumps(out), flush=True)
 
 
@@ -484,17 +500,20 @@ def run_cascade_sharded(args, D, ctx, cas):
     flops_step = B * (cas.detector.flops_per_frame + 2 * P * cas.pose_net.prog.flops)
     print(json.dumps({
         "metric": METRIC, "value": D.world * B * K / dt, "unit": "frames/s", "n_gpus": D.world, "steps": K, "warmup": args.warmup,
-        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" + DTYPE_NOTE, "data": "synthetic",
         "config": {"workload": "configs[3]: ONE 1080p clip of %d frames sharded over %d rank(s): detect (Faster-RCNN R50-FPN) -> all_gather of "
                                "detection slabs -> SORT on every rank -> HRNet-W48 384x288 flip_test + DARK decode on the own shard -> "
                                "all_gather of 2D rows -> VideoPose3D 243-frame lifting" % (D.world * B * K, D.world),
                    "mode": "shard", "frames_per_step_per_gpu": B, "persons_per_frame": P, "gflop_per_frame": flops_step / B / 1e9,
                    "tracks": len(res["keypoints_3d"]),
                    "detector_boxes": "detector runs on every frame; downstream boxes are replayed synthetic GT (random-weight detector)"},
-        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": D.world * flops_step * K / dt / 1e12 / D.world,
-                     "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flops_step * K / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "note": "end-to-end conv FLOP rate per GPU over the whole sharded run (the per-kernel roofline "
-                                              "line is the default mode's)"},
+        "roofline": {"bound": "mfma", "kernel": "conv_split_kernel (+ the float32 MFMA kernels on the layers it does not take), whole step",
+                     "achieved": flops_step * K / dt / 1e12,
+                     "peak": BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS, "unit": "TFLOP/s", "frac": flops_step * K / dt / 1e12 / (BF16_MFMA_PEAK_TFLOPS / SPLIT_PRODUCTS),
+                     "traffic": None, "peak_note": "2500 TFLOP/s dense bf16 / 6 MFMA products per float32 term",
+                     "note": "END-TO-END float32-equivalent conv FLOP rate per GPU over the whole sharded run (host phases and collectives "
+                             "included) against the split kernel's peak; the per-kernel roofline line is the default mode's"},
+        "host_cores_per_rank": (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", D.world))),
         "per_rank_phase_ms": per_rank,
     }), flush=True)
 
@@ -504,48 +523,61 @@ def _lib_check(rc):
         raise RuntimeError("libposepipe_hip call failed: %d" % rc)
 
 
-def cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frame_bgr, gt_box, cas, ctx):
-    """CPU restatement of the reference wrapper path (oracle/) for ONE 1080p frame: detector, then the
-    top-down stage on the frame's (replayed) person box, then one 243-frame lifting window -- the per-frame bodies of
-    wrappers/mmtrack.py:37-60, wrappers/mmpose.py:60-76 and wrappers/videopose3d.py:77-85."""
+def cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames, gt, n_frames, cascades, timed_frames=2):
+    """CPU restatement of the reference wrapper path (oracle/) per 1080p frame: detector, then the top-down stage on the
+    frame's (replayed) person box, then one 243-frame lifting window -- the per-frame bodies of wrappers/mmtrack.py:37-60,
+    wrappers/mmpose.py:60-76 and wrappers/videopose3d.py:77-85.  The first `timed_frames` frames are the timed sample; all
+    `n_frames` (spread over the chunk) go through the GPU path as well -- the detector's own boxes, NOT replayed -- once per
+    numerics mode (cascades: {"bit_exact_mode": a cascade created exact, "default": the timed one}) for the parity readout."""
     from oracle import clib
     from oracle import decode as odec
     from oracle import detector as odet
     from oracle import nets as onets
     from oracle import preprocess as opre
     from posepipeline_amd.models import hrnet
-    from posepipeline_amd.wrappers.videopose3d import normalize_screen_coordinates
+    from posepipeline_amd.wrappers.videopose3d import lift, normalize_screen_coordinates
     clib.lib()
-    t0 = time.perf_counter()
-    dets = odet.detect(odet.FasterRCNNRef(det_sd), frame_bgr[:, :, ::-1])
-    t_det = time.perf_counter() - t0
-    bb = np.array([gt_box[0], gt_box[1], gt_box[2] - gt_box[0], gt_box[3] - gt_box[1]], np.float64)
-    t, c, s, _ = opre.top_down_input(frame_bgr[:, :, ::-1], bb, (288, 384))
-    model = onets.HRNetRef(pose_sd, 48)
-    hm = model.forward(t[None])
-    hmf = model.forward(np.ascontiguousarray(t[None, :, :, ::-1]))
-    kp, _ = odec.decode_topdown(hm, hmf, hrnet.COCO_FLIP_PAIRS, c[None], s[None], post_process="unbiased", kernel=17)
-    kn = normalize_screen_coordinates(kp[:, :, :2].astype(np.float64), 1920, 1080).astype(np.float32)
-    k3 = onets.VideoPose3DRef(lift_sd).forward(onets.videopose3d_windows(kn, 121))
-    dt = time.perf_counter() - t0
-    # the same frame through the GPU path (detector boxes NOT replayed) for a parity readout: on the bit-exact kernels and on
-    # the default (bf16-split) kernels
-    from posepipeline_amd.wrappers.videopose3d import lift
+    det_model, pose_model, lift_model = odet.FasterRCNNRef(det_sd), onets.HRNetRef(pose_sd, 48), onets.VideoPose3DRef(lift_sd)
+    pick = sorted({int(round(i * (len(frames) - 1) / max(1, n_frames - 1))) for i in range(n_frames)})
+    ref, dt, t_det = [], 0.0, 0.0
+    for j, fi in enumerate(pick):
+        frame_bgr, gt_box = frames[fi], gt[fi][0]
+        t0 = time.perf_counter()
+        dets = odet.detect(det_model, frame_bgr[:, :, ::-1])
+        t1 = time.perf_counter()
+        bb = np.array([gt_box[0], gt_box[1], gt_box[2] - gt_box[0], gt_box[3] - gt_box[1]], np.float64)
+        t, c, s, _ = opre.top_down_input(frame_bgr[:, :, ::-1], bb, (288, 384))
+        hm = pose_model.forward(t[None])
+        hmf = pose_model.forward(np.ascontiguousarray(t[None, :, :, ::-1]))
+        kp, _ = odec.decode_topdown(hm, hmf, hrnet.COCO_FLIP_PAIRS, c[None], s[None], post_process="unbiased", kernel=17)
+        kn = normalize_screen_coordinates(kp[:, :, :2].astype(np.float64), 1920, 1080).astype(np.float32)
+        k3 = lift_model.forward(onets.videopose3d_windows(kn, 121))
+        if j < timed_frames:
+            dt += time.perf_counter() - t0
+            t_det += t1 - t0
+        ref.append((fi, bb, dets, kp, k3))
+    n_timed = min(timed_frames, len(pick))
     readout = {}
-    for mode, exact in (("bit_exact_mode", 1), ("default", -1)):
-        _lib_check(ctx.lib.pp_conv_exact(exact))
-        g = cas.detector.run(frame_bgr[None])[0]
-        kg, _ = cas.topdown.run(frame_bgr[None], np.zeros(1, np.int32), bb[None])
-        k3g = lift(cas.lift_net, cas.lift_spec, normalize_screen_coordinates(kg[:, :, :2].astype(np.float64), 1920, 1080))
-        same_n = g.shape == dets.shape
-        readout[mode] = {"detections_equal": bool(same_n and np.array_equal(g, dets)),
-                         "max_abs_diff_boxes_px": float(np.abs(g[:, :4] - dets[:, :4]).max()) if same_n and len(g) else None,
-                         "max_abs_diff_2d_px": float(np.abs(kg[0, :, :2] - kp[0, :, :2]).max()),
-                         "max_abs_diff_3d": float(np.abs(k3g - k3).max())}
-    _lib_check(ctx.lib.pp_conv_exact(-1))
-    return {"value": 1.0 / dt, "unit": "frames/s", "cores": clib.N_THREADS, "kind": "port",
-            "sample": "1 synthetic 1080p frame through the CPU restatement of detect + top-down 2D (W48, flip) + one lifting window "
-                      "(%.1f s, detector %.1f s)" % (dt, t_det),
+    for mode, cas in cascades.items():
+        if cas is None:
+            continue
+        eq, box_d, d2, d3, n_det = 0, 0.0, 0.0, 0.0, 0
+        for fi, bb, dets, kp, k3 in ref:
+            g = cas.detector.run(frames[fi][None])[0]
+            kg, _ = cas.topdown.run(frames[fi][None], np.zeros(1, np.int32), bb[None])
+            k3g = lift(cas.lift_net, cas.lift_spec, normalize_screen_coordinates(kg[:, :, :2].astype(np.float64), 1920, 1080))
+            same_n = g.shape == dets.shape
+            eq += bool(same_n and np.array_equal(g, dets))
+            n_det += len(dets)
+            if same_n and len(g):
+                box_d = max(box_d, float(np.abs(g[:, :4] - dets[:, :4]).max()))
+            d2 = max(d2, float(np.abs(kg[0, :, :2] - kp[0, :, :2]).max()))
+            d3 = max(d3, float(np.abs(k3g - k3).max()))
+        readout[mode] = {"frames": len(ref), "frames_with_identical_detections": eq, "oracle_detections": n_det,
+                         "max_abs_diff_boxes_px": box_d, "max_abs_diff_2d_px": d2, "max_abs_diff_3d": d3}
+    return {"value": n_timed / dt, "unit": "frames/s", "cores": clib.N_THREADS, "kind": "port",
+            "sample": "%d synthetic 1080p frame(s) through the CPU restatement of detect + top-down 2D (W48, flip) + one lifting window "
+                      "(%.1f s, detector %.1f s); parity readout over %d frames" % (n_timed, dt, t_det, len(ref)),
             "parity_vs_gpu": readout}
 
 

@@ -31,13 +31,15 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 6   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
+#define PP_ABI_VERSION 7   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
                               3: PP_OP_VIT_ENCODER / PP_OP_DEPTH_TO_SPACE, bf16 building blocks, UDP top-down (post 2)
                               4: pp_memcpy_d2d, pp_net_create_mem (weights already on the device, e.g. an RCCL broadcast)
                               5: pp_buf.pad (zero halo of conv-only buffers), PP_OP_AVGPOOL, pp_crop_resize_bilinear,
                                  pp_conv_force / pp_conv_variant
                               6: pp_conv_exact, pp_net_conv_kinds; pp_conv_variant accepts 4 (fp32 convolutions on the bf16 matrix cores by a
-                                 three-way operand split are the default where a layer is eligible) */
+                                 three-way operand split are the default where a layer is eligible)
+                              7: pp_net_create_ex / pp_net_numerics: the numerics of a program are fixed when it is created (a per-net
+                                 property, no longer read from the process-wide switch at launch time) */
 
 typedef enum {
     PP_OK = 0,
@@ -165,6 +167,18 @@ int pp_net_create(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, 
  * and copies it device-to-device into the program's own allocation; no host round trip. */
 int pp_net_create_mem(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, int n_bufs,
                       const float* weights, size_t n_weights, int weights_mem, int max_batch, pp_net** out);
+/* same, with the program's convolution numerics chosen explicitly (they are a property of the net, fixed here: split weights
+ * are built at creation, and every later launch of this net -- from any thread, under any later pp_conv_exact call -- runs the
+ * same kernels):  PP_NET_NUMERICS_DEFAULT = what pp_conv_exact / POSEPIPE_CONV_EXACT select at this moment (what pp_net_create
+ * and pp_net_create_mem do), PP_NET_NUMERICS_EXACT = every layer on the float32 MFMA kernels (bit-identical to
+ * oracle/conv_ref.c), PP_NET_NUMERICS_SPLIT = eligible layers on the bf16 matrix cores (three-way split, see pp_conv_exact). */
+#define PP_NET_NUMERICS_DEFAULT 0
+#define PP_NET_NUMERICS_EXACT 1
+#define PP_NET_NUMERICS_SPLIT 2
+int pp_net_create_ex(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, int n_bufs,
+                     const float* weights, size_t n_weights, int weights_mem, int max_batch, int numerics, pp_net** out);
+/* PP_NET_NUMERICS_EXACT or PP_NET_NUMERICS_SPLIT: what the net was created with (never DEFAULT) */
+int pp_net_numerics(pp_net* net);
 void pp_net_destroy(pp_net* net);
 /* device address of activation buffer `buf` (batch-major, then the pp_buf layout) */
 int pp_net_buffer(pp_net* net, int buf, void** dptr, size_t* bytes_per_sample);
@@ -181,7 +195,7 @@ int pp_net_set_lanes(pp_net* net, int enable);
 int pp_net_capture(pp_net* net, int batch);
 /* per-op elapsed time of the last profiled run (HIP events around each op), ms; NULL-safe */
 int pp_net_profile(pp_net* net, int batch, float* ms_per_op);
-/* which kernel family each op launches under the CURRENT numerics setting: 0 = not a convolution, 1 = float32 MFMA kernels
+/* which kernel family each op of this net launches (fixed at creation): 0 = not a convolution, 1 = float32 MFMA kernels
  * (conv_igemm*.hip), 2 = bf16-split kernel (conv_split.hip).  kinds: n_ops ints.  (bench.py prices the two families
  * against their own peaks.) */
 int pp_net_conv_kinds(pp_net* net, int* kinds);
@@ -195,7 +209,9 @@ int pp_conv_force(int ct, int pt);
  * -1 = default (POSEPIPE_CONV_VARIANT, else: the split kernel where eligible, 0 / 3 elsewhere).
  * 0, 1 and 3 give bit-identical results (the k-ordered float32 FMA chain of oracle/conv_ref.c). */
 int pp_conv_variant(int variant);
-/* Numerics of the convolutions of all later launches (and of nets created later: their split weights are built at creation).
+/* Process-wide DEFAULT numerics: what nets created LATER with PP_NET_NUMERICS_DEFAULT get, and what the single-op entry point
+ * pp_conv2d uses.  Nets that already exist are not affected (ABI 7: their numerics were fixed at creation); safe to call from
+ * any thread.
  * Default (0, or -1 with POSEPIPE_CONV_EXACT unset): 3x3 / stride-1 convolutions, 1x1 convolutions from 256 input channels with
  * a multiple of 128 output channels (any from 1024), and full-cover 'valid' convolutions (the RoI head's FCs) run on
  * v_mfma_f32_32x32x16_bf16 -- every float32 operand is split EXACTLY into three bfloat16 values and the six

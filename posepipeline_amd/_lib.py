@@ -20,6 +20,8 @@ PP_OP_DECONV_BF16 = 8
 PP_OP_AVGPOOL = 9
 PP_RELU_NONE, PP_RELU_LAST, PP_RELU_FIRST = 0, 1, 2
 PP_ACT_LEAKY, PP_ACT_MISH, PP_ACT_ELU, PP_ACT_SWISH = 3, 4, 5, 6
+PP_NET_NUMERICS_DEFAULT, PP_NET_NUMERICS_EXACT, PP_NET_NUMERICS_SPLIT = 0, 1, 2
+NUMERICS = {None: 0, "default": 0, "exact": 1, "split": 2}
 
 
 class PosePipeHipError(RuntimeError):
@@ -86,6 +88,8 @@ SIGNATURES = {
     "pp_upload_release": (_i, [_vp]),
     "pp_net_create": (_i, [_vp, C.POINTER(pp_op), _i, C.POINTER(pp_buf), _i, _vp, _sz, _i, C.POINTER(_vp)]),
     "pp_net_create_mem": (_i, [_vp, C.POINTER(pp_op), _i, C.POINTER(pp_buf), _i, _vp, _sz, _i, _i, C.POINTER(_vp)]),
+    "pp_net_create_ex": (_i, [_vp, C.POINTER(pp_op), _i, C.POINTER(pp_buf), _i, _vp, _sz, _i, _i, _i, C.POINTER(_vp)]),
+    "pp_net_numerics": (_i, [_vp]),
     "pp_net_destroy": (None, [_vp]),
     "pp_net_buffer": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_sz)]),
     "pp_net_run": (_i, [_vp, _i, _i, _i]),
@@ -154,6 +158,27 @@ def load_library() -> C.CDLL:
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+import contextlib
+
+
+@contextlib.contextmanager
+def default_numerics(mode):
+    """Process-wide default numerics ("exact" / "split" / None = the environment's) for the nets CREATED inside the block -- composite
+    objects (Cascade, Detector, TopDown wrappers) create theirs in their constructors.  A net keeps what it was created with."""
+    lib = load_library()
+    prev = _DEFAULT_NUMERICS[0]
+    check(lib.pp_conv_exact({None: -1, "default": -1, "exact": 1, "split": 0}[mode]), "pp_conv_exact")
+    _DEFAULT_NUMERICS[0] = mode
+    try:
+        yield
+    finally:
+        check(lib.pp_conv_exact({None: -1, "default": -1, "exact": 1, "split": 0}[prev]), "pp_conv_exact")
+        _DEFAULT_NUMERICS[0] = prev
+
+
+_DEFAULT_NUMERICS = [None]
 
 
 def last_error() -> str:

@@ -201,6 +201,7 @@ struct pp_net {
     // conv_split.hip: the eligible convs' weights as bf16 planes in fragment order (built on the device at creation)
     unsigned char* wsplit = nullptr;
     std::vector<long long> wsplit_off;   // per op: byte offset into wsplit, -1: the op runs on the fp32-MFMA kernels
+    int numerics = PP_NET_NUMERICS_EXACT;   // fixed at creation (ABI 7)
     float* arena = nullptr;
     size_t arena_floats = 0;
     int max_batch = 0;
@@ -379,6 +380,7 @@ static ConvArgs net_conv_args(pp_net* net, const pp_op& op, int batch) {
     a.r2_pad = op.res2 >= 0 ? net->bufs[op.res2].pad : 0;
     const size_t idx = &op - net->ops.data();
     a.wsplit = (net->wsplit && idx < net->wsplit_off.size() && net->wsplit_off[idx] >= 0) ? net->wsplit + net->wsplit_off[idx] : nullptr;
+    a.numerics = net->numerics;
     return a;
 }
 
@@ -435,7 +437,15 @@ int pp_net_create(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, 
 
 int pp_net_create_mem(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, int n_bufs,
                       const float* weights, size_t n_weights, int weights_mem, int max_batch, pp_net** out) {
+    return pp_net_create_ex(ctx, ops, n_ops, bufs, n_bufs, weights, n_weights, weights_mem, max_batch, PP_NET_NUMERICS_DEFAULT, out);
+}
+
+int pp_net_numerics(pp_net* net) { return net ? net->numerics : PP_ERR_ARG; }
+
+int pp_net_create_ex(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, int n_bufs,
+                     const float* weights, size_t n_weights, int weights_mem, int max_batch, int numerics, pp_net** out) {
     PP_REQUIRE(ctx && ops && bufs && weights && out, "pp_net_create: NULL argument");
+    PP_REQUIRE(numerics >= PP_NET_NUMERICS_DEFAULT && numerics <= PP_NET_NUMERICS_SPLIT, "pp_net_create_ex: bad numerics %d", numerics);
     PP_REQUIRE(weights_mem == PP_MEM_HOST || weights_mem == PP_MEM_DEVICE, "pp_net_create: bad weights_mem %d", weights_mem);
     PP_REQUIRE(n_ops > 0 && n_bufs > 0 && max_batch > 0, "pp_net_create: empty program");
     *out = nullptr;
@@ -445,6 +455,8 @@ int pp_net_create_mem(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bu
     net->bufs.assign(bufs, bufs + n_bufs);
     net->max_batch = max_batch;
     net->n_weights = n_weights;
+    // the process-wide switch is read HERE, once: later pp_conv_exact calls (or other threads) do not change this net
+    net->numerics = numerics != PP_NET_NUMERICS_DEFAULT ? numerics : (pp_conv_split_enabled() ? PP_NET_NUMERICS_SPLIT : PP_NET_NUMERICS_EXACT);
     size_t off = 0;
     for (int b = 0; b < n_bufs; ++b) {
         PP_REQUIRE(bufs[b].h > 0 && bufs[b].w > 0 && bufs[b].c > 0 && bufs[b].pad >= 0 && bufs[b].pad <= 8, "buffer %d has an empty dim / bad halo", b);
@@ -488,7 +500,7 @@ int pp_net_create_mem(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bu
     }
     // bf16-split copies of the weights of every conv the split kernel will run
     net->wsplit_off.assign(n_ops, -1);
-    if (pp_conv_split_enabled()) {
+    if (net->numerics == PP_NET_NUMERICS_SPLIT) {
         size_t bytes = 0;
         for (int i = 0; i < n_ops; ++i) {
             if (net->ops[i].type != PP_OP_CONV) continue;
@@ -533,13 +545,12 @@ int pp_net_create_mem(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bu
 
 int pp_net_conv_kinds(pp_net* net, int* kinds) {
     PP_REQUIRE(net && kinds, "pp_net_conv_kinds: NULL argument");
-    const bool split = pp_conv_split_enabled();
     for (size_t i = 0; i < net->ops.size(); ++i) {
         if (net->ops[i].type != PP_OP_CONV) {
             kinds[i] = 0;
             continue;
         }
-        kinds[i] = (split && net->wsplit && net->wsplit_off[i] >= 0) ? 2 : 1;
+        kinds[i] = (net->numerics == PP_NET_NUMERICS_SPLIT && net->wsplit && net->wsplit_off[i] >= 0) ? 2 : 1;
     }
     return PP_OK;
 }

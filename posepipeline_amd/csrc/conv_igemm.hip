@@ -27,6 +27,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -628,12 +629,14 @@ static void magic_u32(unsigned d, unsigned* m, unsigned* s1, unsigned* s2) {
 
 // The split kernel is the default where a layer is eligible; POSEPIPE_CONV_EXACT=1 or an explicit variant 0 / 1 / 3 keeps every
 // layer on the bit-exact fp32-MFMA kernels.
-int g_exact = -1;                     // pp_conv_exact: -1 = POSEPIPE_CONV_EXACT
+// Process-wide DEFAULT only (ABI 7): read once when a net is created and by the single-op API; a net's numerics are its own.
+std::atomic<int> g_exact{-1};         // pp_conv_exact: -1 = POSEPIPE_CONV_EXACT
 bool pp_conv_split_enabled() {
     static const int env_exact = env_int("POSEPIPE_CONV_EXACT", 0);
     static const int env_variant = env_int("POSEPIPE_CONV_VARIANT", -1);
     const int v = g_variant >= 0 ? g_variant : env_variant;
-    const int exact = g_exact >= 0 ? g_exact : env_exact;
+    const int ge = g_exact.load(std::memory_order_relaxed);
+    const int exact = ge >= 0 ? ge : env_exact;
     return v == 4 || (v < 0 && !exact);
 }
 
@@ -642,7 +645,7 @@ extern "C" int pp_conv_exact(int exact) {
         pp_set_error("pp_conv_exact: 1 (bit-exact fp32 MFMA kernels), 0 (bf16-split kernels where eligible) or -1 (POSEPIPE_CONV_EXACT)");
         return PP_ERR_ARG;
     }
-    g_exact = exact;
+    g_exact.store(exact, std::memory_order_relaxed);
     return PP_OK;
 }
 
@@ -698,7 +701,10 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
     }
     a.x_bytes = (unsigned)((size_t)a.N * img_bytes);
     if (a.y_stride == 0) a.y_stride = a.Cout;
-    if (pp_conv_split_enabled() && pp_conv_split_eligible(a)) {
+    // an op of a net: the split kernel exactly where the net built split weights at creation (nothing is decided at launch time);
+    // single-op API (numerics 0): the process-wide setting, with a temporary split copy of the weights
+    if (a.numerics == PP_NET_NUMERICS_SPLIT && a.wsplit) return pp_launch_conv_split(a, stream);
+    if (a.numerics == 0 && pp_conv_split_enabled() && pp_conv_split_eligible(a)) {
         if (a.wsplit) return pp_launch_conv_split(a, stream);
         void* tmp = nullptr;                 // single-op API: split the weights for this call
         PP_HIP_CHECK(hipMalloc(&tmp, pp_conv_split_bytes(a)));

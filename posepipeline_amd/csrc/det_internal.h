@@ -33,8 +33,9 @@ int det_enqueue_rpn(hipStream_t s, const DetRpnArgs& a, int n_frames);
 int det_enqueue_gather(hipStream_t s, const float* boxes, const float* scores, int max_n, const int32_t* keep,
                        const int32_t* n_keep, int limit, float* out_box, float* out_score, int32_t* n_out, int out5,
                        int n_frames);
+// separable != 0: the default-numerics form (same samples, separable evaluation order); 0: the oracle's (iy, ix) order
 int det_enqueue_roi_align(hipStream_t s, const DetFpnArgs& a, const float* rois, const int32_t* n_rois, int max_rois,
-                          float* out, int n_frames);
+                          float* out, int n_frames, int separable);
 int det_enqueue_final_decode(hipStream_t s, const float* rois, const int32_t* n_rois, int max_rois, const float* cls,
                              const float* reg, float sfx, float sfy, float score_thr, float* boxes, float* scores,
                              int32_t* n_out, int n_frames);

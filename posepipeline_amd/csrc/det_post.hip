@@ -412,6 +412,159 @@ __global__ __launch_bounds__(256) void roi_align_kernel(FpnLevels L, int C, cons
     }
 }
 
+// ---- RoIAlign of the DEFAULT numerics: the same average of bilinear samples, evaluated separably --------------------------------
+// profiles/r02_roi_pmc.txt: roi_align_kernel is VALU-bound (5.8e9 vector instructions per 64-frame launch = 9.5 ms of the SIMDs'
+// time; ~200 instructions per sample and wave for 4 taps of address arithmetic and 16 multiply-adds), not memory-bound.
+// A sample's four weights are products hy*hx, hy*lx, ly*hx, ly*lx and the sample grid of a bin is a tensor product (y depends on
+// iy only, x on ix only), so
+//     out[ph][pw][c] = 1/count * sum_iy sum_ix bilinear(y_iy, x_ix)[c] = sum_Y Wy[ph][Y] * ( sum_X Wx[pw][X] * F[Y][X][c] )
+// with Wx[pw][X] = sum over the bin's valid x samples of (hx if x_low == X) + (lx if x_high == X), Wy likewise.  The inner sums
+// T[Y][pw] are computed once per feature row and shared by every sample row and bin that touches the row: ~8 K vector
+// instructions per RoI instead of ~90 K, every window pixel fetched from L2 about once instead of once per tap.
+// Same sample positions, validity rule and clamping as mmcv's kernel; the float32 sum is taken in another ORDER,
+// so this form belongs to the default numerics (tolerance-based parity, tests/test_gpu_split.py); programs created
+// PP_NET_NUMERICS_EXACT keep roi_align_kernel, whose (iy, ix) accumulation order is the oracle's.
+// One wave per RoI, lane = 4 channels (C = 256).  x weights live in two registers ACROSS the lanes (entry pw * S + j, S = gw + 2
+// columns per bin) and reach the multiply-adds as scalars through v_readlane; RoIs wider than 16 samples per bin take the exact
+// loop (rare: > 112 feature pixels).
+__device__ __forceinline__ float4 fma4(float w, const float4 v, const float4 a) {
+    return make_float4(fmaf(w, v.x, a.x), fmaf(w, v.y, a.y), fmaf(w, v.z, a.z), fmaf(w, v.w, a.w));
+}
+
+__global__ __launch_bounds__(256) void roi_align_sep_kernel(FpnLevels L, int C, const float* __restrict__ rois,
+                                                            const int32_t* __restrict__ n_rois, int max_rois, float* __restrict__ out) {
+    const int f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (r >= max_rois) return;
+    float* o = out + ((size_t)f * max_rois + r) * 49 * C + lane * 4;
+    if (r >= n_rois[f]) {
+#pragma unroll 7
+        for (int b = 0; b < 49; ++b) *reinterpret_cast<float4*>(o + b * C) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const float* roi = rois + ((size_t)f * max_rois + r) * 4;
+    const float rx1 = roi[0], ry1 = roi[1], rx2 = roi[2], ry2 = roi[3];
+    const int lvl = roi_level(rx1, ry1, rx2, ry2);
+    const float ss = 1.0f / (float)L.stride[lvl];
+    const int H = L.h[lvl], W = L.w[lvl];
+    const float* feat = L.feat[lvl] + (size_t)f * H * W * C + lane * 4;
+    const float x1 = rx1 * ss - 0.5f, y1 = ry1 * ss - 0.5f, x2 = rx2 * ss - 0.5f, y2 = ry2 * ss - 0.5f;
+    const float rw = x2 - x1, rh = y2 - y1;
+    const float bw = rw / 7.f, bh = rh / 7.f;
+    const int gh = __builtin_amdgcn_readfirstlane((int)ceilf(rh / 7.f)), gw = __builtin_amdgcn_readfirstlane((int)ceilf(rw / 7.f));
+    const float count = (float)max(gh * gw, 1);
+    const int S = gw + 2;
+    if (gw < 1 || gh < 1 || 7 * S > 128) {
+        // degenerate (empty) or very wide RoI: the exact loop, one wave for all 49 bins
+        for (int bin = 0; bin < 49; ++bin) {
+            const int ph = bin / 7, pw = bin - ph * 7;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int iy = 0; iy < gh; ++iy) {
+                const float y = (y1 + (float)ph * bh) + (((float)iy + 0.5f) * bh) / (float)gh;
+                for (int ix = 0; ix < gw; ++ix) {
+                    const float x = (x1 + (float)pw * bw) + (((float)ix + 0.5f) * bw) / (float)gw;
+                    const float4 v = bilinear4(feat, H, W, C, 0, y, x);
+                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                }
+            }
+            *reinterpret_cast<float4*>(o + bin * C) = make_float4(acc.x / count, acc.y / count, acc.z / count, acc.w / count);
+        }
+        return;
+    }
+    // ---- x weights: entry e = pw * S + j is column xb[pw] + j of bin pw; lane e & 63 of register e >> 6 ------------------------
+    int xb[7];
+#pragma unroll
+    for (int pw = 0; pw < 7; ++pw) {
+        const float xf = (x1 + (float)pw * bw) + (0.5f * bw) / (float)gw;       // the bin's first sample
+        xb[pw] = __builtin_amdgcn_readfirstlane(min(max((int)floorf(xf), 0), W - 1));
+    }
+    float wx[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = q * 64 + lane;
+        const int pw = e / S, j = e - pw * S;
+        float w = 0.f;
+        if (pw < 7) {
+            int xbp = xb[0];
+#pragma unroll
+            for (int k = 1; k < 7; ++k) xbp = pw == k ? xb[k] : xbp;
+            const int X = xbp + j;
+            for (int ix = 0; ix < gw; ++ix) {
+                float x = (x1 + (float)pw * bw) + (((float)ix + 0.5f) * bw) / (float)gw;
+                if (x < -1.0f || x > (float)W) continue;
+                if (x <= 0.f) x = 0.f;
+                int xl = (int)x, xh;
+                if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                const float lx = x - (float)xl, hx = 1.f - lx;
+                if (xl == X) w += hx;
+                if (xh == X) w += lx;
+            }
+        }
+        wx[q] = w;
+    }
+    // ---- rows: T[pw] = sum_X Wx[pw][X] F[row][X]; the two most recent rows stay in registers -----------------------------------
+    float4 T0[7], T1[7];
+    int R0 = -1000, R1 = -1000;
+    auto load_row = [&](int row) {          // T1 <- T0, T0 <- row
+#pragma unroll
+        for (int pw = 0; pw < 7; ++pw) T1[pw] = T0[pw];
+        R1 = R0;
+#pragma unroll
+        for (int pw = 0; pw < 7; ++pw) T0[pw] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* frow = feat + (size_t)row * W * C;
+        for (int j = 0; j < S; ++j) {
+            float4 v[7];
+#pragma unroll
+            for (int pw = 0; pw < 7; ++pw) v[pw] = *reinterpret_cast<const float4*>(frow + (size_t)min(xb[pw] + j, W - 1) * C);
+#pragma unroll
+            for (int pw = 0; pw < 7; ++pw) {
+                const int e = pw * S + j;                                             // wave-uniform
+                const float w = e < 64 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wx[0]), e))
+                                       : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wx[1]), e - 64));
+                T0[pw] = fma4(w, v[pw], T0[pw]);
+            }
+        }
+        R0 = row;
+    };
+    const float inv = 1.0f / count;
+    for (int ph = 0; ph < 7; ++ph) {
+        float4 acc[7];
+#pragma unroll
+        for (int pw = 0; pw < 7; ++pw) acc[pw] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int iy = 0; iy < gh; ++iy) {
+            float y = (y1 + (float)ph * bh) + (((float)iy + 0.5f) * bh) / (float)gh;
+            if (y < -1.0f || y > (float)H) continue;
+            if (y <= 0.f) y = 0.f;
+            int yl = (int)y, yh;
+            if (yl >= H - 1) { yh = yl = H - 1; y = (float)yl; } else yh = yl + 1;
+            const float ly = y - (float)yl, hy = 1.f - ly;
+            yl = __builtin_amdgcn_readfirstlane(yl);
+            yh = __builtin_amdgcn_readfirstlane(yh);
+            if (yl != R0 && yl != R1) load_row(yl);
+            if (yh != R0 && yh != R1) load_row(yh);
+            if (yl != R0 && yl != R1) load_row(yl);            // (cannot happen for yh in {yl, yl + 1}; keeps the cache logic closed)
+            const float wl = hy * inv, wh = ly * inv;
+            if (yl == R0) {
+#pragma unroll
+                for (int pw = 0; pw < 7; ++pw) acc[pw] = fma4(wl, T0[pw], acc[pw]);
+            } else {
+#pragma unroll
+                for (int pw = 0; pw < 7; ++pw) acc[pw] = fma4(wl, T1[pw], acc[pw]);
+            }
+            if (yh == R0) {
+#pragma unroll
+                for (int pw = 0; pw < 7; ++pw) acc[pw] = fma4(wh, T0[pw], acc[pw]);
+            } else {
+#pragma unroll
+                for (int pw = 0; pw < 7; ++pw) acc[pw] = fma4(wh, T1[pw], acc[pw]);
+            }
+        }
+#pragma unroll
+        for (int pw = 0; pw < 7; ++pw) *reinterpret_cast<float4*>(o + (ph * 7 + pw) * C) = acc[pw];
+    }
+}
+
 // scalar statement of the same kernel (one thread per channel), kept as the readable reference of the arithmetic
 __global__ __launch_bounds__(256) void roi_align_kernel_scalar(FpnLevels L, int C, const float* __restrict__ rois,
                                                                const int32_t* __restrict__ n_rois, int max_rois,
@@ -525,13 +678,17 @@ int det_enqueue_gather(hipStream_t s, const float* boxes, const float* scores, i
 }
 
 int det_enqueue_roi_align(hipStream_t s, const DetFpnArgs& a, const float* rois, const int32_t* n_rois, int max_rois,
-                          float* out, int n_frames) {
+                          float* out, int n_frames, int separable) {
     PP_REQUIRE(a.c == 256, "roi_align: C=%d (kernel launches one thread per channel, C must be 256)", a.c);
     FpnLevels L;
     for (int l = 0; l < 4; ++l) {
         L.feat[l] = a.feat[l]; L.h[l] = a.h[l]; L.w[l] = a.w[l]; L.stride[l] = a.stride[l];
     }
-    hipLaunchKernelGGL(roi_align_kernel, dim3(max_rois, n_frames), dim3(a.c), 0, s, L, a.c, rois, n_rois, max_rois, out);
+    static const int sep_env = getenv("POSEPIPE_ROI_SEPARABLE") ? atoi(getenv("POSEPIPE_ROI_SEPARABLE")) : -1;   // A/B knob
+    if (sep_env >= 0 ? sep_env != 0 : separable != 0)
+        hipLaunchKernelGGL(roi_align_sep_kernel, dim3((max_rois + 3) / 4, n_frames), dim3(256), 0, s, L, a.c, rois, n_rois, max_rois, out);
+    else
+        hipLaunchKernelGGL(roi_align_kernel, dim3(max_rois, n_frames), dim3(a.c), 0, s, L, a.c, rois, n_rois, max_rois, out);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }

@@ -275,7 +275,8 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
     fa.c = 256;
     void* roi_in_ptr;
     pp_net_buffer(d->netB, d->roi_in, &roi_in_ptr, nullptr);
-    rc = det_enqueue_roi_align(s, fa, d->rois, d->n_rois, d->max_rois, (float*)roi_in_ptr, F);
+    rc = det_enqueue_roi_align(s, fa, d->rois, d->n_rois, d->max_rois, (float*)roi_in_ptr, F,
+                               pp_net_numerics(d->netB) == PP_NET_NUMERICS_SPLIT);
     if (rc != PP_OK) return rc;
     PP_HIP_CHECK(hipEventRecord(d->ev[4], s));
     rc = pp_net_run(d->netB, F * d->max_rois, 0, -1);

@@ -85,6 +85,9 @@ struct ConvArgs {
     // conv_split.hip: the weights pre-split into bf16 planes in fragment order (pp_conv_split_weights); null: pp_launch_conv
     // builds a temporary copy when it picks the split kernel (single-op API; never under graph capture)
     const void* wsplit;
+    // 0: single-op API -- the process-wide setting (pp_conv_exact) decides; 1 / 2: an op of a net created exact / split (ABI 7: a
+    // net's numerics never change after creation; with 2 the split kernel runs exactly where the net built split weights)
+    int numerics;
 };
 // fp32 convolution on the bf16 matrix cores (three-way split, six products; conv_split.hip)
 bool pp_conv_split_eligible(const ConvArgs& a);

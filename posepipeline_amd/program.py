@@ -343,9 +343,11 @@ class ProgramBuilder:
 class Net:
     """pp_net handle: resident weights + activation arena on one Context."""
 
-    def __init__(self, ctx: L.Context, prog: Program, max_batch: int, blob_dev=None):
+    def __init__(self, ctx: L.Context, prog: Program, max_batch: int, blob_dev=None, numerics=None):
         """blob_dev: optional (device pointer, n_floats) of a weight blob that is already resident on ctx's device -- the
-        tensor an RCCL broadcast delivered; prog.blob (host) is not read then."""
+        tensor an RCCL broadcast delivered; prog.blob (host) is not read then.
+        numerics: None / "default" (the process-wide pp_conv_exact / POSEPIPE_CONV_EXACT setting at this moment), "exact"
+        (float32 MFMA kernels, the oracle's bits) or "split" (bf16 matrix cores where eligible).  Fixed for the net's life."""
         self.ctx = ctx
         self.prog = prog
         self.max_batch = int(max_batch)
@@ -357,13 +359,14 @@ class Net:
         h = C.c_void_p()
         if blob_dev is not None:
             dptr, n_floats = blob_dev
-            L.check(lib.pp_net_create_mem(ctx.handle, ops, n_ops, bufs, len(prog.bufs), C.c_void_p(int(dptr)), int(n_floats),
-                                          L.PP_MEM_DEVICE, self.max_batch, C.byref(h)), "pp_net_create_mem")
+            L.check(lib.pp_net_create_ex(ctx.handle, ops, n_ops, bufs, len(prog.bufs), C.c_void_p(int(dptr)), int(n_floats),
+                                         L.PP_MEM_DEVICE, self.max_batch, L.NUMERICS[numerics], C.byref(h)), "pp_net_create_ex")
         else:
             blob = np.ascontiguousarray(prog.blob, dtype=np.float32)
-            L.check(lib.pp_net_create(ctx.handle, ops, n_ops, bufs, len(prog.bufs), L.ptr(blob), blob.size, self.max_batch,
-                                      C.byref(h)), "pp_net_create")
+            L.check(lib.pp_net_create_ex(ctx.handle, ops, n_ops, bufs, len(prog.bufs), L.ptr(blob), blob.size, L.PP_MEM_HOST,
+                                         self.max_batch, L.NUMERICS[numerics], C.byref(h)), "pp_net_create_ex")
         self.handle = h
+        self.numerics = "split" if lib.pp_net_numerics(h) == L.PP_NET_NUMERICS_SPLIT else "exact"
 
     def close(self):
         if getattr(self, "handle", None):
@@ -415,7 +418,7 @@ class Net:
         return out
 
     def conv_kinds(self) -> np.ndarray:
-        """per op: 0 not a conv, 1 float32 MFMA kernels, 2 bf16-split kernel (under the current pp_conv_exact setting)"""
+        """per op: 0 not a conv, 1 float32 MFMA kernels, 2 bf16-split kernel (a property of the net, fixed at creation)"""
         kinds = np.zeros(len(self.prog.ops), dtype=np.int32)
         L.check(self.ctx.lib.pp_net_conv_kinds(self.handle, L.ptr(kinds)), "pp_net_conv_kinds")
         return kinds

@@ -23,22 +23,22 @@ def ctx():
 
 @pytest.fixture(autouse=True)
 def _conv_numerics(request):
-    """GPU tests run the float32-MFMA convolution kernels, which are bit-identical to oracle/conv_ref.c, so that `==` against
-    the oracle is meaningful.  The library's DEFAULT (three-way bf16 split on the bf16 matrix cores: float32-accurate but
-    not bit-identical) is what tests/test_gpu_split.py covers: it switches with pp_conv_exact(0)."""
+    """GPU tests create their nets with the float32-MFMA convolution kernels, which are bit-identical to oracle/conv_ref.c, so
+    that `==` against the oracle is meaningful.  A net keeps the numerics it was created with (ABI 7).  The library's DEFAULT
+    (three-way bf16 split on the bf16 matrix cores: float32-accurate but not bit-identical) is covered by
+    tests/test_gpu_parity_modes.py (the oracle-comparing end-to-end tests in BOTH modes, north_star tolerances) and
+    tests/test_gpu_split.py (per layer / per network against the bit-exact kernels)."""
     if request.node.get_closest_marker("gpu") is None:
         yield
         return
     from posepipeline_amd import _lib
-    lib = _lib.load_library()
     # POSEPIPE_TEST_NUMERICS=default: run the suite on the default kernels instead (the `==` assertions then fail by design; used
     # to check that nothing else -- shapes, ids, error paths, graph capture, streaming -- depends on the numerics mode)
-    exact = -1 if os.environ.get("POSEPIPE_TEST_NUMERICS") == "default" else 1
-    lib.pp_conv_exact(exact)
+    mode = "split" if os.environ.get("POSEPIPE_TEST_NUMERICS") == "default" else "exact"
     old = os.environ.get("POSEPIPE_CONV_EXACT")
-    os.environ["POSEPIPE_CONV_EXACT"] = "1" if exact == 1 else "0"     # worker processes a test starts (sharded ranks, env-knob probes)
-    yield
-    lib.pp_conv_exact(exact)
+    os.environ["POSEPIPE_CONV_EXACT"] = "1" if mode == "exact" else "0"     # worker processes a test starts (sharded ranks, env-knob probes)
+    with _lib.default_numerics(mode):
+        yield
     if old is None:
         os.environ.pop("POSEPIPE_CONV_EXACT", None)
     else:

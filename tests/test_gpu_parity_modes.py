@@ -1,0 +1,294 @@
+"""The oracle-comparing end-to-end tests in BOTH numerics modes, at the sizes the bench times.
+
+"exact": every convolution on the float32 MFMA kernels -- `==` against the oracle wherever the arithmetic is integer or a
+         k-ordered fmaf chain.
+"split": the library's default (and what bench.py times): eligible convolutions on the bf16 matrix cores through an exact
+         three-way operand split.  Here `==` becomes north_star's tolerance -- EVERY joint within 1e-3 px / 1e-3 mm, scores
+         within 1e-5, integer outputs (track ids, frame indices, which rows are zero) identical -- not a quantile.
+
+Seeded-random pose weights cannot carry a per-joint 1e-3 px claim in ANY float32 evaluation order (heat-maps are noise; a
+transposed-network control with the bit-exact kernels moves as many joints, tests/test_gpu_split.py), so the pose networks
+here use `synth.smooth_state_dict`: positive normalised kernels through every stage, i.e. smooth single-peaked heat-maps
+like a trained network's.  The detector keeps seeded-random weights: its discrete decisions are checked with the
+margin-aware oracle (oracle/detector_margins.py): certain <= device <= possible.
+Reference call sites: pose_pipeline/wrappers/mmpose.py:60-81, wrappers/mmtrack.py:37-60, wrappers/videopose3d.py:77-85.
+"""
+import numpy as np
+import pytest
+
+from oracle import decode as odec
+from oracle import detector as odet
+from oracle import detector_margins as odm
+from oracle import nets as onets
+from oracle.tracking import SortTrackerRef
+from posepipeline_amd import _lib as L
+from posepipeline_amd import ops
+from posepipeline_amd.models import faster_rcnn as fr
+from posepipeline_amd.models import hrnet, synth
+from posepipeline_amd.models import videopose3d as vp3d
+from posepipeline_amd.program import Net
+from tests.test_gpu_cascade import reference_3d
+from tests.test_gpu_detector import synth_frame
+from tests.test_gpu_pipeline import oracle_topdown
+
+pytestmark = pytest.mark.gpu
+
+TOL_PX = 1e-3          # north_star: 2D joints within 1e-3 px
+TOL_M = 1e-6           # 3D joints within 1e-3 mm; VideoPose3D's unit is the metre
+TOL_SCORE = 1e-5       # relative to the largest score of the batch
+
+
+@pytest.fixture(params=["exact", "split"])
+def numerics(request, ctx):
+    """every net the test creates gets these numerics (a net keeps what it was created with, ABI 7)"""
+    with L.default_numerics(request.param):
+        yield request.param
+
+
+def assert_scores(got, ref, numerics):
+    ref = np.asarray(ref, np.float32)
+    if numerics == "exact":
+        assert np.array_equal(got, ref)
+    else:
+        assert np.abs(got - ref).max() <= TOL_SCORE * max(float(np.abs(ref).max()), 1e-30), np.abs(got - ref).max() / np.abs(ref).max()
+
+
+# ---- (i) HRNet-W48 384x288 + flip test + DARK decode at full size, every joint ------------------------------------------------
+def test_hrnet_w48_full_size_every_joint(ctx, numerics):
+    spec = hrnet.hrnet_w48_384x288()
+    sd = synth.smooth_state_dict(hrnet.hrnet_param_shapes(spec), seed=11)
+    n = 3
+    x = synth.blob_crops(np.random.default_rng(5), n, spec.in_h, spec.in_w)
+    net = Net(ctx, hrnet.build_hrnet_program(spec, sd), max_batch=2 * n)
+    assert net.numerics == numerics and (numerics == "split") == bool((net.conv_kinds() == 2).any())
+    # (cx, cy, sx, sy) of 1080p persons (mmpose `_box2cs`: scale = box / 200 * 1.25)
+    cs = np.array([[960.0, 540.0, 1.9, 2.5333333], [300.5, 700.25, 1.2, 1.6], [1700.0, 400.0, 2.4, 3.2]], np.float32)
+    # oracle: network on the crops and on their mirror images, flip merge, DARK decode
+    xin = np.ascontiguousarray(np.transpose(np.concatenate([x, x[:, :, ::-1]])[..., :3], (0, 3, 1, 2)))
+    ref_hm = onets.HRNetRef(sd, 48).forward(xin)
+    ref_kp, _ = odec.decode_topdown(ref_hm[:n], ref_hm[n:], hrnet.COCO_FLIP_PAIRS, cs[:, :2], cs[:, 2:], post_process="unbiased", kernel=17)
+    # well-conditioned by construction: positive single-peaked maps
+    assert ref_hm.min() > 0 and np.isfinite(ref_hm).all()
+    # device: the fused stage (mirror, backbone x 2, flip merge + decode), then the raw heat-maps
+    td = ops.TopDown(net, 17, flip_perm=hrnet.flip_perm(17), post="unbiased", blur_kernel=17)
+    kp = td.run_precropped(x, cs)
+    hm = net.read("output", 2 * n).reshape(2 * n, 17, 96, 72)
+    if numerics == "exact":
+        assert np.array_equal(hm, ref_hm)
+    else:
+        assert not np.array_equal(hm, ref_hm), "the split kernels did not run"
+        assert np.abs(hm - ref_hm).max() <= 2e-5 * np.abs(ref_hm).max()
+    d = np.abs(kp[:, :, :2] - ref_kp[:, :, :2]).max(axis=2)
+    print(f"[{numerics}] W48 384x288: {d.size} joints, max deviation {d.max():.2e} px, heat-maps {np.abs(hm - ref_hm).max() / np.abs(ref_hm).max():.2e} of range")
+    assert d.max() <= TOL_PX, d
+    assert_scores(kp[:, :, 2], ref_kp[:, :, 2], numerics)
+
+
+# ---- (ii) the cascade at configs[2] / [3] sizes ---------------------------------------------------------------------------
+def _blob_person(rng, h, w):
+    """a dark rectangle with one bright Gaussian blob per colour plane (what the smoothing pose network peaks on)"""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    tex = np.full((h, w, 3), 30.0, np.float32)
+    cy, cx = rng.uniform(0.35 * h, 0.65 * h), rng.uniform(0.35 * w, 0.65 * w)
+    for c in range(3):
+        sg = rng.uniform(0.05, 0.09) * h
+        oy, ox = rng.uniform(-0.03, 0.03, 2) * h
+        tex[:, :, c] += rng.uniform(150, 215) * np.exp(-((yy - cy - oy) ** 2 + (xx - cx - ox) ** 2) / (2 * sg * sg))
+    return np.clip(tex + rng.uniform(0, 3, tex.shape), 0, 255).astype(np.uint8)
+
+
+def _lift_sd():
+    return synth.synth_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3)
+
+
+def _check_tracks(outs, tracks, frames, n, h, w, pose_sd, width, image_size, lift_sd, numerics, sample):
+    """every followed id against the reference's table chain: PersonBbox.make(keep_tracks=[id]) decides the boxes / zero rows,
+    the oracle chain gives the 2D joints of the sampled frames, process_videopose3d's whole-clip windows the 3D joints"""
+    from posepipeline_amd.cascade import collect
+    from posepipeline_amd.tracking import person_bbox
+    ids = sorted({r[0] for fr_ in tracks for r in fr_})
+    k2, k3 = collect(outs, "keypoints"), collect(outs, "keypoints_3d")
+    assert sorted(k2) == sorted(k3) == ids
+    dicts = [[{"track_id": r[0], "tlhw": np.array([r[1], r[2], r[3] - r[1], r[4] - r[2]], np.float64)} for r in fr_] for fr_ in tracks]
+    worst2 = worst3 = 0.0
+    for tid in ids:
+        bbox, present = person_bbox(dicts, [tid])
+        f2, a2 = k2[tid]
+        filled = np.flatnonzero(present)
+        assert f2 == filled[0] and f2 + len(a2) > filled[-1]
+        for t in range(f2, f2 + len(a2)):                                   # zero rows exactly where the reference has none
+            assert a2[t - f2].any() == bool(present[t]), (tid, t)
+        for t in sample:
+            if t >= n or not present[t]:
+                continue
+            ref = oracle_topdown(pose_sd, width, frames[t:t + 1], bbox[t:t + 1], image_size, "unbiased", 17)[0]
+            worst2 = max(worst2, float(np.abs(a2[t - f2][:, :2] - ref[:, :2]).max()))
+            assert np.abs(a2[t - f2][:, :2] - ref[:, :2]).max() <= TOL_PX, (tid, t, np.abs(a2[t - f2][:, :2] - ref[:, :2]).max())
+            assert_scores(a2[t - f2][:, 2], ref[:, 2], numerics)
+        f3, a3 = k3[tid]
+        ref3 = reference_3d(a2, f2, n, w, h, lift_sd)                        # the lifting oracle on the device's own 2D track
+        assert f3 == f2
+        if numerics == "exact":
+            assert np.array_equal(a3, ref3[f3:f3 + len(a3)]), tid
+        else:
+            worst3 = max(worst3, float(np.abs(a3 - ref3[f3:f3 + len(a3)]).max()))
+            assert np.abs(a3 - ref3[f3:f3 + len(a3)]).max() <= TOL_M, (tid, np.abs(a3 - ref3[f3:f3 + len(a3)]).max())
+    print(f"[{numerics}] {len(ids)} ids: 2D max {worst2:.2e} px, 3D max {worst3:.2e} m")
+    return ids, k2
+
+
+def test_cascade_1080p_four_persons_both_modes(ctx, numerics):
+    """BASELINE.json configs[2]: multi-person 1080p through detector -> SORT -> HRNet-W48 384x288 -> VideoPose3D, 4 persons with
+    crossing trajectories and one missed detection at a chunk boundary (back-fill into the previous chunk)"""
+    from posepipeline_amd.cascade import Cascade
+    from posepipeline_amd.video import ArrayVideo
+    rng = np.random.default_rng(21)
+    h, w, n, chunk = 1080, 1920, 16, 8
+    bg = rng.integers(20, 60, (h // 40, w // 40, 3)).astype(np.uint8)
+    bg = np.repeat(np.repeat(bg, 40, axis=0), 40, axis=1)
+    people = [dict(x=200.0, y=150.0, w=170, h=520, vx=38.0), dict(x=900.0, y=260.0, w=150, h=470, vx=-36.0),
+              dict(x=1400.0, y=90.0, w=190, h=580, vx=6.0), dict(x=100.0, y=500.0, w=120, h=330, vx=12.0)]
+    for q in people:
+        q["tex"] = _blob_person(rng, q["h"], q["w"])
+    frames = np.empty((n, h, w, 3), np.uint8)
+    gt = []
+    for t in range(n):
+        f = bg.copy()
+        rows = []
+        for i, q in enumerate(people):
+            x0, y0 = int(q["x"] + q["vx"] * t), int(q["y"])
+            f[y0:y0 + q["h"], x0:x0 + q["w"]] = q["tex"]
+            if not (i == 2 and t == 8):                                     # person 2 is missed in frame 8 (first of chunk 2)
+                rows.append([x0 + 0.25 * i, y0 + 0.5, x0 + q["w"] - 0.25, y0 + q["h"], 0.6 + 0.08 * i])
+        frames[t] = f
+        gt.append(np.array(rows, np.float32))
+    spec = hrnet.hrnet_w48_384x288()
+    det_sd = synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2)
+    pose_sd = synth.smooth_state_dict(hrnet.hrnet_param_shapes(spec), seed=11)
+    lift_sd = _lift_sd()
+    cas = Cascade(ctx, det_sd, pose_sd, lift_sd, h, w, chunk=chunk, max_persons=4, pose_spec=spec)
+    assert cas.pose_net.numerics == numerics and cas.detector.net_a.numerics == numerics and cas.lift_net.numerics == numerics
+    outs = list(cas.run_video(ArrayVideo(frames), replay_fn=lambda first, m: gt[first:first + m]))
+    assert [o["first_frame"] for o in outs] == [0, 8, 16]
+    tracks = [fr_ for o in outs for fr_ in o["tracks"]]
+    ref_trk = SortTrackerRef()
+    for t in range(n):                                                      # ids: bit-exact in either mode
+        rows = ref_trk.step(gt[t])
+        assert [r[0] for r in tracks[t]] == [int(x[0]) for x in rows]
+        assert np.array_equal(np.array([r[1:] for r in tracks[t]], np.float32), rows[:, 1:])
+    ids, k2 = _check_tracks(outs, tracks, frames, n, h, w, pose_sd, 48, (288, 384), lift_sd, numerics, sample=(0, 7, 8, 9, 15))
+    assert len(ids) == 5                                                    # the missed person comes back under a new id
+    old = tracks[0][2][0]
+    new = [r[0] for r in tracks[9] if r[0] not in {q[0] for q in tracks[0]}][0]
+    assert k2[new][0] == 7 and k2[old][1][8].any() and k2[old][1][9].any() and not k2[old][1][10:].any()
+
+
+def test_cascade_long_clip_both_modes(ctx, numerics):
+    """configs[3]'s temporal part: 330 frames in 6 chunks -- the 3D joints EVERY step emits are the whole-clip lifting of the 2D
+    track (window [t-121, t+121]), frame t leaves the cascade with the chunk that brings frame t+121"""
+    from posepipeline_amd.cascade import Cascade, collect
+    rng = np.random.default_rng(8)
+    h, w, n, chunk = 135, 240, 330, 64
+    bg = np.repeat(np.repeat(rng.integers(20, 60, (h // 15, w // 15, 3)).astype(np.uint8), 15, axis=0), 15, axis=1)
+    tex = _blob_person(rng, 100, 70)
+    frames = np.empty((n, h, w, 3), np.uint8)
+    for t in range(n):
+        frames[t] = bg
+        x0 = 20 + int(0.4 * t)
+        frames[t, 20:120, x0:x0 + 70] = np.clip(tex.astype(np.int32) + (t % 7), 0, 255).astype(np.uint8)
+    pose_spec = hrnet.HRNetSpec(32, 17, 128, 96)
+    det_sd = synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2)
+    pose_sd = synth.smooth_state_dict(hrnet.hrnet_param_shapes(pose_spec), seed=12)
+    lift_sd = _lift_sd()
+    cas = Cascade(ctx, det_sd, pose_sd, lift_sd, h, w, chunk=chunk, max_persons=1, pose_spec=pose_spec)
+    gt = [np.array([[20 + 0.4 * t, 20, 90 + 0.4 * t, 120, 0.9]], np.float32) for t in range(n)]
+    outs = [cas.step(frames[i:i + chunk], replay=gt[i:i + chunk]) for i in range(0, n, chunk)] + [cas.flush()]
+    tracks = [fr_ for o in outs for fr_ in o["tracks"]]
+    ids, k2 = _check_tracks(outs, tracks, frames, n, h, w, pose_sd, 32, (96, 128), lift_sd, numerics, sample=(0, 63, 64, 200, n - 1))
+    assert len(ids) == 1
+    tid = ids[0]
+    f2, a2 = k2[tid]
+    assert f2 == 0 and a2.shape == (n, 17, 3)
+    ref3 = reference_3d(a2, 0, n, w, h, lift_sd)
+    emitted = []
+    for o in outs:
+        if tid not in o["keypoints_3d"]:
+            emitted.append(0)
+            continue
+        fr3 = o["keypoints_3d_frames"][tid]
+        emitted.append(len(fr3))
+        if numerics == "exact":
+            assert np.array_equal(o["keypoints_3d"][tid], ref3[fr3])
+        else:
+            assert np.abs(o["keypoints_3d"][tid] - ref3[fr3]).max() <= TOL_M
+    assert emitted == [0, 7, 64, 64, 64, 10, 121]                          # identical emission schedule in either mode
+
+
+# ---- (iii) detector: margin-aware set equality, ids on detector-produced boxes ----------------------------------------------
+def _det_sd():
+    sd = synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2)
+    for k, g in (("detector.rpn_head.rpn_cls.weight", 0.5), ("detector.rpn_head.rpn_reg.weight", 0.1),
+                 ("detector.roi_head.bbox_head.fc_reg.weight", 0.2)):
+        sd[k] = (sd[k] * g).astype(np.float32)
+    return sd
+
+
+BOX_TOL = {"exact": 0.0, "split": 1e-2}     # px in the SOURCE frame; seeded-random regression weights move 300-px boxes by O(1) deltas through
+                                            # exp(): float32 rounding noise of fc6's 12544-term sums shows at the 1e-3 px level (measured, printed)
+
+
+@pytest.mark.parametrize("size", [(135, 240), (1080, 1920)])
+def test_detector_margin_aware_set_equality(ctx, numerics, size):
+    """Every detection the oracle is CERTAIN of (all its top-k / NMS / threshold / level decisions have >= 1e-4 margin) must come
+    out of the device, and every device detection must be one the oracle holds POSSIBLE -- boxes within BOX_TOL, scores
+    within 1e-4.  In exact mode the sets are the oracle's own, bit for bit (also asserted)."""
+    h, w = size
+    sd = _det_sd()
+    rng = np.random.default_rng(3 if h == 1080 else 2)
+    frames = np.stack([synth_frame(rng, h, w) for _ in range(1 if h == 1080 else 2)])
+    det = fr.Detector(ctx, sd, h, w, max_frames=len(frames))
+    assert det.net_a.numerics == numerics and det.net_b.numerics == numerics
+    dets = det.run(frames)
+    model = odet.FasterRCNNRef(sd)
+    for f in range(len(frames)):
+        certain, possible = odm.detect3(model, frames[f][:, :, ::-1])
+        assert len(certain) > 0 and len(certain) <= len(possible)
+        missing, unexplained, worst = odm.check_between(dets[f], certain, possible, BOX_TOL[numerics])
+        print(f"[{numerics}] {h}x{w} frame {f}: device {len(dets[f])}, certain {len(certain)}, possible {len(possible)}, "
+              f"max box deviation of certain detections {worst:.2e} px")
+        assert not missing, (len(missing), missing[:3])
+        assert not unexplained, (len(unexplained), unexplained[:3])
+        if numerics == "exact":
+            assert np.array_equal(dets[f], odet.detect(model, frames[f][:, :, ::-1]))
+
+
+def test_track_ids_on_detector_boxes(ctx, numerics):
+    """north_star: integer track ids bit-exact -- on boxes the DETECTOR produced (no replay): a 4-frame clip through the device
+    detector and the product tracker against the oracle detector and the oracle tracker.  The tracker only sees detections
+    with score > 0.5; the clip is one where those are certain (asserted), so ids must be identical in either mode."""
+    from posepipeline_amd.tracking import Tracker
+    h, w, n = 135, 240, 4
+    sd = _det_sd()
+    sd["detector.roi_head.bbox_head.fc_cls.bias"] = (sd["detector.roi_head.bbox_head.fc_cls.bias"] + np.array([-4.6, 0.0], np.float32)).astype(np.float32)
+    rng = np.random.default_rng(17)
+    base = synth_frame(rng, h, w)
+    frames = np.stack([np.roll(base, 3 * t, axis=1) for t in range(n)])
+    det = fr.Detector(ctx, sd, h, w, max_frames=n)
+    dets = det.run(frames)
+    model = odet.FasterRCNNRef(sd)
+    trk, ref_trk = Tracker(mode=1, match_iou_thr=0.5, obj_score_thr=0.5), SortTrackerRef()
+    total = 0
+    for f in range(n):
+        ref = odet.detect(model, frames[f][:, :, ::-1])
+        rows = ref_trk.step(ref)
+        g = np.asarray(dets[f], np.float32).reshape(-1, 5)
+        ids, _, info = trk.step(g[:, :4].astype(np.float64), g[:, 4].astype(np.float64))
+        got = [(int(i), g[j]) for i, j in zip(ids, info[:, 1])]
+        assert len(rows) > 0, "the clip must give the tracker something to do"
+        # no score sits within 1e-4 of the tracker's threshold (otherwise the comparison would be ill-posed)
+        assert (np.abs(ref[:, 4] - 0.5) > 1e-4).all()
+        assert [i for i, _ in got] == [int(r[0]) for r in rows], (f, [i for i, _ in got], rows[:, 0])
+        for (_, box), r in zip(got, rows):
+            assert np.abs(box[:4] - r[1:5]).max() <= BOX_TOL[numerics] and abs(box[4] - r[5]) <= 1e-4
+        total += len(rows)
+    print(f"[{numerics}] {total} tracked detector boxes over {n} frames, ids identical")

@@ -29,6 +29,8 @@ TOL_MM = 1e-3        # 3D joints within 1e-3 mm (VideoPose3D works in metres: 1e
 
 @pytest.fixture
 def lib(ctx):
+    """the tests below switch the process-wide DEFAULT numerics (pp_conv_exact) around the creation of their nets / their
+    single-op calls; a net keeps what it was created with"""
     yield ctx.lib
     L.check(ctx.lib.pp_conv_exact(1), "pp_conv_exact")
 
@@ -405,3 +407,43 @@ def test_split_cascade_same_tracks_close_joints(ctx, lib):
     assert np.median(d2) <= 1e-4 and (d2 <= TOL_PX).mean() >= 0.9 and d2.max() <= 0.05, (np.median(d2), d2.max())
     # the lifting network only sees the 2D differences above
     assert d3.max() <= 2e-5, (d3.max(), d2.max())           # measured 6e-6 m for 1.6e-3 px of 2D difference (random lifting weights)
+
+
+def test_split_roi_align_separable_form(ctx, lib):
+    """Default numerics: RoIAlign is evaluated separably (row sums shared by the samples that touch a row, roi_align_sep_kernel) --
+    the same samples, validity rule and clamping as the sample loop of mmcv / oracle.detector.roi_align, another float32
+    summation order.  On the device's OWN FPN features and proposals: every output within 1e-5 of the feature range of the
+    oracle's loop, for RoIs of every FPN level, RoIs that leave the image on every side, tiny and very wide ones."""
+    from oracle import detector as odet
+    sd = synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2)
+    for k, g in (("detector.rpn_head.rpn_cls.weight", 0.5), ("detector.rpn_head.rpn_reg.weight", 0.1)):
+        sd[k] = (sd[k] * g).astype(np.float32)
+    rng = np.random.default_rng(2)
+    frame = synth_frame(rng, 135, 240)
+    L.check(lib.pp_conv_exact(0), "pp_conv_exact")
+    det = fr.Detector(ctx, sd, 135, 240, max_frames=1)
+    L.check(lib.pp_conv_exact(1), "pp_conv_exact")
+    assert det.net_b.numerics == "split"
+    _, props = det.run(frame[None], want_proposals=True)
+    props = props[0]
+    feats = [det.net_a.read(f"p{i}", 1) for i in range(2, 6)]
+    got = det.net_b.read("roi_in", len(props))
+    lv = odet.map_roi_levels(props)
+    w, h = props[:, 2] - props[:, 0], props[:, 3] - props[:, 1]
+    pick = set(range(12))
+    for level in range(4):
+        pick |= set(np.flatnonzero(lv == level)[:12].tolist())
+    pick |= set(np.argsort(w)[:6].tolist()) | set(np.argsort(-w)[:6].tolist()) | set(np.argsort(-w / np.maximum(h, 1e-3))[:6].tolist())
+    pick |= set(np.argsort(props[:, 0])[:4].tolist()) | set(np.argsort(props[:, 1])[:4].tolist())
+    pick |= set(np.argsort(-props[:, 2])[:4].tolist()) | set(np.argsort(-props[:, 3])[:4].tolist())
+    pick = sorted(pick)
+    assert len({int(l) for l in lv[pick]}) >= 3
+    scale = max(float(np.abs(f_).max()) for f_ in feats)
+    worst = 0.0
+    for i in pick:
+        ref = odet.roi_align(feats[lv[i]][0], props[i], 1.0 / odet.STRIDES[lv[i]])
+        worst = max(worst, float(np.abs(got[i] - ref).max()))
+        assert np.abs(got[i] - ref).max() <= 1e-5 * scale, (i, props[i], lv[i], np.abs(got[i] - ref).max() / scale)
+    print(f"separable RoIAlign: {len(pick)} RoIs, max deviation {worst / scale:.2e} of the feature range")
+    # RoIs past n_rois are zero rows
+    assert not det.net_b.read("roi_in", det.MAX_ROIS)[len(props):].any() or len(props) == det.MAX_ROIS

@@ -118,3 +118,52 @@ def test_roi_align_vs_naive_loop():
                                 ly * lx * feat[ya, xa])
                 ref[py, px] = acc / max(gh * gw, 1)
         np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5)
+
+
+# ---- margin-aware (three-valued) restatement of the discrete decisions: oracle/detector_margins.py -------------------------
+def test_three_valued_nms_brackets_every_nearby_evaluation():
+    """nms3 / _topk3: with eps = 0 they reproduce mmcv's greedy NMS; with eps > 0, every evaluation whose scores and boxes are
+    within a tenth of eps of this one keeps all certain boxes and nothing outside the possible ones"""
+    from oracle import boxes as obox
+    from oracle import detector_margins as odm
+    rng = np.random.default_rng(31)
+    n_uncertain = 0
+    for trial in range(6):
+        n = 300
+        c = rng.uniform(0, 400, (12, 2))
+        ctr = c[rng.integers(0, 12, n)] + rng.normal(0, 10, (n, 2))
+        wh = rng.uniform(30, 120, (n, 2))
+        boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+        scores = np.round(rng.uniform(0, 1, n), 3).astype(np.float32)          # many near-ties at the 1e-3 level
+        plain = set(obox.nms_mmcv(boxes, scores, 0.5))
+        st0 = odm.nms3(boxes, scores, np.full(n, odm.K), 0.5, 0.0, 0.0)
+        assert {i for i in np.flatnonzero(st0 == odm.K)} <= plain and plain <= {i for i in np.flatnonzero(st0 != odm.S)}
+        eps = 2e-3
+        st = odm.nms3(boxes, scores, np.full(n, odm.K), 0.5, eps, eps)
+        certain, possible = set(np.flatnonzero(st == odm.K)), set(np.flatnonzero(st != odm.S))
+        assert certain <= plain <= possible
+        n_uncertain += len(possible) - len(certain)
+        for k in range(5):
+            s2 = (scores + rng.uniform(-eps / 10, eps / 10, n)).astype(np.float32)
+            b2 = (boxes + rng.uniform(-1e-3, 1e-3, boxes.shape)).astype(np.float32)
+            near = set(obox.nms_mmcv(b2, s2, 0.5))
+            assert certain <= near <= possible, (trial, k, certain - near, near - possible)
+        # top-k in three-valued logic
+        kept = np.where(st != odm.S)[0]
+        tk = odm._topk3(scores, st, 20, eps)
+        order = [i for i in np.argsort(-scores, kind="stable") if i in plain][:20]
+        assert set(np.flatnonzero(tk == odm.K)) <= set(order) <= set(np.flatnonzero(tk != odm.S))
+    assert n_uncertain > 0            # the near-ties of these cases do make some decisions uncertain
+
+
+def test_check_between_matches_rows():
+    from oracle import detector_margins as odm
+    certain = np.array([[0, 0, 10, 10, 0.9], [20, 20, 40, 50, 0.6]], np.float32)
+    possible = np.concatenate([certain, np.array([[5, 5, 9, 9, 0.3]], np.float32)])
+    dev = certain + np.array([1e-3, -1e-3, 0, 1e-3, 5e-5], np.float32)
+    assert odm.check_between(dev, certain, possible, 1e-2)[:2] == ([], [])
+    miss, unex, _ = odm.check_between(dev[:1], certain, possible, 1e-2)
+    assert len(miss) == 1 and not unex
+    miss, unex, _ = odm.check_between(np.concatenate([dev, [[100, 100, 120, 120, 0.2]]]).astype(np.float32), certain, possible, 1e-2)
+    assert not miss and len(unex) == 1
+    assert odm.check_between(dev, certain, possible, 1e-4)[0]                      # tolerance is enforced

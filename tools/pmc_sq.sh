@@ -6,9 +6,9 @@ O=$R/gpurun_out/pmc_sq
 rm -rf $O; mkdir -p $O
 cd $R
 export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --output-format csv -d $O/p1 -- python bench.py --steps 2 --warmup 1 --cpu-frames 0 > $O/p1.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/p2 -- python bench.py --steps 2 --warmup 1 --cpu-frames 0 > $O/p2.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/p3 -- python bench.py --steps 2 --warmup 1 --cpu-frames 0 > $O/p3.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --output-format csv -d $O/p1 -- python bench.py --profile-serial --steps 2 --warmup 1 > $O/p1.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $O/p2 -- python bench.py --profile-serial --steps 2 --warmup 1 > $O/p2.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/p3 -- python bench.py --profile-serial --steps 2 --warmup 1 > $O/p3.log 2>&1
 python - <<'PY' > $O/summary.txt 2>&1
 import csv, glob, os
 O = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out/pmc_sq")
@@ -23,7 +23,7 @@ for p in ("p1", "p2", "p3"):
             k = row["Counter_Name"]
             tot[k] = tot.get(k, 0.0) + float(row["Counter_Value"])
             n[k] = n.get(k, 0) + 1
-print(f"# SQ counters summed over all {KERNEL} launches of: python bench.py --steps 2 --warmup 1 --cpu-frames 0 (cascade, 32 frames/step)")
+print(f"# SQ counters summed over all {KERNEL} launches of: python bench.py --profile-serial --steps 2 --warmup 1 (cascade, 64 frames/step, every launch on one stream)")
 for k in sorted(tot):
     print(f"{k:32s} {tot[k]:.4e}  over {n[k]} launches")
 g = tot.get

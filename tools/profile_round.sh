@@ -10,15 +10,20 @@ python $R/bench.py --workload c2 > $O/bench_c2.json 2> $O/bench_c2.err
 python $R/bench.py --mode shard --steps 6 --warmup 2 > $O/bench_shard.json 2> $O/bench_shard.err
 python $R/bench.py --persons 4 --steps 6 --warmup 2 --cpu-frames 0 > $O/bench_cascade_p4.json 2> $O/bench_cascade_p4.err
 cd $R
-POSEPIPE_NET_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -- python bench.py --steps 5 --warmup 1 --cpu-frames 0 > $O/serial.log 2>&1
+# the roofline evidence: ONE run under rocprofv3 with every launch on one stream and no detector look-ahead (--profile-serial), so that
+# AverageNs of conv_split_* x launches_per_step reproduces the line's ms_per_step_serial (tools/roofline_check.py prints both)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -- python bench.py --profile-serial --steps 5 --warmup 1 > $O/serial.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes4 -- python bench.py --steps 5 --warmup 1 --cpu-frames 0 > $O/lanes4.log 2>&1
 cp $(ls -t $(find $O/serial -name "*kernel_stats.csv") | head -1) $O/cascade_serial_kernel_stats.csv
 cp $(ls -t $(find $O/lanes4 -name "*kernel_stats.csv") | head -1) $O/cascade_lanes4_kernel_stats.csv
-timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --steps 2 --warmup 1 --cpu-frames 0 > $O/pmc_fetch.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --steps 2 --warmup 1 --cpu-frames 0 > $O/pmc_write.log 2>&1
-python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 264 "cascade chunk 64, 1 person" conv_split > $O/pmc_summary.txt 2>&1
-python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write 109 "cascade chunk 64, 1 person" conv_p3_kernel > $O/pmc_summary_fp32.txt 2>&1
-python tools/pmc_traffic_update.py cascade_chunk64_persons1 $O/pmc_summary.txt "tools/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over python bench.py --steps 2 --warmup 1 (FETCH_SIZE x2, gfx950); all conv_split_* launches" $O/pmc_traffic.json
+grep '^{' $O/serial.log | tail -1 > $O/bench_cascade_profile_serial.json
+python tools/roofline_check.py $O/cascade_serial_kernel_stats.csv $O/bench_cascade_profile_serial.json > $O/roofline_check.txt 2>&1; cat $O/roofline_check.txt
+timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --profile-serial --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --profile-serial --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
+NS=$(python -c "import json;r=json.load(open('$O/bench_cascade_profile_serial.json'))['roofline'];print(r['launches_per_step'], r['fp32_mfma_kernels']['launches_per_step'])")
+python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write ${NS% *} "cascade chunk 64, 1 person (--profile-serial)" conv_split > $O/pmc_summary.txt 2>&1
+python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write ${NS#* } "cascade chunk 64, 1 person (--profile-serial)" conv_p3_kernel > $O/pmc_summary_fp32.txt 2>&1
+python tools/pmc_traffic_update.py cascade_chunk64_persons1 $O/pmc_summary.txt "tools/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over python bench.py --profile-serial --steps 2 --warmup 1 (FETCH_SIZE x2, gfx950); all conv_split_* launches" $O/pmc_traffic.json
 bash tools/pmc_sq.sh > $O/pmc_sq.log 2>&1; cp gpurun_out/pmc_sq/summary.txt $O/cascade_pmc_sq.txt
 bash tools/pmc_kernel.sh roi_align_kernel roi python bench.py --steps 1 --warmup 1 --cpu-frames 0 > $O/roi_pmc.log 2>&1; cp gpurun_out/pmc_roi/summary.txt $O/roi_pmc.txt
 for w in "w48 64" "det 32" "w32 128"; do set -- $w; python tools/profile_net.py $1 $2 > $O/per_op_$1_b$2.txt 2>&1; POSEPIPE_CONV_EXACT=1 python tools/profile_net.py $1 $2 > $O/per_op_$1_b$2_exact.txt 2>&1; done
