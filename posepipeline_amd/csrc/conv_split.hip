@@ -3,10 +3,10 @@
 // Why: v_mfma_f32_16x16x4_f32 peaks at 256 FLOP/clk/CU (157 TFLOP/s at 2.4 GHz); conv_igemm(_p3).hip sustain 0.76-0.85 of it and
 // the detector / HRNet chunks are bound by exactly that (profiles/r02_conv_ablation.txt).  v_mfma_f32_32x32x16_bf16 runs 16x
 // that rate.  A float32 value is the EXACT sum of three bfloat16 values (24 significand bits = 8 + 8 + 8, same exponent range):
-//     a = a0 + a1 + a2,   a0 = top 8 bits of a,  a1 = top 8 bits of a - a0,  a2 = a - a0 - a1   (truncation, no rounding)
+//     a = a0 + a1 + a2,   a0 = bf16(a),  a1 = bf16(a - a0),  a2 = a - a0 - a1   (round to nearest even; every residual is exact)
 // so a*b = sum_{i,j} ai*bj, every ai*bj exact in the MFMA's fp32 product.  Keeping the six terms with i + j <= 2 drops
-// a1*b2 + a2*b1 + a2*b2 <= 2^-23 |a*b| -- the size of ONE float32 rounding of the product, which a float32 FMA chain commits
-// at every step anyway.  The sums are accumulated in the MFMA's float32 accumulators.  Cost: 6 bf16 MFMAs of 16 k for what
+// a1*b2 + a2*b1 + a2*b2 ~ 2^-26 |a*b| with random signs (|a1| <= 2^-9 |a|, |a2| <= 2^-17 |a|) -- a sixth of ONE float32
+// rounding of the product, which a float32 FMA chain commits at every step anyway.  The sums are accumulated in the MFMA's float32 accumulators.  Cost: 6 bf16 MFMAs of 16 k for what
 // takes 4 fp32 MFMAs of 4 k = 2.67x the arithmetic peak (419 TFLOP/s fp32-equivalent).
 // Results are NOT bit-identical to oracle/conv_ref.c (different summation order and the dropped 2^-23 terms): the measured
 // deviation is that of a reordered float32 sum (tests/test_gpu_split.py: same error against a float64 convolution as the
@@ -69,22 +69,28 @@ struct SplitArgs {
     int xcd_remap;
 };
 
-// truncation split of four floats into the three bf16 planes (4 x 16 bit each)
+// Round-to-nearest-even split of four floats into the three bf16 planes (4 x 16 bit each): p0 = bf16(a), p1 = bf16(a - p0),
+// p2 = a - p0 - p1.  The residuals are exact float32 values (a - p0 has at most 16 significant bits, a - p0 - p1 at most 8), so
+// a = p0 + p1 + p2 EXACTLY, as with a truncating split -- but the planes below the first are SIGNED with half the magnitude
+// (|p1| <= 2^-9 |a|, |p2| <= 2^-17 |a|): the three dropped products p1*q2 + p2*q1 + p2*q2 are ~2^-26 |a q| with random signs.
+// Round 2's truncating split kept every plane the sign of a, so on same-sign data (ReLU activations x positive kernels) the
+// dropped terms, 2^-22 |a q| on average, all pushed the same way: -2e-7 per layer, -1.3e-5 over HRNet-W48's ~70 layers
+// (tests/test_gpu_parity_modes.py found it as a uniform score deficit).  v_cvt_pk_bf16_f32 converts and packs two values per
+// instruction: 4.5 vector instructions per element (5.5 with masks and v_perm).  Values within 2^-8 of FLT_MAX would round to
+// infinity; activations and weights are nowhere near.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ void split4(const float4 v, uint2& p0, uint2& p1, uint2& p2) {
-    const unsigned a[4] = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    unsigned h0[4], h1[4], h2[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        h0[i] = a[i] & 0xffff0000u;
-        const float r1 = __uint_as_float(a[i]) - __uint_as_float(h0[i]);     // exact
-        h1[i] = __float_as_uint(r1) & 0xffff0000u;
-        const float r2 = r1 - __uint_as_float(h1[i]);                        // exact, <= 8 significant bits
-        h2[i] = __float_as_uint(r2);
-    }
-    // (hi16 of element 2i+1) << 16 | hi16 of element 2i
-    p0 = make_uint2(__builtin_amdgcn_perm(h0[1], h0[0], 0x07060302u), __builtin_amdgcn_perm(h0[3], h0[2], 0x07060302u));
-    p1 = make_uint2(__builtin_amdgcn_perm(h1[1], h1[0], 0x07060302u), __builtin_amdgcn_perm(h1[3], h1[2], 0x07060302u));
-    p2 = make_uint2(__builtin_amdgcn_perm(h2[1], h2[0], 0x07060302u), __builtin_amdgcn_perm(h2[3], h2[2], 0x07060302u));
+    const f32x2_t a = {v.x, v.y}, b = {v.z, v.w};
+    const bf16x2_t a0 = __builtin_convertvector(a, bf16x2_t), b0 = __builtin_convertvector(b, bf16x2_t);
+    const f32x2_t ra = a - __builtin_convertvector(a0, f32x2_t), rb = b - __builtin_convertvector(b0, f32x2_t);          // exact
+    const bf16x2_t a1 = __builtin_convertvector(ra, bf16x2_t), b1 = __builtin_convertvector(rb, bf16x2_t);
+    const f32x2_t sa = ra - __builtin_convertvector(a1, f32x2_t), sb = rb - __builtin_convertvector(b1, f32x2_t);        // exact, <= 8 bits
+    const bf16x2_t a2 = __builtin_convertvector(sa, bf16x2_t), b2 = __builtin_convertvector(sb, bf16x2_t);              // exact
+    // a bf16x2 register = (element 2i+1) << 16 | element 2i
+    p0 = make_uint2(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, b0));
+    p1 = make_uint2(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1));
+    p2 = make_uint2(__builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, b2));
 }
 
 // Activations of the DeepSortYOLOv4 / YOLOX programs, as conv_igemm_p3.hip: every transcendental is evaluated in double precision
@@ -743,13 +749,15 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* w, uint
         const int k = t * Cin + cin;
         float v = 0.f;
         if (cout < CoutPad) v = w[((size_t)(k >> 5) * CoutPad + cout) * 32 + 8 * (k & 3) + ((k & 31) >> 2)];
-        const unsigned b0 = __float_as_uint(v) & 0xffff0000u;
-        const float r1 = v - __uint_as_float(b0);
-        const unsigned b1 = __float_as_uint(r1) & 0xffff0000u;
-        const float r2 = r1 - __uint_as_float(b1);
-        h[0][j] = (unsigned short)(b0 >> 16);
-        h[1][j] = (unsigned short)(b1 >> 16);
-        h[2][j] = (unsigned short)(__float_as_uint(r2) >> 16);
+        // round-to-nearest-even split (see split4): planes 1 and 2 are signed residuals
+        const __bf16 q0 = (__bf16)v;
+        const float r1 = v - (float)q0;                                      // exact
+        const __bf16 q1 = (__bf16)r1;
+        const float r2 = r1 - (float)q1;                                     // exact, <= 8 significant bits
+        const __bf16 q2 = (__bf16)r2;                                        // exact
+        h[0][j] = __builtin_bit_cast(unsigned short, q0);
+        h[1][j] = __builtin_bit_cast(unsigned short, q1);
+        h[2][j] = __builtin_bit_cast(unsigned short, q2);
     }
     const size_t frag = (i >> 6) * 3;
 #pragma unroll

@@ -418,29 +418,33 @@ __global__ __launch_bounds__(256) void roi_align_kernel(FpnLevels L, int C, cons
 // A sample's four weights are products hy*hx, hy*lx, ly*hx, ly*lx and the sample grid of a bin is a tensor product (y depends on
 // iy only, x on ix only), so
 //     out[ph][pw][c] = 1/count * sum_iy sum_ix bilinear(y_iy, x_ix)[c] = sum_Y Wy[ph][Y] * ( sum_X Wx[pw][X] * F[Y][X][c] )
-// with Wx[pw][X] = sum over the bin's valid x samples of (hx if x_low == X) + (lx if x_high == X), Wy likewise.  The inner sums
-// T[Y][pw] are computed once per feature row and shared by every sample row and bin that touches the row: ~8 K vector
-// instructions per RoI instead of ~90 K, every window pixel fetched from L2 about once instead of once per tap.
-// Same sample positions, validity rule and clamping as mmcv's kernel; the float32 sum is taken in another ORDER,
-// so this form belongs to the default numerics (tolerance-based parity, tests/test_gpu_split.py); programs created
-// PP_NET_NUMERICS_EXACT keep roi_align_kernel, whose (iy, ix) accumulation order is the oracle's.
-// One wave per RoI, lane = 4 channels (C = 256).  x weights live in two registers ACROSS the lanes (entry pw * S + j, S = gw + 2
-// columns per bin) and reach the multiply-adds as scalars through v_readlane; RoIs wider than 16 samples per bin take the exact
-// loop (rare: > 112 feature pixels).
+// with Wx[pw][X] = sum over the bin's valid x samples of (hx if x_low == X) + (lx if x_high == X), Wy likewise.  The row sums
+// T[Y][pw] are computed once per feature row -- every pixel of the RoI's window is loaded ONCE -- and shared by all y samples
+// and bins that touch the row.  RoIs far larger than the map (proposals are not clipped: SURVEY.md A5) cost what the map costs.
+// Same sample positions, validity rule and clamping as mmcv's kernel; the float32 sum is taken in another ORDER, so this form
+// belongs to the default numerics (tolerance-based parity, tests/test_gpu_split.py); programs created PP_NET_NUMERICS_EXACT
+// keep roi_align_kernel, whose (iy, ix) accumulation order is the oracle's.
+// One wave per RoI, lane = 4 channels (C = 256).  Wx is a dense table in LDS ([column of the window][8 floats], filled by the
+// lanes in parallel, read back as broadcasts); the two most recent rows' T stay in registers while the y samples sweep down.
 __device__ __forceinline__ float4 fma4(float w, const float4 v, const float4 a) {
     return make_float4(fmaf(w, v.x, a.x), fmaf(w, v.y, a.y), fmaf(w, v.z, a.z), fmaf(w, v.w, a.w));
 }
 
+constexpr int ROI_MAXW = 288;     // widest FPN map the table holds (level 0 of a 640 x 1088 input: 272 columns)
+
 __global__ __launch_bounds__(256) void roi_align_sep_kernel(FpnLevels L, int C, const float* __restrict__ rois,
                                                             const int32_t* __restrict__ n_rois, int max_rois, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float s_wx[4][ROI_MAXW][8];
     const int f = blockIdx.y;
     const int lane = threadIdx.x & 63;
-    const int r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int r = blockIdx.x * 4 + wv;
     if (r >= max_rois) return;
     float* o = out + ((size_t)f * max_rois + r) * 49 * C + lane * 4;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (r >= n_rois[f]) {
 #pragma unroll 7
-        for (int b = 0; b < 49; ++b) *reinterpret_cast<float4*>(o + b * C) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < 49; ++b) *reinterpret_cast<float4*>(o + b * C) = zero4;
         return;
     }
     const float* roi = rois + ((size_t)f * max_rois + r) * 4;
@@ -454,55 +458,67 @@ __global__ __launch_bounds__(256) void roi_align_sep_kernel(FpnLevels L, int C, 
     const float bw = rw / 7.f, bh = rh / 7.f;
     const int gh = __builtin_amdgcn_readfirstlane((int)ceilf(rh / 7.f)), gw = __builtin_amdgcn_readfirstlane((int)ceilf(rw / 7.f));
     const float count = (float)max(gh * gw, 1);
-    const int S = gw + 2;
-    if (gw < 1 || gh < 1 || 7 * S > 128) {
-        // degenerate (empty) or very wide RoI: the exact loop, one wave for all 49 bins
-        for (int bin = 0; bin < 49; ++bin) {
-            const int ph = bin / 7, pw = bin - ph * 7;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int iy = 0; iy < gh; ++iy) {
-                const float y = (y1 + (float)ph * bh) + (((float)iy + 0.5f) * bh) / (float)gh;
-                for (int ix = 0; ix < gw; ++ix) {
-                    const float x = (x1 + (float)pw * bw) + (((float)ix + 0.5f) * bw) / (float)gw;
-                    const float4 v = bilinear4(feat, H, W, C, 0, y, x);
-                    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    // columns any valid x sample can touch, with one column of slack on either side (zero weights there)
+    const float xs_first = x1 + (0.5f * bw) / (float)max(gw, 1), xs_last = (x1 + 6.f * bw) + (((float)gw - 0.5f) * bw) / (float)max(gw, 1);
+    const bool empty = gw < 1 || gh < 1 || !(xs_last >= -1.0f) || !(xs_first <= (float)W) || W > ROI_MAXW;
+    if (empty) {
+        if (gw >= 1 && gh >= 1 && W > ROI_MAXW) {
+            // map wider than the weight table: the sample loop (one wave for all 49 bins); not reached with a 640 x 1088 input
+            for (int bin = 0; bin < 49; ++bin) {
+                const int ph = bin / 7, pw = bin - ph * 7;
+                float4 acc = zero4;
+                for (int iy = 0; iy < gh; ++iy) {
+                    const float y = (y1 + (float)ph * bh) + (((float)iy + 0.5f) * bh) / (float)gh;
+                    for (int ix = 0; ix < gw; ++ix) {
+                        const float x = (x1 + (float)pw * bw) + (((float)ix + 0.5f) * bw) / (float)gw;
+                        const float4 v = bilinear4(feat, H, W, C, 0, y, x);
+                        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                    }
                 }
+                *reinterpret_cast<float4*>(o + bin * C) = make_float4(acc.x / count, acc.y / count, acc.z / count, acc.w / count);
             }
-            *reinterpret_cast<float4*>(o + bin * C) = make_float4(acc.x / count, acc.y / count, acc.z / count, acc.w / count);
+            return;
         }
+#pragma unroll 7
+        for (int b = 0; b < 49; ++b) *reinterpret_cast<float4*>(o + b * C) = zero4;        // no sample inside the map: mmcv's sum is 0
         return;
     }
-    // ---- x weights: entry e = pw * S + j is column xb[pw] + j of bin pw; lane e & 63 of register e >> 6 ------------------------
-    int xb[7];
+    const int Xmin = __builtin_amdgcn_readfirstlane(min(max((int)floorf(fmaxf(xs_first, -1.0f)) - 1, 0), W - 1));
+    const int Xmax = __builtin_amdgcn_readfirstlane(min(max((int)floorf(fminf(xs_last, (float)W)) + 2, 0), W - 1));
+    const int Wn = Xmax - Xmin + 1;
+    // ---- Wx[pw][X], X = Xmin + column: lane-parallel over the columns ----------------------------------------------------------
+    float (*wxt)[8] = s_wx[wv];
+    for (int c0 = 0; c0 < Wn; c0 += 64) {
+        const int col = c0 + lane;
+        const int X = Xmin + col;
+        float w[8];
 #pragma unroll
-    for (int pw = 0; pw < 7; ++pw) {
-        const float xf = (x1 + (float)pw * bw) + (0.5f * bw) / (float)gw;       // the bin's first sample
-        xb[pw] = __builtin_amdgcn_readfirstlane(min(max((int)floorf(xf), 0), W - 1));
-    }
-    float wx[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int e = q * 64 + lane;
-        const int pw = e / S, j = e - pw * S;
-        float w = 0.f;
-        if (pw < 7) {
-            int xbp = xb[0];
-#pragma unroll
-            for (int k = 1; k < 7; ++k) xbp = pw == k ? xb[k] : xbp;
-            const int X = xbp + j;
-            for (int ix = 0; ix < gw; ++ix) {
-                float x = (x1 + (float)pw * bw) + (((float)ix + 0.5f) * bw) / (float)gw;
-                if (x < -1.0f || x > (float)W) continue;
-                if (x <= 0.f) x = 0.f;
-                int xl = (int)x, xh;
-                if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
-                const float lx = x - (float)xl, hx = 1.f - lx;
-                if (xl == X) w += hx;
-                if (xh == X) w += lx;
+        for (int pw = 0; pw < 7; ++pw) {
+            float acc = 0.f;
+            // the bin's samples lie in [xf, xf + bw): columns floor(xf) .. floor(xf + bw) + 1 (after clamping into the map)
+            const float xf = x1 + (float)pw * bw;
+            if ((float)X >= xf - 2.0f && (float)X <= xf + bw + 2.0f) {
+                for (int ix = 0; ix < gw; ++ix) {
+                    float x = (x1 + (float)pw * bw) + (((float)ix + 0.5f) * bw) / (float)gw;
+                    if (x < -1.0f || x > (float)W) continue;
+                    if (x <= 0.f) x = 0.f;
+                    int xl = (int)x, xh;
+                    if (xl >= W - 1) { xh = xl = W - 1; x = (float)xl; } else xh = xl + 1;
+                    const float lx = x - (float)xl, hx = 1.f - lx;
+                    if (xl == X) acc += hx;
+                    if (xh == X) acc += lx;
+                }
             }
+            w[pw] = acc;
         }
-        wx[q] = w;
+        w[7] = 0.f;
+        if (col < Wn) {
+            *reinterpret_cast<float4*>(&wxt[col][0]) = make_float4(w[0], w[1], w[2], w[3]);
+            *reinterpret_cast<float4*>(&wxt[col][4]) = make_float4(w[4], w[5], w[6], w[7]);
+        }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the table is private to this wave: LDS writes before the reads below
+    __builtin_amdgcn_wave_barrier();
     // ---- rows: T[pw] = sum_X Wx[pw][X] F[row][X]; the two most recent rows stay in registers -----------------------------------
     float4 T0[7], T1[7];
     int R0 = -1000, R1 = -1000;
@@ -511,19 +527,25 @@ __global__ __launch_bounds__(256) void roi_align_sep_kernel(FpnLevels L, int C, 
         for (int pw = 0; pw < 7; ++pw) T1[pw] = T0[pw];
         R1 = R0;
 #pragma unroll
-        for (int pw = 0; pw < 7; ++pw) T0[pw] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* frow = feat + (size_t)row * W * C;
-        for (int j = 0; j < S; ++j) {
-            float4 v[7];
+        for (int pw = 0; pw < 7; ++pw) T0[pw] = zero4;
+        const float* frow = feat + ((size_t)row * W + Xmin) * C;
+        int c = 0;
+        for (; c + 4 <= Wn; c += 4) {
+            float4 v[4];
 #pragma unroll
-            for (int pw = 0; pw < 7; ++pw) v[pw] = *reinterpret_cast<const float4*>(frow + (size_t)min(xb[pw] + j, W - 1) * C);
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(frow + (size_t)(c + u) * C);
 #pragma unroll
-            for (int pw = 0; pw < 7; ++pw) {
-                const int e = pw * S + j;                                             // wave-uniform
-                const float w = e < 64 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wx[0]), e))
-                                       : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wx[1]), e - 64));
-                T0[pw] = fma4(w, v[pw], T0[pw]);
+            for (int u = 0; u < 4; ++u) {
+                const float4 wa = *reinterpret_cast<const float4*>(&wxt[c + u][0]), wb = *reinterpret_cast<const float4*>(&wxt[c + u][4]);
+                T0[0] = fma4(wa.x, v[u], T0[0]); T0[1] = fma4(wa.y, v[u], T0[1]); T0[2] = fma4(wa.z, v[u], T0[2]); T0[3] = fma4(wa.w, v[u], T0[3]);
+                T0[4] = fma4(wb.x, v[u], T0[4]); T0[5] = fma4(wb.y, v[u], T0[5]); T0[6] = fma4(wb.z, v[u], T0[6]);
             }
+        }
+        for (; c < Wn; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(frow + (size_t)c * C);
+            const float4 wa = *reinterpret_cast<const float4*>(&wxt[c][0]), wb = *reinterpret_cast<const float4*>(&wxt[c][4]);
+            T0[0] = fma4(wa.x, v, T0[0]); T0[1] = fma4(wa.y, v, T0[1]); T0[2] = fma4(wa.z, v, T0[2]); T0[3] = fma4(wa.w, v, T0[3]);
+            T0[4] = fma4(wb.x, v, T0[4]); T0[5] = fma4(wb.y, v, T0[5]); T0[6] = fma4(wb.z, v, T0[6]);
         }
         R0 = row;
     };
@@ -531,8 +553,15 @@ __global__ __launch_bounds__(256) void roi_align_sep_kernel(FpnLevels L, int C, 
     for (int ph = 0; ph < 7; ++ph) {
         float4 acc[7];
 #pragma unroll
-        for (int pw = 0; pw < 7; ++pw) acc[pw] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int iy = 0; iy < gh; ++iy) {
+        for (int pw = 0; pw < 7; ++pw) acc[pw] = zero4;
+        // the bin's y samples lie in [y1 + ph bh, y1 + (ph + 1) bh): skip the part of the loop that is outside the map
+        const float yb = y1 + (float)ph * bh;
+        int iy0 = 0, iy1 = gh;
+        if (bh > 0.f) {
+            iy0 = __builtin_amdgcn_readfirstlane(min(max((int)floorf((-1.0f - yb) * (float)gh / bh - 0.5f) - 1, 0), gh));
+            iy1 = __builtin_amdgcn_readfirstlane(min(max((int)ceilf(((float)H - yb) * (float)gh / bh - 0.5f) + 2, 0), gh));
+        }
+        for (int iy = iy0; iy < iy1; ++iy) {
             float y = (y1 + (float)ph * bh) + (((float)iy + 0.5f) * bh) / (float)gh;
             if (y < -1.0f || y > (float)H) continue;
             if (y <= 0.f) y = 0.f;

@@ -76,13 +76,20 @@ def broadcast_blob_device(blob, n_floats: int, dist, device, src=0, backend="ncc
 
 def broadcast_blob_fn(dist, device, backend="nccl", src=0, log=None):
     """blob_fn for cascade.Cascade / faster_rcnn.Detector: every program's blob comes from rank `src` and stays on the
-    device (the receivers never touch their own prog.blob).  log: optional list that receives (name, n_floats)."""
+    device (the receivers never touch their own prog.blob).  log: optional list that receives (name, n_floats, tensor).
+    The returned pointer stays valid until the NEXT call of blob_fn (or until the closure is dropped): the closure itself holds
+    the last tensor, so pp_net_create_ex's device-to-device copy (synchronous: it returns after the copy) never reads memory the
+    caching allocator has taken back."""
+    held = []
+
     def blob_fn(name, prog):
         n = int(prog.blob.size)
         t = broadcast_blob_device(prog.blob if dist.get_rank() == src else None, n, dist, device, src=src, backend=backend)
+        held[:] = [t]                           # alive while the program that consumes it is being created
         if log is not None:
-            log.append((name, n, t))            # keeps the tensor alive until the caller drops the log
+            log.append((name, n, t))
         return int(t.data_ptr()), n
+    blob_fn.held = held
     return blob_fn
 
 

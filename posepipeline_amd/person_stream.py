@@ -100,6 +100,7 @@ class PersonStreams:
         self.n_frames = 0             # frames tracked so far
         self.streams: dict = {}       # track_id -> _PersonStream (followed ids that still owe output)
         self.ignored: set = set()
+        self.finished: set = set()    # followed ids whose stream was completed and emitted (their tracker said they were gone)
 
     def ingest(self, chunk_tracks, live_sets=None):
         """chunk_tracks: per frame, rows (track_id, x1, y1, x2, y2, score[, tlwh]) as the tracking stage reports them.  Records the
@@ -119,6 +120,12 @@ class PersonStreams:
                 tid, x1, y1, x2, y2 = r[:5]
                 if tid in self.ignored:
                     continue
+                if tid in self.finished:
+                    # the stream of this id was closed because the tracker's live set no longer held it; a second stream would
+                    # emit frames that do not continue the first one.  Trackers that retain ids across misses must pass
+                    # live_sets (SortReidTracker.live_ids / ByteTracker.live_ids do).
+                    raise RuntimeError(f"track id {tid} re-appeared in frame {t} after its stream was finished: pass live_sets= "
+                                       "for a tracker that keeps ids alive across missed frames")
                 st = self.streams.get(tid)
                 if st is None:
                     if self.keep_tracks is not None:
@@ -193,6 +200,7 @@ class PersonStreams:
                 st.next3d = hi
             if final or ended:
                 del self.streams[tid]
+                self.finished.add(tid)
             else:
                 drop = st.next3d - pad - st.k2_base       # rows no window will read again
                 if drop > 0:

@@ -123,13 +123,38 @@ def robust_path(path, run=None):
             os.close(fd)
             print(f"Unable to read all the frames. Transcoding {path} to {good}")
             try:
-                (run or subprocess.run)(["ffmpeg", "-y", "-i", path, "-c:v", "libx264", "-b:v", "1M", good])
+                proc = (run or subprocess.run)(["ffmpeg", "-y", "-i", path, "-c:v", "libx264", "-b:v", "1M", good])
             except FileNotFoundError as e:
+                os.unlink(good)
                 raise RuntimeError(f"{path}: a frame does not decode and ffmpeg is not installed to transcode the file") from e
+            # a failed transcode must not be cached as the validated path (the reference has no such cache: it would retry)
+            rc = getattr(proc, "returncode", 0)
+            if rc not in (0, None) or not os.path.exists(good) or os.path.getsize(good) == 0:
+                cap.release()
+                if os.path.exists(good):
+                    os.unlink(good)
+                raise RuntimeError(f"{path}: a frame does not decode and the ffmpeg transcode failed (exit status {rc})")
+            _TRANSCODES.append(good)
             break
     cap.release()
     _ROBUST[key] = good
     return good
+
+
+_TRANSCODES: list = []
+
+
+def _cleanup_transcodes():
+    for p in _TRANSCODES:
+        try:
+            os.unlink(p)
+        except OSError:
+            pass
+
+
+import atexit  # noqa: E402
+
+atexit.register(_cleanup_transcodes)
 
 
 def open_video(path):

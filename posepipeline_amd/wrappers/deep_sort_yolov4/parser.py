@@ -30,26 +30,28 @@ _cache: dict = {}
 
 def _params(relpath, shapes, seed, **kw):
     """the reference's checkpoint when it is installed (checkpoints_tf: GraphDef constants read directly, Keras HDF5 through
-    its converted .npz or h5py), seeded weights of the same architecture with POSEPIPE_SYNTHETIC_WEIGHTS=1"""
+    its converted .npz or h5py), seeded weights of the same architecture with POSEPIPE_SYNTHETIC_WEIGHTS=1.
+    Returns (params, seeded): seeded is True only for the synthetic branch -- the caller may adjust SEEDED weights
+    (seed_person_head), never a real checkpoint, whichever file (.h5 / .pb or the converted .npz) it came from."""
     from ... import checkpoints_tf
     path = os.path.join(weights.model_data_dir(), relpath)
     converted = os.path.splitext(path)[0] + ".npz"
     if os.path.exists(path) or os.path.exists(converted):
         if relpath.endswith(".pb"):
-            return checkpoints_tf.mars_params(path if os.path.exists(path) else converted, shapes)
-        return checkpoints_tf.yolo_params(path, shapes)
+            return checkpoints_tf.mars_params(path if os.path.exists(path) else converted, shapes), False
+        return checkpoints_tf.yolo_params(path, shapes), False
     if os.environ.get("POSEPIPE_SYNTHETIC_WEIGHTS") == "1":
-        return yolov4.synth_params(shapes, seed, **kw)
+        return yolov4.synth_params(shapes, seed, **kw), True
     raise FileNotFoundError(f"{path} (set POSEPIPE_SYNTHETIC_WEIGHTS=1 to run with seeded synthetic weights)")
 
 
 def _models(src_h, src_w, device=0):
     key = (src_h, src_w, device)
     if key not in _cache:
-        ysd = _params("deep_sort_yolov4/yolo4.h5", yolov4.yolov4_param_shapes(), seed=4)
-        if not os.path.exists(os.path.join(weights.model_data_dir(), "deep_sort_yolov4/yolo4.h5")):
+        ysd, seeded = _params("deep_sort_yolov4/yolo4.h5", yolov4.yolov4_param_shapes(), seed=4)
+        if seeded:
             yolov4.seed_person_head(ysd)                 # seeded weights only: make the random head produce person candidates
-        msd = _params("deep_sort_yolov4/mars-small128.pb", mars.mars_param_shapes(), seed=5)
+        msd, _ = _params("deep_sort_yolov4/mars-small128.pb", mars.mars_param_shapes(), seed=5)
         ctx = _lib.Context(device)
         _cache[key] = (ctx, yolov4.YoloV4Detector(ctx, ysd, src_h, src_w, max_frames=BATCH),
                        mars.MarsEncoder(ctx, msd, src_h, src_w))

@@ -141,5 +141,37 @@ def test_wrapper_prefers_installed_checkpoints(tmp_path, monkeypatch):
     (tmp_path / "deep_sort_yolov4").mkdir()
     sd = yolov4.synth_params(shapes, seed=11)
     np.savez(tmp_path / "deep_sort_yolov4" / "mars-small128.npz", **sd)
-    got = parser._params("deep_sort_yolov4/mars-small128.pb", shapes, seed=5)
-    assert all(np.array_equal(got[k], sd[k]) for k in sd)
+    got, seeded = parser._params("deep_sort_yolov4/mars-small128.pb", shapes, seed=5)
+    assert not seeded and all(np.array_equal(got[k], sd[k]) for k in sd)
+
+
+def test_npz_only_yolo_checkpoint_is_not_reseeded(tmp_path, monkeypatch):
+    """only the converted yolo4.npz is installed (no .h5): it is a REAL checkpoint -- `_models` must not run seed_person_head
+    on it (that rewrites the objectness / class-0 biases of the heads and would silence a trained detector)"""
+    from posepipeline_amd.wrappers.deep_sort_yolov4 import parser
+    monkeypatch.setenv("PIPELINE_3RDPARTY", str(tmp_path))
+    monkeypatch.setenv("POSEPIPE_SYNTHETIC_WEIGHTS", "1")            # even with the synthetic switch on, an installed file wins
+    (tmp_path / "deep_sort_yolov4").mkdir()
+    yshapes = yolov4.yolov4_param_shapes()
+    ysd = yolov4.synth_params(yshapes, seed=21)
+    np.savez(tmp_path / "deep_sort_yolov4" / "yolo4.npz", **ysd)
+    got, seeded = parser._params("deep_sort_yolov4/yolo4.h5", yshapes, seed=4)
+    assert not seeded and all(np.array_equal(got[k], ysd[k]) for k in ysd)
+    # what _models does with the flag, without a GPU: the seeded branch is the only one that touches the head
+    called = []
+    monkeypatch.setattr(yolov4, "seed_person_head", lambda sd: called.append(1))
+
+    class _Stop(Exception):
+        pass
+
+    def no_gpu(*a, **k):
+        raise _Stop()
+    monkeypatch.setattr(parser._lib, "Context", no_gpu)
+    parser._cache.clear()
+    with pytest.raises(_Stop):
+        parser._models(64, 64)
+    assert not called
+    (tmp_path / "deep_sort_yolov4" / "yolo4.npz").unlink()
+    with pytest.raises(_Stop):
+        parser._models(64, 64)
+    assert called == [1]                                             # no file at all: seeded weights, head seeded

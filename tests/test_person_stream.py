@@ -203,3 +203,27 @@ def test_max_persons_and_keep_tracks():
     assert sorted(collect(outs)) == [0, 1, 3]
     outs = run_stream(tracks, [5, 7], pad, lift_fn, keep_tracks=[2])
     assert sorted(collect(outs)) == [2]
+
+
+def test_finished_id_reappearing_is_a_loud_error():
+    """an id whose stream was finished (the default live set = the ids of the frame's rows said it was gone) must not silently
+    start a second stream whose frames do not continue the first: a tracker that retains ids has to pass live_sets"""
+    pad = 2
+    lift_fn, _, _ = make_lift(pad)
+    ps = PersonStreams(K, pad, SRC, fake_topdown, lift_fn)
+    row = lambda tid, x: (tid, float(x), 10.0, float(x) + 20.0, 50.0, 0.9)
+    ps.ingest([[row(3, t)] for t in range(4)])
+    ps.advance()
+    ps.ingest([[] for _ in range(8)])           # id 3 vanishes: with the default live sets its stream ends ...
+    ps.advance()
+    assert 3 not in ps.streams and 3 in ps.finished
+    with pytest.raises(RuntimeError, match="re-appeared"):
+        ps.ingest([[row(3, 40)]])               # ... and a later row with the same id is refused
+    # with live sets that keep the id alive across the gap the same sequence is fine
+    ps2 = PersonStreams(K, pad, SRC, fake_topdown, lift_fn)
+    ps2.ingest([[row(3, t)] for t in range(4)], live_sets=[{3}] * 4)
+    ps2.advance()
+    ps2.ingest([[] for _ in range(8)], live_sets=[{3}] * 8)
+    ps2.advance()
+    ps2.ingest([[row(3, 40)]], live_sets=[{3}])
+    assert 3 in ps2.streams and not ps2.finished

@@ -59,11 +59,17 @@ def test_unreadable_frame_transcodes_whole_file(fake_cv2, tmp_path, capsys):
     p.write_bytes(b"x" * 100)
     FakeCapture.frames_ok[str(p)] = 7                                        # frame 7 of 12 does not decode
     calls = []
-    out = video.robust_path(str(p), run=lambda cmd: calls.append(cmd))
+
+    def ffmpeg(cmd):                                                         # stand-in: writes the transcode, exit status 0
+        calls.append(cmd)
+        with open(cmd[-1], "wb") as f:
+            f.write(b"transcoded")
+        return types.SimpleNamespace(returncode=0)
+    out = video.robust_path(str(p), run=ffmpeg)
     assert out != str(p) and out.endswith(".mp4")
     assert calls == [["ffmpeg", "-y", "-i", str(p), "-c:v", "libx264", "-b:v", "1M", out]]     # the reference's command
     assert "Transcoding" in capsys.readouterr().out
-    assert video.robust_path(str(p), run=lambda cmd: calls.append(cmd)) == out and len(calls) == 1
+    assert video.robust_path(str(p), run=ffmpeg) == out and len(calls) == 1
     # through the table API: the path handed to the wrappers is the transcode
     import datetime
     from posepipeline_amd import djshim, pipeline as pl
@@ -83,6 +89,26 @@ def test_missing_ffmpeg_is_an_error_not_a_silent_short_clip(fake_cv2, tmp_path):
         raise FileNotFoundError("ffmpeg")
     with pytest.raises(RuntimeError, match="ffmpeg is not installed"):
         video.robust_path(str(p), run=no_ffmpeg)
+
+
+def test_failed_transcode_is_an_error_and_is_not_cached(fake_cv2, tmp_path):
+    """ffmpeg's exit status is checked: a failed (or empty) transcode raises and leaves no cached verdict behind, so the next
+    call validates again instead of handing an empty file to every later stage"""
+    import os
+    p = tmp_path / "bad3.mp4"
+    p.write_bytes(b"z" * 10)
+    FakeCapture.frames_ok[str(p)] = 3
+    outs = []
+
+    def failing(cmd):
+        outs.append(cmd[-1])
+        return types.SimpleNamespace(returncode=1)
+    with pytest.raises(RuntimeError, match="transcode failed"):
+        video.robust_path(str(p), run=failing)
+    assert not video._ROBUST and not os.path.exists(outs[0])
+    with pytest.raises(RuntimeError, match="transcode failed"):               # empty output with status 0 is a failure, too
+        video.robust_path(str(p), run=lambda cmd: types.SimpleNamespace(returncode=0))
+    assert not video._ROBUST
 
 
 def test_raw_containers_need_no_decoder(tmp_path):
