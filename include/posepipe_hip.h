@@ -39,7 +39,8 @@ extern "C" {
                               6: pp_conv_exact, pp_net_conv_kinds; pp_conv_variant accepts 4 (fp32 convolutions on the bf16 matrix cores by a
                                  three-way operand split are the default where a layer is eligible)
                               7: pp_net_create_ex / pp_net_numerics: the numerics of a program are fixed when it is created (a per-net
-                                 property, no longer read from the process-wide switch at launch time) */
+                                 property, no longer read from the process-wide switch at launch time); pp_op gained in2 / in3 /
+                                 up2_log2 / up3_log2 (sizeof(pp_op) 104 -> 120) */
 
 typedef enum {
     PP_OK = 0,
@@ -113,9 +114,10 @@ typedef enum {
                                 and a 4-term gather; operands rounded to bf16, fp32 accumulation (tolerance-based parity) */
     PP_OP_AVGPOOL = 9,       /* nn.AvgPool2d((kh, kw), stride), no padding: float32 sum in (kh, kw) order / (kh * kw)  (the
                                 GlobalAveragePooling neck of mmtrack's ReID model, mot/deepsort/deepsort_*.py:27) */
-    PP_OP_UPSAMPLE_ADD = 7,  /* out[y][x] = act((in[y >> up_log2][x >> up_log2] + res1[y][x]) + res2[y][x]): nearest
-                                upsample + accumulate of an HRNet fuse layer (relu: PP_RELU_NONE / PP_RELU_LAST);
-                                same additions, same order as a conv with up_log2, from a fully parallel kernel */
+    PP_OP_UPSAMPLE_ADD = 7,  /* out[y][x] = act(((((res1[y][x] + in[y >> up_log2][x >> up_log2]) + in2[y >> up2_log2][x >> up2_log2])
+                                + in3[y >> up3_log2][x >> up3_log2]) + res2[y][x]): nearest upsample + accumulate of an HRNet
+                                fuse layer in mmpose's summation order (res1, in2, in3, res2 optional; relu: PP_RELU_NONE /
+                                PP_RELU_LAST); same additions, same order as a chain of convs with up_log2, in one pass */
 } pp_op_type;
 
 #define PP_RELU_NONE 0
@@ -146,6 +148,10 @@ typedef struct pp_op {
                                  bit 2 / 3: pad_h / pad_w apply in front only: the last output row / column of the
                                  symmetric-padding result is not computed (the 2x2 sub-convolutions of a deconvolution) */
     int64_t w_off, b_off;     /* float offsets into the weight blob: W (layout below), bias[cout_pad16] */
+    /* ABI 7 -- PP_OP_UPSAMPLE_ADD only (every other op: -1 / 0): two more coarse inputs, so that a whole HRNet fuse sum
+     * y_i = relu(((partial + up(t_a)) + up(t_b)) + up(t_c)) is ONE pass over the fine map (mmpose's `y += ...` order) */
+    int32_t in2, in3;         /* buffer ids, -1 = none */
+    int32_t up2_log2, up3_log2;
 } pp_op;
 
 typedef struct pp_buf {

@@ -54,7 +54,16 @@ class pp_op(C.Structure):
         ("pad_end", C.c_int32),
         ("w_off", C.c_int64),
         ("b_off", C.c_int64),
+        ("in2", C.c_int32),          # ABI 7: PP_OP_UPSAMPLE_ADD's further coarse inputs (-1 = none)
+        ("in3", C.c_int32),
+        ("up2_log2", C.c_int32),
+        ("up3_log2", C.c_int32),
     ]
+
+    def __init__(self, *args, **kw):
+        kw.setdefault("in2", -1)
+        kw.setdefault("in3", -1)
+        super().__init__(*args, **kw)
 
 
 class pp_buf(C.Structure):

@@ -238,7 +238,7 @@ static void net_plan_lanes(pp_net* net, int n_lanes) {
         auto add = [&](int d) {
             if (d >= 0 && std::find(deps.begin(), deps.end(), d) == deps.end()) deps.push_back(d);
         };
-        for (int b : {op.in, op.res1, op.res2})
+        for (int b : {op.in, op.res1, op.res2, op.in2, op.in3})
             if (b >= 0) add(last_writer[b]);
         add(last_writer[op.out]);                       // WAW
         for (int r : readers[op.out]) add(r);           // WAR
@@ -261,7 +261,7 @@ static void net_plan_lanes(pp_net* net, int n_lanes) {
                 net->op_needs_event[d] = 1;
             }
         lane_tail[lane] = i;
-        for (int b : {op.in, op.res1, op.res2})
+        for (int b : {op.in, op.res1, op.res2, op.in2, op.in3})
             if (b >= 0 && b != op.out) readers[b].push_back(i);
         last_writer[op.out] = i;
         readers[op.out].clear();
@@ -272,13 +272,15 @@ static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
     const int nb = (int)net.bufs.size();
     PP_REQUIRE(op.in >= 0 && op.in < nb && op.out >= 0 && op.out < nb, "op %d: buffer id out of range", idx);
     PP_REQUIRE(op.res1 < nb && op.res2 < nb, "op %d: residual buffer id out of range", idx);
+    PP_REQUIRE(op.in2 < nb && op.in3 < nb && (op.type == PP_OP_UPSAMPLE_ADD || (op.in2 < 0 && op.in3 < 0)),
+               "op %d: in2 / in3 are inputs of PP_OP_UPSAMPLE_ADD only (-1 elsewhere)", idx);
     const pp_buf& bi = net.bufs[op.in];
     const pp_buf& bo = net.bufs[op.out];
     const int eh = op.pad_end & 1, ew = (op.pad_end >> 1) & 1;   // TensorFlow SAME: the odd padding row / column goes last
     PP_REQUIRE(op.out_c_off >= 0 && op.in_c_off >= 0 && (op.out_c_off & 3) == 0 && (op.in_c_off & 3) == 0,
                "op %d: channel offsets must be non-negative multiples of 4", idx);
     if (op.type != PP_OP_CONV) {
-        for (int b : {op.in, op.out, op.res1, op.res2})
+        for (int b : {op.in, op.out, op.res1, op.res2, op.in2, op.in3})
             PP_REQUIRE(b < 0 || net.bufs[b].pad == 0, "op %d: only convolutions may touch a buffer with a zero halo (buffer %d)", idx, b);
     } else {
         PP_REQUIRE(bo.pad == 0 || (!op.out_nchw && op.out_c_off == 0 && bo.c == op.cout && (op.cout & 3) == 0),
@@ -339,6 +341,13 @@ static int net_check_op(const pp_net& net, const pp_op& op, int idx) {
         for (int r : {op.res1, op.res2})
             if (r >= 0)
                 PP_REQUIRE(net.bufs[r].c == bo.c && net.bufs[r].h == bo.h && net.bufs[r].w == bo.w, "op %d: residual shape mismatch", idx);
+        PP_REQUIRE(op.in3 < 0 || op.in2 >= 0, "op %d: in3 without in2", idx);
+        for (int k = 0; k < 2; ++k) {
+            const int b = k ? op.in3 : op.in2, u = k ? op.up3_log2 : op.up2_log2;
+            if (b >= 0)
+                PP_REQUIRE(u >= 0 && u <= 5 && net.bufs[b].c == bo.c && (net.bufs[b].h << u) == bo.h && (net.bufs[b].w << u) == bo.w &&
+                               b != op.out, "op %d: in%d must be [h >> up][w >> up][c] of the out buffer", idx, k + 2);
+        }
     } else if (op.type == PP_OP_VIT_ENCODER) {
         PP_REQUIRE(op.cin == op.cout && bi.c == op.cin && bo.c == op.cin && bi.h == bo.h && bi.w == bo.w && op.in != op.out,
                    "op %d: vit encoder needs distinct in / out buffers of [h][w][dim]", idx);
@@ -412,7 +421,8 @@ static int net_launch_op(pp_net* net, const pp_op& op, int batch, hipStream_t s)
     } else if (op.type == PP_OP_UPSAMPLE_ADD) {
         return pp_launch_upsample_add(net->buf_ptr(op.in), op.res1 >= 0 ? net->buf_ptr(op.res1) : nullptr,
                                       op.res2 >= 0 ? net->buf_ptr(op.res2) : nullptr, net->buf_ptr(op.out), batch, bo.h, bo.w,
-                                      bo.c, op.up_log2, op.relu == PP_RELU_LAST, s);
+                                      bo.c, op.up_log2, op.relu == PP_RELU_LAST, s, op.in2 >= 0 ? net->buf_ptr(op.in2) : nullptr,
+                                      op.up2_log2, op.in3 >= 0 ? net->buf_ptr(op.in3) : nullptr, op.up3_log2);
     } else if (op.type == PP_OP_VIT_ENCODER) {
         pp_vit_encoder* enc = net->vits[&op - net->ops.data()];
         return pp_vit_encoder_run(enc, net->buf_ptr(op.in), net->buf_ptr(op.out), batch, s);

@@ -14,7 +14,8 @@ namespace {
 
 __global__ __launch_bounds__(256) void upsample_add_kernel(const float4* __restrict__ t, const float4* __restrict__ r1,
                                                            const float4* __restrict__ r2, float4* __restrict__ y, size_t total,
-                                                           int H, int W, int c4, int up, int relu) {
+                                                           int H, int W, int c4, int up, int relu, const float4* __restrict__ t2,
+                                                           int up2, const float4* __restrict__ t3, int up3) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int cc = (int)(i % c4);
@@ -27,6 +28,14 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float4* __restr
     float4 v = t[((n * hs + (yy >> up)) * ws + (x >> up)) * c4 + cc];
     if (r1) {
         const float4 a = r1[i];
+        v.x = __fadd_rn(v.x, a.x); v.y = __fadd_rn(v.y, a.y); v.z = __fadd_rn(v.z, a.z); v.w = __fadd_rn(v.w, a.w);
+    }
+    if (t2) {          // further coarse terms, in mmpose's `y += ...` order
+        const float4 a = t2[((n * (H >> up2) + (yy >> up2)) * (W >> up2) + (x >> up2)) * c4 + cc];
+        v.x = __fadd_rn(v.x, a.x); v.y = __fadd_rn(v.y, a.y); v.z = __fadd_rn(v.z, a.z); v.w = __fadd_rn(v.w, a.w);
+    }
+    if (t3) {
+        const float4 a = t3[((n * (H >> up3) + (yy >> up3)) * (W >> up3) + (x >> up3)) * c4 + cc];
         v.x = __fadd_rn(v.x, a.x); v.y = __fadd_rn(v.y, a.y); v.z = __fadd_rn(v.z, a.z); v.w = __fadd_rn(v.w, a.w);
     }
     if (r2) {
@@ -129,14 +138,15 @@ extern "C" int pp_crop_resize_bilinear(pp_ctx* ctx, const float* src_nhwc4, int 
 }
 
 int pp_launch_upsample_add(const float* t, const float* res1, const float* res2, float* y, int n, int H, int W, int c,
-                           int up_log2, int relu, hipStream_t stream) {
+                           int up_log2, int relu, hipStream_t stream, const float* t2, int up2, const float* t3, int up3) {
     PP_REQUIRE(n > 0 && H > 0 && W > 0 && c > 0 && (c & 3) == 0, "upsample_add: c = %d must be a multiple of 4", c);
     PP_REQUIRE(up_log2 >= 0 && up_log2 <= 5 && (H >> up_log2 << up_log2) == H && (W >> up_log2 << up_log2) == W,
                "upsample_add: %dx%d is not a multiple of 2^%d", H, W, up_log2);
     const size_t total = (size_t)n * H * W * (c / 4);
     hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
                        reinterpret_cast<const float4*>(t), reinterpret_cast<const float4*>(res1),
-                       reinterpret_cast<const float4*>(res2), reinterpret_cast<float4*>(y), total, H, W, c / 4, up_log2, relu);
+                       reinterpret_cast<const float4*>(res2), reinterpret_cast<float4*>(y), total, H, W, c / 4, up_log2, relu,
+                       reinterpret_cast<const float4*>(t2), up2, reinterpret_cast<const float4*>(t3), up3);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }

@@ -145,9 +145,11 @@ int pp_launch_attention(const void* qkv, int batch, int tokens, int heads, int h
                         int head_major = 0);
 // [n][h][w][4 * c] (parity-major channel groups g = 2 * dy + dx) -> [n][2h][2w][c]
 int pp_launch_depth_to_space(const float* x, float* y, int n, int h, int w, int c, hipStream_t stream);
-// y[n][H][W][c] = act((t[n][H >> u][W >> u][c] + res1) + res2)   (elementwise.hip; res1 / res2 may be null)
+// y[n][H][W][c] = act((((res1 + t[n][H >> u][W >> u][c]) + t2[.. >> u2]) + t3[.. >> u3]) + res2)   (elementwise.hip; res1 / res2 /
+// t2 / t3 may be null)
 int pp_launch_upsample_add(const float* t, const float* res1, const float* res2, float* y, int n, int H, int W, int c,
-                           int up_log2, int relu, hipStream_t stream);
+                           int up_log2, int relu, hipStream_t stream, const float* t2 = nullptr, int up2 = 0,
+                           const float* t3 = nullptr, int up3 = 0);
 // encoder behind PP_OP_VIT_ENCODER; `params` is a DEVICE pointer into the program's fp32 weight blob
 struct pp_vit_encoder;
 size_t pp_vit_param_floats(int tokens, int dim, int depth, int hidden);

@@ -8,11 +8,11 @@ num_deconv_layers=0, final_conv_kernel=1).  W32 is the same family with widths (
 
 Fusion done here (the reference runs every conv / BN / ReLU / add / upsample as its own op):
   * BN folded into each conv; ReLU and the residual add in the conv epilogue;
-  * HRModule fuse layers  y_i = relu(sum_j f_ij(x_j))  are accumulated in j order by the epilogues
-    of the f_ij convs themselves: the 1x1 "upsample" convs write (partial + value) to every pixel
-    of the 2^(j-i) x 2^(j-i) patch (nearest upsample), the identity term rides along as a second
-    residual, and the last j applies the ReLU -- same additions in the same order as mmpose's
-    `y += ...` loop, so the result is bit-identical to the unfused evaluation.
+  * HRModule fuse layers  y_i = relu(sum_j f_ij(x_j))  are accumulated in mmpose's j order: the strided terms (j < i) and
+    the identity term by the epilogues of the strided convs (residual adds), the coarse terms (j > i) -- 1x1 conv + BN at
+    the COARSE resolution, nearest upsample -- by one PP_OP_UPSAMPLE_ADD pass over the fine map that adds all of them in
+    order and applies the ReLU: one read and one write of the fine map per output instead of one per term.  Same additions
+    in the same order as mmpose's `y += ...` loop, so the result is bit-identical to the unfused evaluation.
 """
 from __future__ import annotations
 
@@ -25,7 +25,10 @@ from ..program import ProgramBuilder, Program, fold_bn
 
 import os
 
-FUSE_UP_IN_CONV = os.environ.get("POSEPIPE_HRNET_SPLIT_UP", "0") != "1"     # A/B switch, see _HR.module
+# How the coarse-to-fine terms of a fuse layer are accumulated (A/B switch, see _HR.module): "onepass" (default) = the 1x1 convs
+# stay at their own resolution and ONE PP_OP_UPSAMPLE_ADD pass adds all of them to the partial sum; "conv" = round 1's form,
+# each 1x1 conv's epilogue scatters over its 2^u x 2^u patch (one read + write of the fine map per term).  Same bits either way.
+FUSE_MODE = os.environ.get("POSEPIPE_HRNET_FUSE", "onepass")
 
 COCO_FLIP_PAIRS = [(1, 2), (3, 4), (5, 6), (7, 8), (9, 10), (11, 12), (13, 14), (15, 16)]
 # Halpe-136: derived from the `swap=` fields of /root/reference/3rdparty/mmpose/config/_base_/halpe.py
@@ -172,6 +175,8 @@ class _HR:
             # follows it (j + 1 == i), x_i as res2:  (partial + conv) + x_i.
             acc = -1
             j = 0
+            ups = []                                    # "onepass": the coarse terms (buffer, up_log2), j > i, added at the end
+            onepass = FUSE_MODE == "onepass"
             while j < n_br:
                 if j == i:
                     assert acc == -1 and i == 0
@@ -183,16 +188,13 @@ class _HR:
                 relu = L.PP_RELU_LAST if is_last else L.PP_RELU_NONE
                 f = f"{mp}fuse_layers.{i}.{j}."
                 if j > i:
-                    # 1x1 conv + BN on the coarse branch, then nearest upsample + accumulate.  FUSE_UP_IN_CONV = the first
-                    # form of this round (the conv epilogue scatters over the 2^u x 2^u patch); the split form gives the
-                    # same bits from a fully parallel kernel (csrc/elementwise.hip) and is what runs
-                    if FUSE_UP_IN_CONV:
+                    if onepass:
+                        ups.append((self.cb(xs[j], f + "0", f + "1", pad=0), j - i))      # 1x1 conv + BN at the coarse resolution
+                    else:
+                        # the conv epilogue scatters (partial + value) over the 2^u x 2^u patch
                         h, w, c = pb.dims(xs[i])
                         acc = self.cb(xs[j], f + "0", f + "1", pad=0, relu=relu, res1=acc, up_log2=j - i,
                                       out=pb.buf(h, w, c))
-                    else:
-                        t = self.cb(xs[j], f + "0", f + "1", pad=0)
-                        acc = pb.upsample_add(t, up_log2=j - i, res1=acc, relu=relu, name=f + "up")
                 else:
                     y = xs[j]
                     for k in range(i - j - 1):
@@ -201,6 +203,10 @@ class _HR:
                     acc = self.cb(y, f"{f}{k}.0", f"{f}{k}.1", stride=2, relu=relu, res1=acc,
                                   res2=xs[i] if absorb else -1)
                 j += 2 if absorb else 1
+            if ups:
+                # y = relu(((acc + up(t_a)) + up(t_b)) + up(t_c)): every coarse term of this output in one pass
+                acc = pb.upsample_add(ups[0][0], up_log2=ups[0][1], res1=acc, relu=L.PP_RELU_LAST, more=ups[1:],
+                                      name=f"{mp}fuse_layers.{i}.up")
             outs.append(acc)
         return outs
 

@@ -185,14 +185,20 @@ class ProgramBuilder:
         return self._plain_op(L.PP_OP_VIT_ENCODER, x, out, cin=dim, cout=dim, kh=depth, kw=heads, stride=mlp_ratio,
                               w_off=self._add_blob(params), name=name, flops=2.0 * macs)
 
-    def upsample_add(self, t, *, up_log2, res1=-1, res2=-1, relu=L.PP_RELU_NONE, name="upsample_add") -> int:
-        """out = act((nearest-upsample(t, 2^up_log2) + res1) + res2), the accumulate step of an HRNet fuse layer."""
+    def upsample_add(self, t, *, up_log2, res1=-1, res2=-1, relu=L.PP_RELU_NONE, name="upsample_add", more=()) -> int:
+        """out = act((((res1 + up(t, 2^up_log2)) + up(t2, 2^u2)) + up(t3, 2^u3)) + res2): the accumulate step(s) of an HRNet fuse
+        layer in one pass.  more: up to two further coarse terms [(buffer, up_log2), ...], added in this order."""
         h, w, c = self.dims(t)
         out = self.buf(h << up_log2, w << up_log2, c)
+        more = list(more)
+        assert len(more) <= 2
+        for tb, ub in more:
+            assert self.dims(tb) == ((h << up_log2) >> ub, (w << up_log2) >> ub, c), (self.dims(tb), self.dims(out), ub)
+        (in2, up2), (in3, up3) = (more + [(-1, 0), (-1, 0)])[:2]
         self.vops.append(dict(type=L.PP_OP_UPSAMPLE_ADD, in_=t, out=out, res1=res1, res2=res2, cin=c, cout=c, kh=1, kw=1,
                               stride=1, pad_h=0, pad_w=0, dil_h=1, dil_w=1, relu=relu, up_log2=up_log2, out_nchw=0,
                               res1_shift=0, res1_off_w=0, out_c_off=0, in_c_off=0, pad_end=0, w_off=0, b_off=0, name=name,
-                              flops=0.0))
+                              in2=in2, in3=in3, up2_log2=up2, up3_log2=up3, flops=0.0))
         return out
 
     def deconv4x4s2_bf16(self, x, weight, bias, *, relu=L.PP_RELU_NONE, name="deconv_bf16") -> int:
@@ -260,8 +266,8 @@ class ProgramBuilder:
         need = [0] * n_v
         for op in self.vops:
             conv = op["type"] == L.PP_OP_CONV
-            for k in ("in_", "out", "res1", "res2"):
-                v = op[k]
+            for k in ("in_", "out", "res1", "res2", "in2", "in3"):
+                v = op.get(k, -1)
                 if v >= 0 and not conv:
                     ok[v] = False
             if not conv:
@@ -284,8 +290,8 @@ class ProgramBuilder:
         last_use = [-1] * n_v
         first_def = [None] * n_v
         for i, op in enumerate(self.vops):
-            for key in ("in_", "res1", "res2", "out"):
-                v = op[key]
+            for key in ("in_", "res1", "res2", "in2", "in3", "out"):
+                v = op.get(key, -1)
                 if v >= 0:
                     last_use[v] = i
             if first_def[op["out"]] is None:
@@ -307,7 +313,7 @@ class ProgramBuilder:
                 key = self.dims(v) + (vpad[v],)
                 pool = free.get(key, [])
                 # never alias an operand of this very op
-                busy = {v2p[op[k]] for k in ("in_", "res1", "res2") if op[k] >= 0}
+                busy = {v2p[op[k]] for k in ("in_", "res1", "res2", "in2", "in3") if op.get(k, -1) >= 0}
                 pick = next((p for p in pool if p not in busy), None)
                 if pick is not None:
                     pool.remove(pick)
@@ -317,8 +323,8 @@ class ProgramBuilder:
                     phys_pad.append(vpad[v])
                     v2p[v] = len(phys_dims) - 1
             # release operands whose last use is this op
-            for key in ("in_", "res1", "res2", "out"):
-                u = op[key]
+            for key in ("in_", "res1", "res2", "in2", "in3", "out"):
+                u = op.get(key, -1)
                 if u >= 0 and last_use[u] == i and not self.vbufs[u].pinned and v2p[u] >= 0:
                     lst = free.setdefault(self.dims(u) + (vpad[u],), [])
                     if v2p[u] not in lst:
@@ -329,7 +335,7 @@ class ProgramBuilder:
             for k, val in op.items():
                 if k in ("name", "flops"):
                     continue
-                if k in ("in_", "out", "res1", "res2"):
+                if k in ("in_", "out", "res1", "res2", "in2", "in3"):
                     val = v2p[val] if val >= 0 else -1
                 setattr(rec, k, int(val))
             ops.append(rec)

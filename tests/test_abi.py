@@ -36,9 +36,10 @@ def test_binding_table_matches_header():
 
 
 def test_struct_layout_matches_header():
-    # pp_op (ABI v2): 22 int32 + 2 int64
-    assert ctypes.sizeof(_lib.pp_op) == 104
-    assert _lib.pp_op.w_off.offset == 88 and _lib.pp_op.b_off.offset == 96
+    # pp_op (ABI v7): 22 int32 + 2 int64 + 4 int32 (in2, in3, up2_log2, up3_log2)
+    assert ctypes.sizeof(_lib.pp_op) == 120
+    assert _lib.pp_op.w_off.offset == 88 and _lib.pp_op.b_off.offset == 96 and _lib.pp_op.in2.offset == 104
+    assert _lib.pp_op().in2 == -1 and _lib.pp_op().in3 == -1            # "none" by default, like res1 / res2 in every builder
     assert ctypes.sizeof(_lib.pp_buf) == 16            # h, w, c, pad (ABI v5)
 
 
