@@ -561,20 +561,32 @@ def cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames, gt, n_frames, cascade
     for mode, cas in cascades.items():
         if cas is None:
             continue
-        eq, box_d, d2, d3, n_det = 0, 0.0, 0.0, 0.0, 0
+        eq, box_d, sc_d, d2, d3, n_det, n_match, n_dev = 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0
         for fi, bb, dets, kp, k3 in ref:
             g = cas.detector.run(frames[fi][None])[0]
             kg, _ = cas.topdown.run(frames[fi][None], np.zeros(1, np.int32), bb[None])
             k3g = lift(cas.lift_net, cas.lift_spec, normalize_screen_coordinates(kg[:, :, :2].astype(np.float64), 1920, 1080))
-            same_n = g.shape == dets.shape
-            eq += bool(same_n and np.array_equal(g, dets))
+            eq += bool(g.shape == dets.shape and np.array_equal(g, dets))
             n_det += len(dets)
-            if same_n and len(g):
-                box_d = max(box_d, float(np.abs(g[:, :4] - dets[:, :4]).max()))
+            n_dev += len(g)
+            # row order follows the scores, and near-tied scores swap places under any change of the float32 summation order:
+            # match every oracle detection to the device detection with the nearest box
+            for row in dets:
+                if len(g):
+                    d = np.abs(g[:, :4] - row[:4]).max(axis=1)
+                    j = int(np.argmin(d))
+                    if d[j] <= 0.05:
+                        n_match += 1
+                        box_d = max(box_d, float(d[j]))
+                        sc_d = max(sc_d, float(abs(g[j, 4] - row[4])))
             d2 = max(d2, float(np.abs(kg[0, :, :2] - kp[0, :, :2]).max()))
             d3 = max(d3, float(np.abs(k3g - k3).max()))
-        readout[mode] = {"frames": len(ref), "frames_with_identical_detections": eq, "oracle_detections": n_det,
-                         "max_abs_diff_boxes_px": box_d, "max_abs_diff_2d_px": d2, "max_abs_diff_3d": d3}
+        readout[mode] = {"frames": len(ref), "frames_with_bit_identical_detections": eq, "oracle_detections": n_det,
+                         "device_detections": n_dev, "oracle_detections_matched_within_0.05px": n_match,
+                         "max_abs_diff_boxes_px": box_d, "max_abs_diff_scores": sc_d, "max_abs_diff_2d_px": d2, "max_abs_diff_3d": d3,
+                         "note": "seeded-random weights: the detector's 100-of-~1000 cut and NMS sit on near-ties, heat-maps are noise "
+                                 "(ill-conditioned arg-max / DARK step); the tolerance claims are tests/test_gpu_parity_modes.py "
+                                 "(well-conditioned weights, margin-aware detector check)"}
     return {"value": n_timed / dt, "unit": "frames/s", "cores": clib.N_THREADS, "kind": "port",
             "sample": "%d synthetic 1080p frame(s) through the CPU restatement of detect + top-down 2D (W48, flip) + one lifting window "
                       "(%.1f s, detector %.1f s); parity readout over %d frames" % (n_timed, dt, t_det, len(ref)),

@@ -137,9 +137,12 @@ class _Relation:
         rows = self._rows_out()
         if attrs == ("KEY",):
             return [{a: r[a] for a in self.table.primary_key} for r in rows]
+        pk = self.table.primary_key
         if not attrs or as_dict:
-            return [dict(r) if not attrs else {a: r[a] for a in attrs} for r in rows]
-        cols = [[r[a] for r in rows] for a in attrs]
+            # "KEY" among the attributes of an as_dict fetch: the primary-key attributes are merged into each row's dict
+            names = [b for a in attrs for b in (pk if a == "KEY" else (a,))]
+            return [dict(r) if not attrs else {a: r[a] for a in names} for r in rows]
+        cols = [[({b: r[b] for b in pk} if a == "KEY" else r[a]) for r in rows] for a in attrs]
         return cols[0] if len(cols) == 1 else tuple(cols)
 
     def delete(self):
@@ -287,7 +290,9 @@ class Computed(Table):
         for key in keys:
             if any(not _Relation(cls, (_as_restriction(r),))._match_key(key) for r in restrictions):
                 continue
-            if any(all(r[a] == key[a] for a in cls.primary_key) for r in cls._store):
+            # done already?  A key_source may be coarser than the table's primary key (BestDetectedFrames: Video & DetectedFrames,
+            # pipeline.py:783-785): like DataJoint's `key_source - target`, compare on the attributes the key has
+            if any(all(r[a] == key[a] for a in key) for r in cls._store):
                 continue
             try:
                 self.make(dict(key))

@@ -218,6 +218,23 @@ class DetectedFrames(dj.Computed):  # pipeline.py:712-722
 
 
 @schema
+class BestDetectedFrames(dj.Computed):  # pipeline.py:770-785
+    definition = """
+    -> DetectedFrames
+    """
+
+    def make(self, key):  # pipeline.py:775-781: of a video's DetectedFrames rows, the one whose subject is found most often
+        rows = (DetectedFrames & key).fetch("fraction_found", "KEY", as_dict=True)
+        best = dict(rows[int(np.argmax([r["fraction_found"] for r in rows]))])
+        best.pop("fraction_found")
+        self.insert1(best)
+
+    @property
+    def key_source(self):  # pipeline.py:783-785
+        return Video & DetectedFrames
+
+
+@schema
 class TopDownMethodLookup(dj.Lookup):  # pipeline.py:979-998
     definition = """
     top_down_method      : int

@@ -6,10 +6,16 @@ pose_pipeline/utils/tracking.py:5 `annotate_single_person`), so `scripts/process
 The bodies are this package's own: every recipe is a walk over the declarative `STAGES` table below (lookup table ->
 method table -> computed tables), so adding a stage or a method is a table entry, not another copy of the sequence.
 
-Defaults that differ from the reference, on purpose: tracking "MMTrack_deepsort" (the reference's "DeepSortYOLOv4" is
-built as well: pass its name), lifting "VideoPose3D" (the reference's "GastNet" is outside the hot path), 2D method
-"MMPose" (the reference's default string "MMpose" is not a row of its own lookup table).  `BestDetectedFrames` and the
-OpenPose branch (out of scope) are not part of the walk.
+The DEFAULTS are the reference's own (utils/standard_pipelines.py:12,58-59,112-114), with the reference's behaviour:
+  * tracking_method_name "DeepSortYOLOv4" -- tracking_method 0, built here (wrappers/deep_sort_yolov4/);
+  * top_down_method_name "MMpose" -- NOT a row of TopDownMethodLookup (the row is spelled "MMPose"), so a call that relies on
+    the default fails in the lookup's fetch1, exactly like the reference; callers pass "MMPose" / "MMPoseHalpe" / ...
+    (scripts/process_h36m.py does);
+  * lifting_method_name "GastNet" -- a lookup row whose wrapper is outside the hot path:
+    LiftingPerson.make raises for it; callers of the hot path pass "VideoPose3D".
+A method name that is not in its lookup table raises from fetch1 (no silent substitution).  `BestDetectedFrames` is populated
+where the reference populates it (:100, :162); the OpenPose branch (:95-97, SURVEY.md section 2, out of scope) is not part of
+the walk.
 """
 from __future__ import annotations
 
@@ -78,7 +84,7 @@ def _person_key(tracking_key: dict):
     return rows.fetch1("KEY") if len(rows) == 1 else None
 
 
-def tracking_pipeline(keys: Union[Dict, List[Dict]], tracking_method_name: str = "MMTrack_deepsort", reserve_jobs: bool = False):
+def tracking_pipeline(keys: Union[Dict, List[Dict]], tracking_method_name: str = "DeepSortYOLOv4", reserve_jobs: bool = False):
     """Video key(s) -> tracked boxes -> (auto-annotated) subject -> smoothed person box.
     Returns the PersonBbox keys of the videos that have exactly one."""
     done = []
@@ -94,8 +100,8 @@ def tracking_pipeline(keys: Union[Dict, List[Dict]], tracking_method_name: str =
     return done
 
 
-def top_down_pipeline(key: Union[Dict, List[Dict]], tracking_method_name: str = "MMTrack_deepsort",
-                      top_down_method_name: str = "MMPose", reserve_jobs: bool = False):
+def top_down_pipeline(key: Union[Dict, List[Dict]], tracking_method_name: str = "DeepSortYOLOv4",
+                      top_down_method_name: str = "MMpose", reserve_jobs: bool = False):
     """... -> 2D key points of the subject.  Returns the TopDownPerson keys; False as soon as a video has no person box
     (its subject is not annotated yet, or was marked invalid with a negative video_subject_id)."""
     out = []
@@ -109,12 +115,13 @@ def top_down_pipeline(key: Union[Dict, List[Dict]], tracking_method_name: str = 
             return False
         top_down_key = STAGES["top_down"].enter(person, top_down_method_name)
         STAGES["top_down"].run(top_down_key, reserve_jobs)
+        P.BestDetectedFrames.populate(key, reserve_jobs=reserve_jobs)
         out.append(top_down_key)
     return out
 
 
-def lifting_pipeline(key, tracking_method_name: str = "MMTrack_deepsort", top_down_method_name: str = "MMPose",
-                     lifting_method_name: str = "VideoPose3D", reserve_jobs: bool = False):
+def lifting_pipeline(key, tracking_method_name: str = "DeepSortYOLOv4", top_down_method_name: str = "MMpose",
+                     lifting_method_name: str = "GastNet", reserve_jobs: bool = False):
     """... -> 3D joints.  Returns True when the video has a LiftingPerson row afterwards; the falsy result of
     top_down_pipeline, or False, when an upstream row is missing (another worker holds the job)."""
     upstream = top_down_pipeline(key, tracking_method_name, top_down_method_name, reserve_jobs=reserve_jobs)
@@ -130,6 +137,6 @@ def lifting_pipeline(key, tracking_method_name: str = "MMTrack_deepsort", top_do
     if len(P.LiftingPerson & lifting_key) == 0:
         print(f"{lifting_key}: 3D joints not available (job reserved elsewhere?)")
         return False
-    for table in (P.VideoInfo, P.DetectedFrames):
+    for table in (P.VideoInfo, P.DetectedFrames, P.BestDetectedFrames):
         table.populate(key, reserve_jobs=reserve_jobs)
     return len(P.LiftingPerson & key) > 0

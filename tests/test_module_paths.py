@@ -54,7 +54,8 @@ def test_recipe_through_reference_paths(monkeypatch, tmp_path):
     monkeypatch.setattr(wmm, "mmpose_top_down_person", lambda key, method="x": np.ones((5, 17, 3), np.float32))
     monkeypatch.setattr(wvp, "process_videopose3d",
                         lambda key, **kw: {"keypoints_3d": np.zeros((5, 17, 3)), "keypoints_valid": [True] * 5})
-    assert lifting_pipeline(vkey) is True
+    assert lifting_pipeline(vkey, tracking_method_name="MMTrack_deepsort", top_down_method_name="MMPose",
+                            lifting_method_name="VideoPose3D") is True
     assert seen == ["deepsort"]                                          # tracking_method 5 = MMTrack_deepsort (pipeline.py:539-541)
     assert (pl.PersonBboxValid & vkey).fetch1("keep_tracks").tolist() == [7]
     assert (pl.LiftingPerson & vkey).fetch1("keypoints_3d").shape == (5, 17, 3)

@@ -137,16 +137,32 @@ def test_lifting_pipeline_recipe_with_stub_wrappers(monkeypatch, tmp_path):
     monkeypatch.setattr(wmm, "mmpose_top_down_person", lambda key, method="x": np.ones((9, 17, 3), np.float32))
     monkeypatch.setattr(wvp, "process_videopose3d",
                         lambda key, **kw: {"keypoints_3d": np.zeros((9, 17, 3)), "keypoints_valid": [True] * 9})
-    assert sp.lifting_pipeline(vkey) is True
+    names = dict(tracking_method_name="MMTrack_deepsort", top_down_method_name="MMPose", lifting_method_name="VideoPose3D")
+    # the DEFAULTS are the reference's (utils/standard_pipelines.py:112-114) and behave like there: "MMpose" is not a row of
+    # TopDownMethodLookup, so a call that relies on it fails in the lookup; "GastNet" is a row whose wrapper is out of scope
+    import inspect
+    sig = inspect.signature(sp.lifting_pipeline).parameters
+    assert (sig["tracking_method_name"].default, sig["top_down_method_name"].default, sig["lifting_method_name"].default) == \
+        ("DeepSortYOLOv4", "MMpose", "GastNet")
+    assert inspect.signature(sp.tracking_pipeline).parameters["tracking_method_name"].default == "DeepSortYOLOv4"
+    with pytest.raises(Exception, match="fetch1"):
+        sp.top_down_pipeline(vkey, tracking_method_name="MMTrack_deepsort")          # default "MMpose": unknown method name
+    with pytest.raises(Exception, match="fetch1"):
+        sp.tracking_pipeline(vkey, tracking_method_name="NoSuchTracker")
+    with pytest.raises(Exception, match="not implemented"):
+        sp.lifting_pipeline(vkey, tracking_method_name="MMTrack_deepsort", top_down_method_name="MMPose")   # default "GastNet"
+    (pl.LiftingMethod & {**vkey, "lifting_method": 0}).delete()          # the row that call registered (as in the reference)
+    assert sp.lifting_pipeline(vkey, **names) is True
     assert (pl.PersonBboxValid & vkey).fetch1("keep_tracks").tolist() == [3]       # auto-annotated: one identity
+    assert len(pl.BestDetectedFrames & vkey) == 1 and (pl.BestDetectedFrames & vkey).fetch1("KEY")["video_subject_id"] == 0
     assert len(pl.TopDownPerson & vkey) == 1 and len(pl.LiftingPerson & vkey) == 1
     assert (pl.LiftingMethod & vkey).fetch1("lifting_method") == 1
     # a second call is a no-op that still reports success
-    assert sp.lifting_pipeline(vkey) is True
+    assert sp.lifting_pipeline(vkey, **names) is True
     # two identities: no automatic annotation -> the recipe waits
     vkey2 = {"video_project": "p", "filename": "h"}
     pl.Video.insert1({**vkey2, "video": path, "start_time": datetime.datetime(2024, 5, 1)})
     two = [one[0] + [{"track_id": 4, "tlbr": np.array([30.0, 2, 40, 22]), "tlhw": np.array([30.0, 2, 10, 20]), "confidence": 0.8}]] * 9
     fake.mmtrack_bounding_boxes = lambda file_path, method="tracktor": two
-    assert sp.lifting_pipeline(vkey2) is False or sp.lifting_pipeline(vkey2) == []
+    assert sp.lifting_pipeline(vkey2, **names) is False or sp.lifting_pipeline(vkey2, **names) == []
     assert len(pl.PersonBbox & vkey2) == 0
