@@ -64,6 +64,8 @@ struct SplitArgs {
     int PWp;                              // patch pitch (TILE) / stored row pitch of the input (STREAM), in pixels
     int NP, NPp;                          // patch pixels, padded so that the two k halves are 64 B apart mod 128
     int mode, stride;
+    int r1_shift, r1_H, r1_W;             // res1 is read at (y >> r1_shift, x >> r1_shift) of an r1_H x r1_W map (FPN top-down add)
+    int ktaps, KW, pad, Hin, Win;         // GEMM with ktaps > 1: a KH x KW (strided) convolution as one product per (channel chunk, tap)
     long long S;                          // STREAM: positions of the padded input stream, GEMM: output pixels
     unsigned x_bytes;
     int xcd_remap;
@@ -140,7 +142,12 @@ __device__ __forceinline__ void block_pixel(int r, int bw_log2, int& iy, int& ix
 //             256 CONSECUTIVE stream positions whatever the map's width -- no tile quantisation on HRNet's 36 / 18 / 9-pixel rows;
 //             patch = the 256 + 2 pitch + 2 positions around it, loaded without any test; halo positions are not stored
 // MODE_GEMM   1x1 (any stride), and 'valid' convs whose kernel covers the whole input (the RoI head's 7x7 fc6, rewritten by
-//             the launcher as 1x1 over 49 x 256 channels): tile = 256 consecutive output pixels, one "tap"
+//             the launcher as 1x1 over 49 x 256 channels): tile = 256 consecutive output pixels, one "tap".
+//             ktaps > 1 (round 3: 3x3 stride 2): the same product form, one step per (16-channel chunk, tap) -- the operand of a
+//             step is the tile's 256 input pixels AT THAT TAP (gathered with the stride, out-of-image taps read as zero through
+//             a per-slot validity mask).  No patch reuse between taps (a strided patch is 4x the tile: 117 KB of LDS per stage),
+//             so every input element is staged 2.25 times instead of once; at 16 KB per step that is ~17 % of the vector
+//             memory path, and the layers leave the fp32 MFMA kernels (95 - 130 TFLOP/s) for this kernel's one-tap rate.
 enum { MODE_TILE = 0, MODE_STREAM = 1, MODE_GEMM = 2 };
 
 // COB: output-channel blocks (32 channels) per wave and per workgroup; PXB: pixel blocks (32 pixels) per wave.  PXB = 1
@@ -187,6 +194,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
 
     // ---- patch loader: slot j of this thread = (patch pixel p, channel quad) -----------------------------------------
     unsigned goff[NSLOT];
+    unsigned vmask[T == 1 ? NSLOT : 1];               // GEMM with taps: bit t = tap t of this slot's pixel lies inside the image
     // LDS byte offset (plane 0) of slot j: woff0 + (NT / 4) * 16 j (NT / 4 pixels further, same quad)
     const int woff0 = ((((tid & 3) >> 1) * a.NPp + (tid >> 2)) * 16 + (tid & 1) * 8);
 #pragma unroll
@@ -205,10 +213,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
             if (in_patch && pos >= 0 && pos < a.S) off = (unsigned)pos * (unsigned)a.Cin * 4u;
         } else {
             const long long m = s0 + p;
+            if constexpr (T == 1) vmask[j] = 0;
             if (in_patch && m < a.S) {
                 const int img = (int)(m / (a.H * a.W)), rem = (int)(m - (long long)img * (a.H * a.W));
                 const int ho = rem / a.W, wo = rem - ho * a.W;
-                off = (unsigned)(((img * a.xp_h + ho * a.stride) * a.xp_w + wo * a.stride) * a.Cin) * 4u;
+                if (T == 1 && a.ktaps > 1) {
+                    // origin of the pixel's window (may lie before the image: the offset wraps, a valid tap's sum is exact again)
+                    const int iy0 = ho * a.stride - a.pad, ix0 = wo * a.stride - a.pad;
+                    off = (unsigned)(((img * a.xp_h + iy0) * a.xp_w + ix0) * a.Cin) * 4u;
+                    unsigned vm = 0;
+                    for (int t = 0; t < a.ktaps; ++t) {
+                        const int dy = t / a.KW, dx = t - dy * a.KW;
+                        if ((unsigned)(iy0 + dy) < (unsigned)a.Hin && (unsigned)(ix0 + dx) < (unsigned)a.Win) vm |= 1u << t;
+                    }
+                    if constexpr (T == 1) vmask[j] = vm;
+                    if (off == 0xffffffffu) off = 0xfffffffeu;      // (never a multiple of 16; keeps the sentinel unambiguous)
+                } else {
+                    off = (unsigned)(((img * a.xp_h + ho * a.stride) * a.xp_w + wo * a.stride) * a.Cin) * 4u;
+                }
             }
         }
         goff[j] = off == 0xffffffffu ? off : off + (unsigned)quad * 16u;
@@ -216,9 +238,21 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
     float4 xr[NSLOT];
     auto load_patch = [&](int c) {
+        unsigned add = (unsigned)c * 64u;
+        int tbit = -1;
+        if (T == 1 && a.ktaps > 1) {                  // step c = (channel chunk c / ktaps, tap c % ktaps)
+            const int cc = c / a.ktaps, t = c - cc * a.ktaps;
+            const int dy = t / a.KW, dx = t - dy * a.KW;
+            add = (unsigned)(((dy * a.xp_w + dx) * a.Cin + 16 * cc) * 4);
+            tbit = t;
+        }
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
-            const unsigned off = goff[j] == 0xffffffffu ? 0xffffffffu : goff[j] + (unsigned)c * 64u;
+            bool ok = goff[j] != 0xffffffffu;
+            if constexpr (T == 1) {
+                if (tbit >= 0) ok = ((vmask[j] >> tbit) & 1u) != 0;
+            }
+            const unsigned off = ok ? goff[j] + add : 0xffffffffu;
             xr[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
         }
     };
@@ -499,7 +533,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     for (int pb = 0; pb < PXB; ++pb) {
         const int n_ = ook[pb] ? on[pb] : 0, y_ = ook[pb] ? oy[pb] : 0, x_ = ook[pb] ? ox[pb] : 0;
         ypix[pb] = ((size_t)n_ * (a.H + a.y_pad) + y_) * (a.W + a.y_pad) + x_;
-        r1pix[pb] = ((size_t)n_ * (a.H + a.r1_pad) + y_) * (a.W + a.r1_pad) + x_;
+        r1pix[pb] = ((size_t)n_ * (a.r1_H + a.r1_pad) + (y_ >> a.r1_shift)) * (a.r1_W + a.r1_pad) + (x_ >> a.r1_shift);
         r2pix[pb] = ((size_t)n_ * (a.H + a.r2_pad) + y_) * (a.W + a.r2_pad) + x_;
     }
     float4 rv[PXB][COB][4];
@@ -702,7 +736,7 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
         const int img = (int)(m / (a.H * a.W)), rem = (int)(m - (long long)img * (a.H * a.W));
         const int oy = rem / a.W, ox = rem - oy * a.W;
         const size_t ypix = ((size_t)img * (a.H + a.y_pad) + oy) * (a.W + a.y_pad) + ox;
-        const size_t r1pix = ((size_t)img * (a.H + a.r1_pad) + oy) * (a.W + a.r1_pad) + ox;
+        const size_t r1pix = ((size_t)img * (a.r1_H + a.r1_pad) + (oy >> a.r1_shift)) * (a.r1_W + a.r1_pad) + (ox >> a.r1_shift);
         const size_t r2pix = ((size_t)img * (a.H + a.r2_pad) + oy) * (a.W + a.r2_pad) + ox;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
@@ -821,8 +855,11 @@ static bool split_shape(const ConvArgs& a, int* taps, int* cin, int* mode) {
     const bool k1 = a.KH == 1 && a.KW == 1 && a.pad_h == 0 && a.pad_w == 0;
     const bool full = a.KH == a.Hin && a.KW == a.Win && a.pad_h == 0 && a.pad_w == 0 && a.dil_h == 1 && a.dil_w == 1 &&
                       a.x_pad == 0 && a.Hout == 1 && a.Wout == 1 && !k1;
-    if (!(k3 || k1 || full)) return false;
-    *taps = k3 ? 9 : 1;
+    // 3x3 stride 2 (HRNet's transition / fuse layers, ResNet's strided blocks): the product form with one step per (chunk, tap)
+    static const int s2_on = env_int("POSEPIPE_SPLIT_S2", 1);
+    const bool k3s2 = s2_on && a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad_h == 1 && a.pad_w == 1 && a.dil_h == 1 && a.dil_w == 1 && !full;
+    if (!(k3 || k1 || full || k3s2)) return false;
+    *taps = (k3 || k3s2) ? 9 : 1;
     *cin = full ? a.K : a.Cin;
     *mode = k3 ? MODE_TILE : MODE_GEMM;
     return true;
@@ -837,19 +874,23 @@ static int gemm8_cfg(const ConvArgs& a, int mode, int cin) {
     // (256 x 128 tile, two workgroups per CU: 256 -> 1024 97 -> 108, others even); below, the fp32 kernel (64 -> 256: 62 vs 47).
     static const int on = env_int("POSEPIPE_SPLIT_GEMM8", 1), min_c = env_int("POSEPIPE_SPLIT_GEMM8_MIN_C", 512),
                      min_c4 = env_int("POSEPIPE_SPLIT_GEMM4_MIN_C", 256);
-    if (!on || mode != MODE_GEMM) return 0;
+    const bool tap_gather = a.KH * a.KW > 1 && cin == a.Cin;        // 3x3 stride 2: the tap kernel's product form, not this one
+    if (!on || mode != MODE_GEMM || tap_gather) return 0;
     if (cin < min_c) return (cin >= min_c4 && a.Cout % 128 == 0) ? 3 : 0;       // 3: 4 waves, 256 x 128 tile, two workgroups per CU
     return a.Cout % 256 == 0 ? 1 : a.Cout % 128 == 0 ? 2 : 0;
 }
 
 bool pp_conv_split_eligible(const ConvArgs& a) {
-    const bool res1_plain = !a.res1 || (a.res1_shift == 0 && a.res1_off_w == 0 && a.res1_H == a.Hout && a.res1_W == a.Wout);
+    // res1: the output's own shape, or a coarser map read with >> shift (FPN's lat[i-1] += up(lat[i]), fused as a shifted read)
+    const bool res1_plain = !a.res1 || (a.res1_off_w == 0 && a.res1_shift >= 0 && a.res1_shift <= 4 &&
+                                        ((a.Hout - 1) >> a.res1_shift) < a.res1_H && ((a.Wout - 1) >> a.res1_shift) < a.res1_W &&
+                                        (a.res1_shift > 0 || (a.res1_H == a.Hout && a.res1_W == a.Wout)));
     int taps, cin, mode;
     // 1x1 layers with Cout % 128 == 0: the 8-wave product kernel.  Others: the tap kernel's one-tap form wins from ~1024 input
     // channels only (its 256 x 64 tile re-reads X Cout / 64 times; below, the fp32 kernel's smaller tiles do as well or better).
     static const int gemm_min_cin = env_int("POSEPIPE_SPLIT_GEMM_MIN_CIN", 1024);
     if (!split_shape(a, &taps, &cin, &mode)) return false;
-    if (mode == MODE_GEMM && cin < gemm_min_cin && !gemm8_cfg(a, mode, cin)) return false;
+    if (mode == MODE_GEMM && taps == 1 && cin < gemm_min_cin && !gemm8_cfg(a, mode, cin)) return false;
     return cin % 16 == 0 && a.Cout % 4 == 0 && a.up_log2 == 0 && !a.out_nchw && res1_plain && a.relu <= PP_ACT_SWISH &&
            (a.y_stride == 0 || a.y_stride == a.Cout) && a.y_coff == 0;
 }
@@ -892,7 +933,15 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     s.xp_w = full ? 1 : a.Win + a.x_pad;
     s.stride = a.stride;
     s.y_pad = a.y_pad; s.r1_pad = a.r1_pad; s.r2_pad = a.r2_pad; s.relu = a.relu;
+    s.r1_shift = a.res1 ? a.res1_shift : 0;
+    s.r1_H = a.res1 ? a.res1_H : a.Hout;
+    s.r1_W = a.res1 ? a.res1_W : a.Wout;
     s.nchunks = cin / 16;
+    s.ktaps = 1; s.KW = a.KW; s.pad = a.pad_h; s.Hin = a.Hin; s.Win = a.Win;
+    if (mode == MODE_GEMM && taps > 1) {     // tap-gather product: a step per (chunk, tap), weights in the same [chunk][tap] order
+        s.ktaps = taps;
+        s.nchunks = (cin / 16) * taps;
+    }
     s.x_bytes = a.x_bytes;
     s.xcd_remap = a.xcd_remap;
     if (const int g8 = gemm8_cfg(a, mode, cin)) {

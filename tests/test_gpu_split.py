@@ -447,3 +447,63 @@ def test_split_roi_align_separable_form(ctx, lib):
     print(f"separable RoIAlign: {len(pick)} RoIs, max deviation {worst / scale:.2e} of the feature range")
     # RoIs past n_rois are zero rows
     assert not det.net_b.read("roi_in", det.MAX_ROIS)[len(props):].any() or len(props) == det.MAX_ROIS
+
+
+# n, h, w, cin, cout: 3x3 stride 2 (HRNet transition / fuse layers, ResNet's strided blocks) -- the product form with one step per
+# (channel chunk, tap): odd and even maps (last row / column taps leave the image on the far side, too), 1..32 chunks,
+# Cout with one and two channel blocks per workgroup, ragged last tile
+CASES_S2 = [(2, 24, 18, 48, 96), (1, 23, 35, 16, 48), (3, 12, 10, 192, 384), (1, 40, 68, 512, 512), (2, 17, 17, 96, 32), (1, 96, 72, 48, 48)]
+
+
+@pytest.mark.parametrize("case", CASES_S2)
+def test_split_3x3_stride_2(ctx, lib, case):
+    n, h, w, cin, cout = case
+    rng = np.random.default_rng(sum(case) + 7)
+    x = (rng.standard_normal((n, h, w, cin)) * np.exp(2 * rng.standard_normal((n, h, w, cin)))).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = rng.standard_normal(cout).astype(np.float32)
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    r = rng.standard_normal((n, ho, wo, cout)).astype(np.float32)
+    for relu, res in ((0, None), (L.PP_RELU_LAST, r)):
+        check_layer(lib, ctx, x, wt, b, 1, stride=2, res=res, relu=relu)
+
+
+def test_split_stride_2_inside_a_program(ctx, lib):
+    """a strided 3x3 layer that READS a zero-halo buffer (its producer is a 3x3 stride-1 layer) and one with two residuals, as
+    HRNet's fuse layers chain them: same result as the float32 MFMA kernels to 1e-5, and the split kernel is what ran"""
+    rng = np.random.default_rng(23)
+    c = 48
+    pb = ProgramBuilder()
+    x = pb.buf(24, 36, c, name="input")
+    w = [(rng.standard_normal((co, ci, 3, 3)) / np.sqrt(9 * ci)).astype(np.float32) for co, ci in ((c, c), (96, c), (96, 96))]
+    b = [rng.standard_normal(co).astype(np.float32) for co in (c, 96, 96)]
+    y1 = pb.conv(x, w[0], b[0], pad=1, relu=L.PP_RELU_LAST)
+    y2 = pb.conv(y1, w[1], b[1], pad=1, stride=2, relu=L.PP_RELU_LAST)
+    y3 = pb.conv(y2, w[2], b[2], pad=1, relu=L.PP_RELU_LAST)
+    out = pb.buf(12, 18, 96, name="output")
+    pb.conv(y1, w[1], b[1], pad=1, stride=2, relu=L.PP_RELU_LAST, res1=y2, res2=y3, out=out)
+    prog = pb.build()
+    xin = rng.standard_normal((5, 24, 36, c)).astype(np.float32)
+
+    def run():
+        net = Net(ctx, prog, max_batch=5)
+        kinds = net.conv_kinds()
+        return net.forward(xin), kinds
+    (exact, k_e), (split, k_s) = both(lib, run)
+    assert (k_e == 1).all() and (k_s == 2).all()
+    assert not np.array_equal(exact, split) and np.abs(split - exact).max() <= 1e-5 * np.abs(exact).max()
+
+
+def test_split_1x1_with_shifted_residual(ctx, lib):
+    """FPN's lateral convs: 1x1 + (top-down map read at (y >> 1, x >> 1)) -- on the product kernels (256 -> 256: the 4-wave form,
+    512 / 1024 -> 256: the 8-wave form) the coarse residual is read with the shift in the epilogue, odd fine maps included"""
+    rng = np.random.default_rng(61)
+    for cin, h, w in ((256, 40, 68), (512, 21, 35), (1024, 10, 17)):
+        x = rng.standard_normal((3, h, w, cin)).astype(np.float32)
+        wt = (rng.standard_normal((256, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)
+        b = rng.standard_normal(256).astype(np.float32)
+        r = rng.standard_normal((3, (h + 1) // 2, (w + 1) // 2, 256)).astype(np.float32)
+        exact, split = both(lib, lambda: hip_conv_op(ctx, x, wt, b, res1=r, res1_shift=1))
+        from tests.helpers import ref_conv_op
+        assert np.array_equal(exact, ref_conv_op(x, wt, b, res1=r, res1_shift=1))
+        assert not np.array_equal(exact, split) and np.abs(split - exact).max() <= 1e-5 * np.abs(exact).max(), cin
