@@ -93,99 +93,188 @@ def broadcast_blob_fn(dist, device, backend="nccl", src=0, log=None):
     return blob_fn
 
 
+class _Gather:
+    """One in-flight all_gather of a fixed-size float32 slab per rank: ONE collective on one flat tensor that lives on
+    `device` (RCCL: device memory, no per-rank tensor list, one D2H copy when the result is read; gloo: host memory).
+    start() returns immediately (async_op), result() waits and returns [world][rows][cols] as numpy."""
+
+    def __init__(self, dist, device, local: np.ndarray):
+        import torch
+        self.world = dist.get_world_size()
+        self.shape = local.shape
+        t = torch.from_numpy(np.ascontiguousarray(local, np.float32)).to(device, non_blocking=True).reshape(-1)
+        self.out = torch.empty(self.world * t.numel(), dtype=torch.float32, device=device)
+        self.src = t                       # kept alive until the collective has finished
+        fn = getattr(dist, "all_gather_into_tensor", None)
+        if fn is not None:
+            self.work = fn(self.out, t, async_op=True)
+        else:                              # stand-in dist objects of the tests / world size 1
+            outs = [self.out[r * t.numel():(r + 1) * t.numel()] for r in range(self.world)]
+            self.work = dist.all_gather(outs, t)
+
+    def result(self) -> np.ndarray:
+        if self.work is not None and hasattr(self.work, "wait"):
+            self.work.wait()
+        return self.out.cpu().numpy().reshape((self.world,) + tuple(self.shape))
+
+
 def all_gather_ragged(local: np.ndarray, counts, dist, device="cpu") -> np.ndarray:
     """all_gather of per-rank arrays whose leading dim differs (counts[r] rows on rank r): pad to the max,
     one collective, trim.  Returns the concatenation in rank order."""
-    import torch
-    world = dist.get_world_size()
     m = max(max(counts), 1)
-    pad = np.zeros((m,) + local.shape[1:], dtype=local.dtype)
+    pad = np.zeros((m,) + local.shape[1:], dtype=np.float32)
     pad[: local.shape[0]] = local
-    t = _to_tensor(pad, device)
-    outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t)
-    return np.concatenate([o.cpu().numpy()[: counts[r]] for r, o in enumerate(outs)], axis=0)
+    got = _Gather(dist, device, pad).result()
+    return np.concatenate([got[r][: counts[r]] for r in range(len(counts))], axis=0)
 
 
 def process_video_sharded(dist, n_frames, chunks_fn, detect_fn, associate_fn, topdown_fn, lift_fn, src_hw, device="cpu",
                           num_joints=17, pad=121, max_persons=1, keep_tracks=None, timings=None):
-    """Run the cascade on frames [0, n_frames) sharded over the ranks of `dist`.
+    """Run the cascade on frames [0, n_frames) sharded over the ranks of `dist` (rank r owns the contiguous frames
+    [b_r, b_{r+1})).
 
-    chunks_fn(lo, hi)              -> this rank's frames as a list of (first_frame, n, handle) chunks covering [lo, hi)
+    chunks_fn(lo, hi)              -> this rank's frames as an ITERABLE of (first_frame, n, handle) chunks covering [lo, hi) in
+                                      order.  It is called twice -- once for the detection pass, once for the 2D pass -- and
+                                      may be lazy (a generator over a FrameStreamer): then only the chunk being processed
+                                      (and the one being uploaded) is resident.  Resident shards return the same handles twice.
     detect_fn(handle, first, n)    -> list (per frame) of [m][5] float32 (x1, y1, x2, y2, score), m <= 100
     associate_fn(dets_all_frames)  -> per frame, tracker rows (track_id, x1, y1, x2, y2, score[, tlwh]); sequential
     topdown_fn(handle, n, idx, boxes) -> [len(idx)][K][3] key points of the person-frames (chunk-local frame idx, tlwh)
     lift_fn(kn)                    -> (m, J, 3) 3D joints of a normalised 2D context (m, K, 2)
     timings: optional dict that receives per-phase wall seconds of this rank.
+
+    Both device passes advance in per-chunk ROUNDS: in round k every rank processes its k-th chunk and starts an asynchronous
+    all_gather of that round's fixed-size result slab, which travels while chunk k + 1 computes; only the last round's
+    collective is exposed.  Tracking is sequential in time over the WHOLE clip, so the association (host, microseconds per
+    frame, identical on every rank) runs between the two passes.
     Returns on every rank: dict(tracks = per-frame rows, keypoints / keypoints_3d = {track_id: (first_frame, array)})."""
     import time
     rank, world = dist.get_rank(), dist.get_world_size()
     b = shard_bounds(n_frames, world)
     lo, hi = b[rank], b[rank + 1]
-    counts = [b[r + 1] - b[r] for r in range(world)]
     t0 = time.perf_counter()
-    chunks = chunks_fn(lo, hi)
-    assert sum(c[1] for c in chunks) == hi - lo and (not chunks or chunks[0][0] == lo)
-    # 1-2. detect locally, exchange fixed-size slabs
-    slab = np.zeros((hi - lo, MAX_DET, 5), np.float32)
-    cnt = np.zeros((hi - lo, 1), np.float32)
-    for first, n, handle in chunks:
-        for i, d in enumerate(detect_fn(handle, first, n)):
-            d = np.asarray(d, np.float32).reshape(-1, 5)[:MAX_DET]
-            slab[first - lo + i, : len(d)] = d
-            cnt[first - lo + i, 0] = len(d)
-    t1 = time.perf_counter()
-    packed = np.concatenate([slab.reshape(hi - lo, -1), cnt], axis=1)
-    allp = all_gather_ragged(packed, counts, dist, device)
-    all_dets = [allp[i, :-1].reshape(MAX_DET, 5)[: int(allp[i, -1])] for i in range(n_frames)]
+    # ---- pass 1: detect chunk by chunk; each round's slab [chunk frames][100 x 5 + count + frame + more] is gathered asynchronously --
+    width = MAX_DET * 5 + 3
+    it = iter(chunks_fn(lo, hi))
+    cur = next(it, None)
+    assert cur is None or cur[0] == lo
+    # slab height = the longest first chunk (later chunks are not longer); the only blocking collective of the pass
+    rows = int(_Gather(dist, device, np.array([[cur[1] if cur else 0]], np.float32)).result().max())
+    all_dets = [None] * n_frames
+    round_of = np.full(n_frames, -1, np.int64)                 # which round brought frame f (every rank learns every rank's chunking)
+    t_det = 0.0
+    covered = lo
+
+    def absorb(g, k):
+        """slab of round k from every rank -> detections per frame; returns whether any rank has a further chunk"""
+        more = False
+        for r_slab in g.result():
+            more |= bool(r_slab[0, -1] > 0)
+            for row in r_slab:
+                f = int(row[-2])
+                if f >= 0:
+                    all_dets[f] = row[: int(row[-3]) * 5].reshape(-1, 5).copy()
+                    round_of[f] = k
+        return more
+
+    prev, k = None, 0
+    while True:
+        slab = np.full((max(rows, 1), width), -1.0, np.float32)
+        slab[:, -1] = 0.0
+        if cur is not None:
+            first, n, handle = cur
+            assert first == covered and n <= rows, (first, covered, n, rows)
+            ta = time.perf_counter()
+            dets = detect_fn(handle, first, n)
+            t_det += time.perf_counter() - ta
+            for i, d in enumerate(dets):
+                d = np.asarray(d, np.float32).reshape(-1, 5)[:MAX_DET]
+                slab[i, : len(d) * 5] = d.reshape(-1)
+                slab[i, -3] = len(d)
+                slab[i, -2] = first + i
+            covered = first + n
+            cur = next(it, None)
+            slab[0, -1] = 1.0 if cur is not None else 0.0      # "this rank has a further chunk"
+        g = _Gather(dist, device, slab)                        # round k travels while round k + 1 is detected
+        if prev is not None:
+            absorb(*prev)
+        prev = (g, k)
+        k += 1
+        if cur is None:
+            # nothing left locally: the round just issued tells whether another rank still has chunks (then this rank keeps
+            # taking part in the collectives with empty slabs)
+            if not absorb(*prev):
+                prev = None
+                break
+            prev = None
+    rounds = k
+    assert covered == hi and all(d is not None for d in all_dets), (covered, hi)
+    t1 = t0 + t_det
     t2 = time.perf_counter()
-    # 3. identical sequential association + person-box decisions on every rank
+    # ---- identical sequential association + person-box decisions on every rank ----------------------------------------------------
     tracks = associate_fn(all_dets)
     t3 = time.perf_counter()
     t_2d = [0.0, 0.0]
 
-    def chunk_of(frame):
-        for first, n, handle in chunks:
-            if first <= frame < first + n:
-                return first, n, handle
-        raise IndexError(frame)
-
     def sharded_topdown(jobs):
-        # 4. 2D on the own shard's person-frames (chunk by chunk), then everybody gets every row
+        # ---- pass 2: 2D on the own shard's person-frames, chunk by chunk; every round's rows are gathered asynchronously ---------
         ta = time.perf_counter()
-        owner = np.searchsorted(np.asarray(b[1:]), [j[1] for j in jobs], side="right")
-        mine = [i for i, r in enumerate(owner) if r == rank]
-        rows = np.zeros((len(mine), num_joints, 3), np.float32)
-        by_chunk: dict = {}
-        for k, i in enumerate(mine):
-            by_chunk.setdefault(chunk_of(jobs[i][1])[0], []).append(k)
-        for first, n, handle in chunks:
-            ks = by_chunk.get(first)
-            if not ks:
-                continue
-            idx = np.array([jobs[mine[k]][1] - first for k in ks], np.int32)
-            boxes = np.array([jobs[mine[k]][2] for k in ks], np.float64)
-            rows[ks] = np.asarray(topdown_fn(handle, n, idx, boxes), np.float32)
-        tb = time.perf_counter()
-        per_rank = [int((owner == r).sum()) for r in range(world)]
-        got = all_gather_ragged(rows, per_rank, dist, device)
+        t_wait = 0.0
+        job_frames = np.array([j[1] for j in jobs], np.int64)
+        owner = np.searchsorted(np.asarray(b[1:]), job_frames, side="right")
+        # slab height: the most person-frames any (rank, round) computes -- known everywhere: every rank knows every job and,
+        # from pass 1, which round brought which frame
+        cap = 1
+        for r in range(world):
+            sel = owner == r
+            if sel.any():
+                cap = max(cap, int(np.bincount(round_of[job_frames[sel]], minlength=rounds).max()))
         out = [None] * len(jobs)
-        pos = np.concatenate([[0], np.cumsum(per_rank)])
-        seen = [0] * world
-        for i, r in enumerate(owner):
-            out[i] = got[pos[r] + seen[r]]
-            seen[r] += 1
-        t_2d[0] += tb - ta
-        t_2d[1] += time.perf_counter() - tb
+
+        def absorb2(g):
+            for r_slab in g.result():
+                for row in r_slab:
+                    i = int(row[-1])
+                    if i >= 0:
+                        out[i] = row[:-1].reshape(num_joints, 3).copy()
+
+        it2 = iter(chunks_fn(lo, hi))
+        prev2 = None
+        for k in range(rounds):
+            slab = np.full((cap, num_joints * 3 + 1), -1.0, np.float32)
+            ks = np.flatnonzero((owner == rank) & (round_of[job_frames] == k))
+            if len(ks):
+                first, n, handle = next(it2)
+                while first + n <= job_frames[ks].min():       # chunks without a person-frame are skipped, never uploaded twice
+                    first, n, handle = next(it2)
+                assert ((job_frames[ks] >= first) & (job_frames[ks] < first + n)).all()
+                idx = (job_frames[ks] - first).astype(np.int32)
+                boxes = np.array([jobs[i][2] for i in ks], np.float64)
+                rows_k = np.asarray(topdown_fn(handle, n, idx, boxes), np.float32).reshape(len(ks), -1)
+                slab[: len(ks), :-1] = rows_k
+                slab[: len(ks), -1] = ks
+            g = _Gather(dist, device, slab)                    # round k travels while round k + 1 computes
+            if prev2 is not None:
+                tw = time.perf_counter()
+                absorb2(prev2)
+                t_wait += time.perf_counter() - tw
+            prev2 = g
+        tw = time.perf_counter()
+        if prev2 is not None:
+            absorb2(prev2)
+        t_wait += time.perf_counter() - tw
+        assert all(o is not None for o in out)
+        t_2d[0] += time.perf_counter() - ta - t_wait
+        t_2d[1] += t_wait
         return out
 
     ps = PersonStreams(num_joints, pad, src_hw, sharded_topdown, lift_fn, max_persons=max_persons, keep_tracks=keep_tracks)
     ps.ingest(tracks)
-    out = ps.advance(final=True)        # 5. lifting of every track, replicated
+    out = ps.advance(final=True)        # lifting of every track, replicated (0.03 GFLOP per frame)
     t4 = time.perf_counter()
     if timings is not None:
         timings.update(detect=t1 - t0, gather_dets=t2 - t1, associate=t3 - t2, topdown=t_2d[0], gather_2d=t_2d[1],
-                       lift=t4 - t3 - t_2d[0] - t_2d[1], total=t4 - t0)
+                       lift=t4 - t3 - t_2d[0] - t_2d[1], total=t4 - t0, rounds=rounds)
     return dict(tracks=tracks, keypoints=collect([out], "keypoints"), keypoints_3d=collect([out], "keypoints_3d"))
 
 

@@ -163,6 +163,59 @@ def test_sharded_video_equals_single_process():
             assert np.array_equal(g["ragged"], np.array([[0.0] * 3] * 2 + [[1.0] * 3] * 3))
 
 
+def _worker_rounds(rank, world, port, outdir):
+    """chunk size 6 over shards of 18 / 19 frames: 3 rounds on rank 0, 4 on rank 1 (rank 0 joins the last round with an empty
+    slab); chunks come from a LAZY generator -- nothing but the chunk in work exists -- which is consumed exactly twice"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        events, calls = [], []
+
+        def lazy_chunks(lo, hi):
+            calls.append((lo, hi))
+
+            def gen():
+                for f in range(lo, hi, 6):
+                    events.append(("upload", f))
+                    yield f, min(6, hi - f), np.arange(f, min(f + 6, hi))
+            return gen()
+
+        def detect(handle, first, n):
+            events.append(("detect", first))
+            return fake_detect(handle)
+
+        def rows(handle, n, idx, boxes):
+            events.append(("2d", int(handle[0])))
+            return fake_rows(handle[idx], boxes)
+        tm = {}
+        res = parallel.process_video_sharded(dist, N_FRAMES, lazy_chunks, detect, associate, rows, fake_lift, SRC, pad=PAD,
+                                             max_persons=3, timings=tm)
+        b = parallel.shard_bounds(N_FRAMES, world)
+        assert calls == [(b[rank], b[rank + 1])] * 2 and tm["rounds"] == 4
+        # a chunk is requested only after the previous one was processed (bounded residency): uploads and work alternate
+        det = [e for e in events if e[0] in ("upload", "detect")][: 2 * len(range(b[rank], b[rank + 1], 6))]
+        assert [e[0] for e in det[:2]] == ["upload", "detect"]
+        for i in range(1, len(det) - 1, 2):
+            assert det[i][0] == "detect" and det[i + 1][0] == "upload" and det[i + 1][1] == det[i][1] + 6
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), **_pack(res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_rounds_with_lazy_chunks_and_ragged_round_counts():
+    ref = _pack(run(LocalDist()))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_rounds, args=(2, port, d), nprocs=2, join=True)
+        for r in range(2):
+            g = np.load(os.path.join(d, f"r{r}.npz"))
+            assert sorted(g.files) == sorted(ref)
+            for k, v in ref.items():
+                assert np.array_equal(g[k], v), k
+
+
 def test_shard_bounds():
     assert parallel.shard_bounds(37, 2) == [0, 18, 37]
     assert parallel.shard_bounds(300, 8)[-1] == 300 and len(parallel.shard_bounds(300, 8)) == 9

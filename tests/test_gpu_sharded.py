@@ -111,3 +111,96 @@ def test_two_ranks_equal_single_process_cascade(ctx):
             for k, v in ref.items():
                 assert np.array_equal(g[k], v), (r, k)                                    # ids, 2D, 3D: bit for bit
             assert np.array_equal(g["own_det"], odet.detect(model, frames[b[r]][:, :, ::-1])), r
+
+
+# ---- the same at the bench's size and numerics: 1080p, HRNet-W48, DEFAULT (split) kernels, one chunk per rank -------------------
+H2, W2, N2, CHUNK2 = 1080, 1920, 8, 4
+
+
+def _clip_1080p():
+    from tests.test_gpu_detector import synth_frame
+    rng = np.random.default_rng(29)
+    frames = np.stack([synth_frame(rng, H2, W2) for _ in range(N2)])
+    gt = []
+    for t in range(N2):
+        rows = [[300 + 20.0 * t, 150, 480 + 20.0 * t, 700, 0.9], [1200 - 15.0 * t, 260, 1370 - 15.0 * t, 760, 0.8]]
+        if t == 4:
+            rows = rows[:1]                    # person 1 missed in the first frame of rank 1's shard: fills across the rank boundary
+        gt.append(np.array(rows, np.float32))
+    return frames, gt
+
+
+def _state_dicts_1080p(seed_shift):
+    from posepipeline_amd.models import faster_rcnn as fr, hrnet, synth
+    from posepipeline_amd.models import videopose3d as vp3d
+    spec = hrnet.hrnet_w48_384x288()
+    return (synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2 + seed_shift), spec,
+            synth.synth_state_dict(hrnet.hrnet_param_shapes(spec), seed=1 + seed_shift),
+            synth.synth_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3 + seed_shift))
+
+
+def _worker_1080p(rank, world, port, outdir):
+    os.environ["POSEPIPE_CONV_EXACT"] = "0"            # the library's default numerics in this process (read when nets are created)
+    import torch
+    import torch.distributed as dist
+    from posepipeline_amd import _lib, parallel
+    from posepipeline_amd.cascade import Cascade
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        frames, gt = _clip_1080p()
+        det_sd, spec, pose_sd, lift_sd = _state_dicts_1080p(0 if rank == 0 else 100)
+        ctx = _lib.Context(0)
+        with _lib.default_numerics("split"):
+            cas = Cascade(ctx, det_sd, pose_sd, lift_sd, H2, W2, chunk=CHUNK2, max_persons=3, pose_spec=spec,
+                          blob_fn=parallel.broadcast_blob_fn(dist, torch.device("cuda", 0), backend="gloo"))
+        assert cas.pose_net.numerics == "split" and cas.detector.net_a.numerics == "split"
+        b = parallel.shard_bounds(N2, world)
+        lo, hi = b[rank], b[rank + 1]
+        fb = H2 * W2 * 3
+        dptr = ctx.malloc(CHUNK2 * fb)                  # ONE chunk buffer: the shard is streamed through it, once per pass
+        uploads = []
+
+        def chunks_fn(lo_, hi_):
+            for f in range(lo_, hi_, CHUNK2):
+                n = min(CHUNK2, hi_ - f)
+                ctx.h2d(dptr, frames[f:f + n])
+                uploads.append(f)
+                yield f, n, dptr
+
+        tm = {}
+        res = parallel.process_video_sharded(dist, N2, chunks_fn, *parallel.cascade_stages(cas, lambda first, n: gt[first:first + n]),
+                                             src_hw=(H2, W2), max_persons=3, timings=tm)
+        assert uploads == [lo, lo] and tm["rounds"] == 1                                   # one chunk per rank, two passes
+        np.savez(os.path.join(outdir, f"r{rank}.npz"), **_pack(res["tracks"], res["keypoints"], res["keypoints_3d"]))
+        ctx.free(dptr)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_1080p_default_numerics(ctx):
+    """configs[3] as the bench shards it, in the numerics the bench times: 8 frames of 1080p, 2 ranks x 1 chunk of 4 frames,
+    HRNet-W48 384x288, split kernels; rank 1 starts from wrong weights and receives rank 0's.  Every rank's ids, 2D and 3D
+    equal the single-process streamed Cascade (created with the same numerics) bit for bit -- per-element results of the
+    split kernels do not depend on batch composition either."""
+    import torch.multiprocessing as mp
+    from posepipeline_amd import _lib
+    from posepipeline_amd.cascade import Cascade, collect
+    frames, gt = _clip_1080p()
+    det_sd, spec, pose_sd, lift_sd = _state_dicts_1080p(0)
+    with _lib.default_numerics("split"):
+        cas = Cascade(ctx, det_sd, pose_sd, lift_sd, H2, W2, chunk=CHUNK2, max_persons=3, pose_spec=spec)
+    outs = [cas.step(frames[i:i + CHUNK2], replay=gt[i:i + CHUNK2]) for i in range(0, N2, CHUNK2)] + [cas.flush()]
+    ref = _pack([fr for o in outs for fr in o["tracks"]], collect(outs, "keypoints"), collect(outs, "keypoints_3d"))
+    assert sum(k.startswith("k3_") and not k.endswith("first") for k in ref) >= 3           # the missed person returns under a new id
+    cas.close()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_1080p, args=(2, port, d), nprocs=2, join=True)
+        for r in range(2):
+            g = np.load(os.path.join(d, f"r{r}.npz"))
+            assert sorted(g.files) == sorted(ref)
+            for k, v in ref.items():
+                assert np.array_equal(g[k], v), (r, k)

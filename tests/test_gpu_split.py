@@ -452,11 +452,13 @@ def test_split_roi_align_separable_form(ctx, lib):
 # n, h, w, cin, cout: 3x3 stride 2 (HRNet transition / fuse layers, ResNet's strided blocks) -- the product form with one step per
 # (channel chunk, tap): odd and even maps (last row / column taps leave the image on the far side, too), 1..32 chunks,
 # Cout with one and two channel blocks per workgroup, ragged last tile
-CASES_S2 = [(2, 24, 18, 48, 96), (1, 23, 35, 16, 48), (3, 12, 10, 192, 384), (1, 40, 68, 512, 512), (2, 17, 17, 96, 32), (1, 96, 72, 48, 48)]
+CASES_S2 = [(2, 24, 18, 48, 96), (1, 23, 35, 16, 48), (3, 12, 10, 192, 384), (1, 40, 68, 512, 512), (2, 17, 17, 96, 32), (1, 96, 72, 48, 48),
+            (2, 21, 33, 128, 128), (1, 16, 16, 256, 64)]
 
 
 @pytest.mark.parametrize("case", CASES_S2)
-def test_split_3x3_stride_2(ctx, lib, case):
+def test_split_3x3_stride_2(ctx, lib, case, monkeypatch):
+    monkeypatch.setenv("POSEPIPE_SPLIT_S2_MIN_CIN", "16")       # (read once per process: set by the first of these cases)
     n, h, w, cin, cout = case
     rng = np.random.default_rng(sum(case) + 7)
     x = (rng.standard_normal((n, h, w, cin)) * np.exp(2 * rng.standard_normal((n, h, w, cin)))).astype(np.float32)
@@ -490,7 +492,7 @@ def test_split_stride_2_inside_a_program(ctx, lib):
         kinds = net.conv_kinds()
         return net.forward(xin), kinds
     (exact, k_e), (split, k_s) = both(lib, run)
-    assert (k_e == 1).all() and (k_s == 2).all()
+    assert (k_e == 1).all() and (k_s[[0, 2]] == 2).all()          # (the strided layers themselves: split from 128 input channels only)
     assert not np.array_equal(exact, split) and np.abs(split - exact).max() <= 1e-5 * np.abs(exact).max()
 
 
