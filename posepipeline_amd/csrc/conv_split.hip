@@ -860,9 +860,11 @@ static bool split_shape(const ConvArgs& a, int* taps, int* cin, int* mode) {
     // 128 / 256 / 512-channel strided 3x3 122 -> 132, 132 -> 139, 135 -> 140 TFLOP/s, HRNet 192 -> 384 98 -> 104; with 48 / 96 input
     // channels or ONE channel block per workgroup (Cout 96) it LOSES to the fp32 kernels (48 -> 96: 95 -> 58), so: from 128 input
     // channels, two channel blocks.  (What these layers want is the patch form with a strided patch: 4x the LDS per tile.)
-    static const int s2_on = env_int("POSEPIPE_SPLIT_S2", 1), s2_min_cin = env_int("POSEPIPE_SPLIT_S2_MIN_CIN", 128);
-    const bool k3s2 = s2_on && a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad_h == 1 && a.pad_w == 1 && a.dil_h == 1 && a.dil_w == 1 && !full &&
-                      a.Cin >= s2_min_cin && (((a.Cout + 31) / 32) & 1) == 0;
+    static const int s2_on = env_int("POSEPIPE_SPLIT_S2", 1);
+    // POSEPIPE_SPLIT_S2_MIN_CIN (read per call): tests set it to run the form on every shape it supports, whatever the launcher would pick
+    const char* s2_env = getenv("POSEPIPE_SPLIT_S2_MIN_CIN");
+    const bool s2_pick = s2_env ? a.Cin >= atoi(s2_env) : (a.Cin >= 128 && (((a.Cout + 31) / 32) & 1) == 0);
+    const bool k3s2 = s2_on && a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad_h == 1 && a.pad_w == 1 && a.dil_h == 1 && a.dil_w == 1 && !full && s2_pick;
     if (!(k3 || k1 || full || k3s2)) return false;
     *taps = (k3 || k3s2) ? 9 : 1;
     *cin = full ? a.K : a.Cin;

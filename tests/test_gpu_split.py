@@ -458,7 +458,7 @@ CASES_S2 = [(2, 24, 18, 48, 96), (1, 23, 35, 16, 48), (3, 12, 10, 192, 384), (1,
 
 @pytest.mark.parametrize("case", CASES_S2)
 def test_split_3x3_stride_2(ctx, lib, case, monkeypatch):
-    monkeypatch.setenv("POSEPIPE_SPLIT_S2_MIN_CIN", "16")       # (read once per process: set by the first of these cases)
+    monkeypatch.setenv("POSEPIPE_SPLIT_S2_MIN_CIN", "16")       # the form's correctness also where the launcher would not pick it
     n, h, w, cin, cout = case
     rng = np.random.default_rng(sum(case) + 7)
     x = (rng.standard_normal((n, h, w, cin)) * np.exp(2 * rng.standard_normal((n, h, w, cin)))).astype(np.float32)
