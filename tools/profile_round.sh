@@ -25,8 +25,8 @@ python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write ${NS% *} "cascade chunk 64
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write ${NS#* } "cascade chunk 64, 1 person (--profile-serial)" conv_p3_kernel > $O/pmc_summary_fp32.txt 2>&1
 python tools/pmc_traffic_update.py cascade_chunk64_persons1 $O/pmc_summary.txt "tools/profile_round.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over python bench.py --profile-serial --steps 2 --warmup 1 (FETCH_SIZE x2, gfx950); all conv_split_* launches" $O/pmc_traffic.json
 bash tools/pmc_sq.sh > $O/pmc_sq.log 2>&1; cp gpurun_out/pmc_sq/summary.txt $O/cascade_pmc_sq.txt
-bash tools/pmc_kernel.sh roi_align_kernel roi python bench.py --steps 1 --warmup 1 --cpu-frames 0 > $O/roi_pmc.log 2>&1; cp gpurun_out/pmc_roi/summary.txt $O/roi_pmc.txt
-for w in "w48 64" "det 32" "w32 128"; do set -- $w; python tools/profile_net.py $1 $2 > $O/per_op_$1_b$2.txt 2>&1; POSEPIPE_CONV_EXACT=1 python tools/profile_net.py $1 $2 > $O/per_op_$1_b$2_exact.txt 2>&1; done
+bash tools/pmc_kernel.sh roi_align_sep_kernel roi python bench.py --profile-serial --steps 1 --warmup 1 > $O/roi_pmc.log 2>&1; cp gpurun_out/pmc_roi/summary.txt $O/roi_pmc.txt
+for w in "w48 128" "det 64" "w32 128"; do set -- $w; python tools/profile_net.py $1 $2 > $O/per_op_$1_b$2.txt 2>&1; POSEPIPE_CONV_EXACT=1 python tools/profile_net.py $1 $2 > $O/per_op_$1_b$2_exact.txt 2>&1; done
 python tools/split_check.py > $O/conv_split_accuracy.txt 2>&1
 python -m pytest tests/test_gpu_split.py -q -s -k reordering 2>&1 | grep "heat-maps\|joints\|passed\|failed" > $O/conv_split_control.txt
 # keep only the small files
