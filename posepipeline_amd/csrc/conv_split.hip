@@ -159,10 +159,18 @@ enum { MODE_TILE = 0, MODE_STREAM = 1, MODE_GEMM = 2 };
 // wave and tap), one barrier per tap.  Why: with per-wave fragment loads straight from global memory (NW = 4) every wave of a
 // workgroup pulls the same 6 KB per tap through the texture-address path; an ablation build without those loads runs the
 // 256 -> 256 layer at 307 instead of 228 TFLOP/s (profiles/r02_conv_split_ablation.txt), i.e. they are the largest single loss.
-template <int T, int NSLOT, int COB, int PXB = 2, int NW = 4>
+//
+// RING4 (round 3; NW = 4, 3x3 tile / stream forms): the layers with too few chunks or tiles for the 8-wave form (all of HRNet) get
+// the weights through the LDS ring, too, while keeping TWO workgroups per CU -- what made the 8-wave form lose there was one
+// workgroup per CU sitting at its per-tap barrier with nothing else to run.  LDS per workgroup: the patch becomes SINGLE-buffered
+// (33 - 40 KB: chunk c + 1 waits in registers, as before, and is written during the last tap of chunk c, after the barrier that
+// closed tap 7 has seen every fragment read of the old patch complete) + the 4-slot ring (12 / 24 KB) = <= 73 KB, two per CU.
+// Every wave copies ceil(COB * 3 / 4) fragments per tap (duplicates where 4 does not divide: the counts must be wave-uniform).
+template <int T, int NSLOT, int COB, int PXB = 2, int NW = 4, bool RING4 = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(SplitArgs a) {
     constexpr int NT = 64 * NW;
-    constexpr bool WLDS = NW == 8;
+    constexpr bool WLDS = NW == 8 || RING4;
+    static_assert(!RING4 || (NW == 4 && T == 9), "RING4 is the 4-wave 3x3 form");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -367,17 +375,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         // s + 3 is issued into the slot step s - 1 used, and before the closing barrier the DMA of step s + 2 is awaited -- by
         // counting: vmcnt is in issue order, so "all but the DMA of s + 3 and the patch loads issued after it" have landed.
         constexpr int WSLOT = COB * 3 * 1024;
-        const unsigned wring = (unsigned)(2 * buf_bytes);
+        constexpr int NDMA = (COB * 3 + NW - 1) / NW;  // 1 KB fragments each wave copies per step (8 waves: 1; 4 waves: 2 / 1 for COB 2 / 1)
+        const unsigned wring = (unsigned)((RING4 ? 1 : 2) * buf_bytes);
         const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-        const int myslab = wave % (COB * 3);           // one 1 KB fragment per wave and step (waves past COB * 3 copy a duplicate)
-        const uint4* wsrc = a.w + (size_t)cb0 * 192 + myslab * 64 + lane;
         const int nsteps = a.nchunks * T;
         auto issue_w = [&](int step) {
             if (step >= nsteps) return;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + wring + (unsigned)((step & 3) * WSLOT + myslab * 1024));
-            const uint4* g = wsrc + (size_t)step * wstep;
-            // raw instruction, see conv_split_gemm_kernel: the builtin makes the compiler order every later ds_read behind vmcnt(0)
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory", "m0");
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i) {
+                const int myslab = (wave + NW * i) % (COB * 3);      // (waves past COB * 3 copy a duplicate: same bytes, same place)
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + wring + (unsigned)((step & 3) * WSLOT + myslab * 1024));
+                const uint4* g = a.w + (size_t)cb0 * 192 + myslab * 64 + lane + (size_t)step * wstep;
+                // raw instruction, see conv_split_gemm_kernel: the builtin makes the compiler order every later ds_read behind vmcnt(0)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory", "m0");
+            }
         };
         auto read_w = [&](int step, uint4 (&dst)[COB][3]) {
             const unsigned char* base = smem + wring + (step & 3) * WSLOT + lane * 16;
@@ -386,14 +397,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl) dst[cb][pl] = *reinterpret_cast<const uint4*>(base + (cb * 3 + pl) * 1024);
         };
-        // allow `n` (0, 1, NSLOT, NSLOT + 1) of the youngest vector-memory operations to stay in flight
+        // allow `n` (0, NDMA, NSLOT, NSLOT + NDMA) of the youngest vector-memory operations to stay in flight
         auto wait_all_but = [&](int n) {
-            // (no lgkmcnt: a wave's patch writes and fragment reads are complete long before the barriers that matter for them --
-            // the patch of chunk c + 1 is written four taps before its first read, a ring slot is reused two barriers after its
-            // last read was consumed)
-            if (n == NSLOT + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSLOT + 1) : "memory");
+            // (8-wave form, no lgkmcnt: a wave's patch writes and fragment reads are complete long before the barriers that matter
+            // for them -- the patch of chunk c + 1 is written four taps before its first read, a ring slot is reused two barriers
+            // after its last read was consumed.  RING4 reuses its single patch buffer at once and waits for lgkmcnt where it must.)
+            if (n == NSLOT + NDMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSLOT + NDMA) : "memory");
             else if (n == NSLOT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSLOT) : "memory");
-            else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else if (n == NDMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
         issue_w(0);
@@ -436,7 +447,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
                 // closing barrier of the step: the DMA of step st + 2 has landed (younger: the DMA of st + 3 if there is one, and at
                 // the first tap of a chunk the patch loads issued at its start); LDS writes of store_patch are complete
                 {
-                    const int younger = (st + 3 < nsteps ? 1 : 0) + ((t == 0 && c + 1 < a.nchunks) ? NSLOT : 0);
+                    const int younger = (st + 3 < nsteps ? NDMA : 0) + ((t == 0 && c + 1 < a.nchunks) ? NSLOT : 0);
                     wait_all_but(younger);
                     __builtin_amdgcn_s_barrier();
                 }
@@ -447,12 +458,66 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
             }
             if (c + 2 < a.nchunks) load_patch(c + 2);
         };
+        // RING4: ONE patch buffer.  Chunk c + 1 sits in registers from the end of chunk c - 1 and is written during tap T - 1 of chunk c.
+        auto chunk4 = [&](auto par, int c) {
+            constexpr int PAR = decltype(par)::value;
+            const int st0 = c * T;
+            const bool more_patch = c + 1 < a.nchunks;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int cur = (PAR + t) & 1;
+                const int st = st0 + t;
+                if (st + 1 < nsteps) read_w(st + 1, wf[cur ^ 1]);
+                if (t != T - 1) issue_w(st + 3);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pb = 0; pb < PXB; ++pb) {
+                    if (pb == 0 && t == T - 1) {
+                        // every wave's fragment reads of this chunk's patch completed before the barrier that closed tap T - 2:
+                        // overwrite it with chunk c + 1 (the compiler's wait for those loads must not cover a younger DMA, hence
+                        // the DMA of this step after it), then request chunk c + 2
+                        if (more_patch) store_patch(0, 0, NSLOT);
+                        issue_w(st + 3);
+                        if (c + 2 < a.nchunks) load_patch(c + 2);
+                    }
+                    mma(wf[cur], pb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t + 1 < T) load_x(smem, t + 1, pb);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                {
+                    // closing barrier: the DMA of step st + 2 has landed.  Younger: the DMA(s) of st + 3, and the patch loads of the
+                    // next-but-one chunk where they were issued after it -- in tap T - 1 (this step) and, seen from tap 0, in the
+                    // step before
+                    const int younger = (st + 3 < nsteps ? NDMA : 0) +
+                                        (((t == T - 1 && c + 2 < a.nchunks) || (t == 0 && c + 1 < a.nchunks)) ? NSLOT : 0);
+                    wait_all_but(younger);
+                    // t == T - 2: the reads of the last tap's fragments (issued above) must be complete before anyone overwrites the
+                    // patch; t == T - 1: the patch writes must be complete before anyone reads the new patch
+                    if (t >= T - 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            if (more_patch) {
+#pragma unroll
+                for (int pb = 0; pb < PXB; ++pb) load_x(smem, 0, pb);
+            }
+        };
+        if constexpr (RING4) {
+            int c4 = 0;
+            for (; c4 + 1 < a.nchunks; c4 += 2) {
+                chunk4(std::integral_constant<int, 0>{}, c4);
+                chunk4(std::integral_constant<int, 1>{}, c4 + 1);
+            }
+            if (c4 < a.nchunks) chunk4(std::integral_constant<int, 0>{}, c4);
+        } else {
         int c8 = 0;
         for (; c8 + 1 < a.nchunks; c8 += 2) {
             chunk8(std::integral_constant<int, 0>{}, c8);
             chunk8(std::integral_constant<int, 1>{}, c8 + 1);
         }
         if (c8 < a.nchunks) chunk8(std::integral_constant<int, 0>{}, c8);
+        }   // !RING4
     } else {
     // One 16-channel chunk: T steps.  Weights of step s + 1 are requested (global -> the other register set) before the MFMAs of
     // step s; a pixel block's fragments of step s + 1 are read from LDS into the SAME registers as soon as its MFMAs of step s
@@ -1023,32 +1088,40 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     }
     const int nslot = (s.NP + 16 * nw - 1) / (16 * nw);     // exactly: only the last patch slot of a thread can be partly outside
     const dim3 grid(gx, (unsigned)(s.ncb / cob));
-    const size_t lds = (size_t)2 * 3 * 2 * s.NPp * 16 + (nw == 8 ? (size_t)4 * cob * 3072 : 0);
-#define PP_SPLIT_LAUNCH(T_, NS_, NW_)                                                                                   \
+    // 4 waves, 3x3: weights through the LDS ring with a single-buffered patch (RING4), two workgroups per CU
+    static const int ring4_env = env_int("POSEPIPE_SPLIT_RING4", 1);
+    const bool ring4 = ring4_env && nw == 4 && mode != MODE_GEMM && (size_t)3 * 2 * s.NPp * 16 + (size_t)4 * cob * 3072 <= 80 * 1024;
+    const size_t lds = (size_t)(ring4 ? 1 : 2) * 3 * 2 * s.NPp * 16 + ((nw == 8 || ring4) ? (size_t)4 * cob * 3072 : 0);
+#define PP_SPLIT_LAUNCH(T_, NS_, NW_, R4_)                                                                              \
     do {                                                                                                                \
         static std::once_flag once;                                                                                     \
         std::call_once(once, [] {     /* > 64 KB of dynamic LDS has to be allowed per kernel */                         \
-            (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 2, 2, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (NW_ == 8 ? 160 : 100) * 1024); \
-            (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 1, 2, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (NW_ == 8 ? 160 : 100) * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 2, 2, NW_, R4_>, hipFuncAttributeMaxDynamicSharedMemorySize, (NW_ == 8 ? 160 : 100) * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 1, 2, NW_, R4_>, hipFuncAttributeMaxDynamicSharedMemorySize, (NW_ == 8 ? 160 : 100) * 1024); \
         });                                                                                                             \
         if (cob == 2)                                                                                                   \
-            hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 2, 2, NW_>), grid, dim3(64 * NW_), lds, stream, s);          \
+            hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 2, 2, NW_, R4_>), grid, dim3(64 * NW_), lds, stream, s);     \
         else                                                                                                            \
-            hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 1, 2, NW_>), grid, dim3(64 * NW_), lds, stream, s);          \
+            hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 1, 2, NW_, R4_>), grid, dim3(64 * NW_), lds, stream, s);     \
     } while (0)
     if (mode == MODE_GEMM)
-        PP_SPLIT_LAUNCH(1, 4, 4);
+        PP_SPLIT_LAUNCH(1, 4, 4, false);
     else if (nw == 8) {
-        if (nslot <= 5) PP_SPLIT_LAUNCH(9, 5, 8);
-        else PP_SPLIT_LAUNCH(9, 6, 8);
+        if (nslot <= 5) PP_SPLIT_LAUNCH(9, 5, 8, false);
+        else PP_SPLIT_LAUNCH(9, 6, 8, false);
+    } else if (ring4) {
+        if (nslot <= 5) PP_SPLIT_LAUNCH(9, 5, 4, true);
+        else if (nslot == 6) PP_SPLIT_LAUNCH(9, 6, 4, true);
+        else if (nslot == 7) PP_SPLIT_LAUNCH(9, 7, 4, true);
+        else PP_SPLIT_LAUNCH(9, 8, 4, true);
     } else if (nslot <= 5)
-        PP_SPLIT_LAUNCH(9, 5, 4);
+        PP_SPLIT_LAUNCH(9, 5, 4, false);
     else if (nslot == 6)
-        PP_SPLIT_LAUNCH(9, 6, 4);
+        PP_SPLIT_LAUNCH(9, 6, 4, false);
     else if (nslot == 7)
-        PP_SPLIT_LAUNCH(9, 7, 4);
+        PP_SPLIT_LAUNCH(9, 7, 4, false);
     else
-        PP_SPLIT_LAUNCH(9, 8, 4);
+        PP_SPLIT_LAUNCH(9, 8, 4, false);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         pp_set_error("conv_split launch failed: %s", hipGetErrorString(e));

@@ -3,8 +3,8 @@
 conv_split_kernel's 8-wave form and conv_split_gemm_kernel issue `global_load_lds_dwordx4` as raw instructions the compiler cannot
 see and order their LDS traffic by COUNTED `s_waitcnt vmcnt(n)` and by barriers placed by hand (csrc/conv_split.hip).  A
 miscounted wait or a missing barrier does not fail deterministically: it shows as an occasional wrong tile when the memory
-system is busy.  So every such form -- 8-wave tile and stream forms, COB 1 and 2, even and odd chunk counts,
-conv_split_gemm_kernel<2,4> / <4,2> / <2,2> -- is launched 50 times inside layer programs that run on 4 HIP streams (the forms
+system is busy.  So every such form -- 8-wave tile and stream forms, the 4-wave ring form (RING4), COB 1 and 2, even and odd chunk
+counts, conv_split_gemm_kernel<2,4> / <4,2> / <2,2> -- is launched 50 times inside layer programs that run on 4 HIP streams (the forms
 overlap each other), WHILE a second context on another thread runs the detector on 1080p frames -- the configuration of
 bench.py's timed region (Cascade's detector look-ahead).  Every repetition must reproduce the first one bit for bit, and the first
 one must agree with the float32 MFMA kernels.
@@ -106,7 +106,9 @@ class _Background:
 
 
 # tap cases: >= 512 workgroups and >= 16 channel chunks select the 8-wave form; 88 x 88 maps do not tile evenly -> stream form on halo buffers
-CASES = [("tap", 256, 96, 12), ("tap", 272, 88, 16), ("gemm", 512, 80, 8), ("gemm", 528, 72, 10), ("gemm", 256, 80, 8), ("gemm", 272, 72, 9)]
+# 48 / 96 input channels: too few chunks for the 8-wave form -> the 4-wave ring form (RING4: single-buffered patch, weights through
+# the LDS ring, two workgroups per CU), tile form on 64 x 64 maps, stream form on 44 x 44
+CASES = [("tap", 256, 96, 12), ("tap", 272, 88, 16), ("tap", 48, 64, 12), ("tap", 96, 44, 24), ("gemm", 512, 80, 8), ("gemm", 528, 72, 10), ("gemm", 256, 80, 8), ("gemm", 272, 72, 9)]
 
 
 @pytest.mark.parametrize("kind,cin,hw,batch", CASES)
