@@ -69,7 +69,22 @@ struct SplitArgs {
     long long S;                          // STREAM: positions of the padded input stream, GEMM: output pixels
     unsigned x_bytes;
     int xcd_remap;
+    int gx, gy;                           // conv_split_gemm_kernel with xcd_remap: logical grid (pixel tiles, channel columns)
 };
+
+// Workgroup id -> (tile, channel column) of a 1-D launch of 8 * ceil(ntiles / 8) * ncol ids.  Consecutive ids go round-robin over
+// the 8 XCDs (each with its own L2).  XCD x owns a CONTIGUOUS run of tiles (neighbouring tiles share their halo rows in its L2)
+// and walks it tile by tile, all channel columns of a tile one after the other: the columns read the same input tile, which
+// then comes from HBM once instead of once per column (256 -> 1024 at 40x68 has 8 columns, 512 -> 2048 16).  false: idle id.
+__device__ __forceinline__ bool xcd_tile_column(unsigned L, unsigned ntiles, unsigned ncol, unsigned& tile, unsigned& col) {
+    const unsigned xcd = L & 7u, j = L >> 3;
+    const unsigned tj = j / ncol;
+    col = j - tj * ncol;
+    const unsigned q = ntiles >> 3, r = ntiles & 7u;
+    if (tj >= (xcd < r ? q + 1 : q)) return false;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + tj;
+    return true;
+}
 
 // Round-to-nearest-even split of four floats into the three bf16 planes (4 x 16 bit each): p0 = bf16(a), p1 = bf16(a - p0),
 // p2 = a - p0 - p1.  The residuals are exact float32 values (a - p0 has at most 16 significant bits, a - p0 - p1 at most 8), so
@@ -175,14 +190,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    unsigned L = blockIdx.x;
-    if (a.xcd_remap) {      // consecutive workgroup ids go round-robin over the 8 XCDs: give every XCD a contiguous run of tiles
-        const unsigned total = gridDim.x;
-        const unsigned xcd = L & 7u, j = L >> 3;
-        const unsigned q = total >> 3, r = total & 7u;
-        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    unsigned L = blockIdx.x, col = blockIdx.y;
+    if (a.xcd_remap) {      // 1-D launch, see xcd_tile_column
+        if (!xcd_tile_column(blockIdx.x, (unsigned)a.gx, (unsigned)a.gy, L, col)) return;
     }
-    const int cb0 = blockIdx.y * COB;
+    const int cb0 = (int)col * COB;
     const int plane_bytes = 2 * a.NPp * 16;           // [half][pixel] x 16 B
     const int buf_bytes = 3 * plane_bytes;
 
@@ -670,8 +682,12 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const long long m0 = (long long)blockIdx.x * BM;
-    const int cbB = blockIdx.y * (BN / 32);          // first channel block of the workgroup
+    unsigned bx = blockIdx.x, by = blockIdx.y;
+    if (a.xcd_remap) {      // 1-D launch, see xcd_tile_column
+        if (!xcd_tile_column(blockIdx.x, (unsigned)a.gx, (unsigned)a.gy, bx, by)) return;
+    }
+    const long long m0 = (long long)bx * BM;
+    const int cbB = by * (BN / 32);                  // first channel block of the workgroup
     const int cb0 = cbB + wn * 2;                    // ... of this wave
 
     // ---- loaders -------------------------------------------------------------------------------------------------------------
@@ -1020,7 +1036,12 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         s.mode = MODE_GEMM;
         s.S = (long long)a.M;
         const int BM = g8 == 2 ? 512 : 256, BN = g8 == 1 ? 256 : 128;
-        const dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)(a.Cout / BN));
+        dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)(a.Cout / BN));
+        s.gx = (int)grid.x; s.gy = (int)grid.y;
+        static const int gemm_remap = env_int("POSEPIPE_SPLIT_GEMM_REMAP", 1);
+        s.xcd_remap = gemm_remap && s.gy > 1;
+        if (s.xcd_remap) grid = dim3((unsigned)((s.gx + 7) / 8 * 8 * s.gy), 1);
+        else s.xcd_remap = 0;
         const size_t lds = (size_t)2 * (3 * 2 * (BM + 4) * 16 + BN * 6 * 16);
         static std::once_flag once;
         std::call_once(once, [] {
@@ -1087,7 +1108,9 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         nw = 4;
     }
     const int nslot = (s.NP + 16 * nw - 1) / (16 * nw);     // exactly: only the last patch slot of a thread can be partly outside
-    const dim3 grid(gx, (unsigned)(s.ncb / cob));
+    dim3 grid(gx, (unsigned)(s.ncb / cob));
+    s.gx = (int)grid.x; s.gy = (int)grid.y;
+    if (s.xcd_remap) grid = dim3((unsigned)((s.gx + 7) / 8 * 8 * s.gy), 1);
     // 4 waves, 3x3: weights through the LDS ring with a single-buffered patch (RING4), two workgroups per CU
     static const int ring4_env = env_int("POSEPIPE_SPLIT_RING4", 1);
     const bool ring4 = ring4_env && nw == 4 && mode != MODE_GEMM && (size_t)3 * 2 * s.NPp * 16 + (size_t)4 * cob * 3072 <= 80 * 1024;
