@@ -659,6 +659,299 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
             }
 }
 
+// ---- 3x3 layers with 33 .. 48 output channels (HRNet-W48's first branch: 27 % of the program) -----------------------------------
+// With 32-row MFMA tiles 48 output channels occupy 3/4 of two channel blocks: a quarter of the matrix work is padding.  This form
+// uses v_mfma_f32_16x16x32_bf16 (same rate, 16 x 16 outputs, K = 32): THREE channel blocks of 16 -- no padding -- and K = 32 made
+// of TWO TAPS x the chunk's 16 input channels, so the patch layout in LDS and its loader are unchanged: a lane's B fragment is
+// pixel (lane & 15) at k half ((lane >> 4) & 1) of tap A (lanes 0 - 31) or tap B (lanes 32 - 63) -- one ds_read_b128 per plane
+// at slot pixel + tap offset.  Nine taps make five pairs (the tenth half-step multiplies zero weights): per chunk and 64 pixels
+// 3 x 5 x 6 x 4 = 360 MFMAs of 8 passes instead of 2 x 9 x 6 x 2 = 216 of 16: -17 % matrix-pipe time.  A wave covers 64 pixels =
+// four 16-pixel sub-blocks (the halves of its two 32-pixel blocks, same lane -> pixel map), 12 accumulators of 4 registers; the
+// accumulator rows of a lane are 4 CONSECUTIVE channels of its pixel: the epilogue keeps its float4 stores.
+// Weights: [chunk][pair][16-channel block][plane][lane] x 16 B (split_weights48_kernel), read per wave one step ahead.
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int NSLOT>
+__global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
+    constexpr int NT = 256, NPAIR = 5, CB = 3, SB = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    unsigned L = blockIdx.x, col_unused = 0;
+    if (a.xcd_remap) {
+        if (!xcd_tile_column(blockIdx.x, (unsigned)a.gx, 1u, L, col_unused)) return;
+    }
+    const int plane_bytes = 2 * a.NPp * 16;
+    const int buf_bytes = 3 * plane_bytes;
+    int n = 0, x0 = 0, y0 = 0;
+    long long s0 = 0;
+    if (a.mode == MODE_TILE) {
+        const int tx = (int)(L % (unsigned)a.tiles_x);
+        const unsigned L2 = L / (unsigned)a.tiles_x;
+        const int ty = (int)(L2 % (unsigned)a.tiles_y);
+        n = (int)(L2 / (unsigned)a.tiles_y);
+        x0 = tx * a.TW;
+        y0 = ty * a.TH;
+    } else {
+        s0 = (long long)L * 256;
+    }
+    // ---- patch loader (as conv_split_kernel) ------------------------------------------------------------------------------------
+    unsigned goff[NSLOT];
+    const int woff0 = ((((tid & 3) >> 1) * a.NPp + (tid >> 2)) * 16 + (tid & 1) * 8);
+#pragma unroll
+    for (int j = 0; j < NSLOT; ++j) {
+        const int u = tid + NT * j;
+        const int p = u >> 2, quad = u & 3;
+        const bool in_patch = p < a.NP;
+        unsigned off = 0xffffffffu;
+        if (a.mode == MODE_TILE) {
+            const int pr = p / a.PWp, pc = p - pr * a.PWp;
+            const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
+            if (in_patch && pc < a.TW + 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                off = (unsigned)(((n * a.xp_h + iy) * a.xp_w + ix) * a.Cin) * 4u;
+        } else {
+            const long long pos = s0 - a.PWp - 1 + p;
+            if (in_patch && pos >= 0 && pos < a.S) off = (unsigned)pos * (unsigned)a.Cin * 4u;
+        }
+        goff[j] = off == 0xffffffffu ? off : off + (unsigned)quad * 16u;
+    }
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+    float4 xr[NSLOT];
+    auto load_patch = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const unsigned off = goff[j] == 0xffffffffu ? 0xffffffffu : goff[j] + (unsigned)c * 64u;
+            xr[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+        }
+    };
+    const bool last_ok = (tid >> 2) + (NT / 4) * (NSLOT - 1) < a.NP;
+    auto store_patch = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            uint2 p0, p1, p2;
+            split4(xr[j], p0, p1, p2);
+            if (j == NSLOT - 1 && !last_ok) continue;
+            unsigned char* d = smem + buf * buf_bytes + woff0 + (NT / 4) * 16 * j;
+            *reinterpret_cast<uint2*>(d) = p0;
+            *reinterpret_cast<uint2*>(d + plane_bytes) = p1;
+            *reinterpret_cast<uint2*>(d + 2 * plane_bytes) = p2;
+        }
+    };
+    // ---- operand addresses and output pixels: sub-block sb = 2 * (32-pixel block of the wave) + half ------------------------------
+    // (the output coordinates are recomputed in the epilogue: 16 registers less across the K loop)
+    const int khalf = (lane >> 4) & 1;
+    auto sub_block = [&](int sb, int& aof, int& on_, int& oy_, int& ox_, bool& ok) {
+        const int b = wave * 2 + (sb >> 1), r = (sb & 1) * 16 + (lane & 15);
+        if (a.mode == MODE_TILE) {
+            const int BW = 32 >> a.bw_log2, BH = 1 << a.bw_log2;
+            int by, bx;
+            block_pixel(r, a.bw_log2, by, bx);
+            const int gy = b >> a.gx_log2, gx = b & ((1 << a.gx_log2) - 1);
+            const int ry = gy * BH + by, rx = gx * BW + bx;
+            aof = ((khalf * a.NPp) + ry * a.PWp + rx) * 16;
+            on_ = n;
+            oy_ = y0 + ry;
+            ox_ = x0 + rx;
+            ok = oy_ < a.H && ox_ < a.W;
+        } else {
+            const int pl = b * 32 + r;
+            aof = ((khalf * a.NPp) + pl) * 16;
+            const long long sp = s0 + pl;
+            const bool in = sp < a.S;
+            const long long sc = in ? sp : 0;
+            const int per = a.xp_h * a.PWp, row = a.PWp;
+            on_ = (int)(sc / per);
+            const int rem = (int)(sc - (long long)on_ * per);
+            oy_ = rem / row;
+            ox_ = rem - oy_ * row;
+            ok = in && oy_ < a.H && ox_ < a.W;
+        }
+    };
+    int aofs[SB];            // LDS byte offset of this lane's pixel (tap (0,0), plane 0, its k half)
+#pragma unroll
+    for (int sb = 0; sb < SB; ++sb) {
+        int t0, t1, t2;
+        bool t3;
+        sub_block(sb, aofs[sb], t0, t1, t2, t3);
+    }
+    // tap offset of this lane per pair: lanes 0 - 31 read tap 2 * pair, lanes 32 - 63 tap 2 * pair + 1 (pair 4: tap 8 twice, the
+    // second against zero weights)
+    int tofs[NPAIR];
+#pragma unroll
+    for (int q = 0; q < NPAIR; ++q) {
+        const int t = min(2 * q + (lane >> 5), 8);
+        tofs[q] = ((t / 3) * a.PWp + (t % 3)) * 16;
+    }
+    // weights: fragment (step, block cb, plane) at ((step * 3 + cb) * 3 + plane) * 64 + lane, step = chunk * 5 + pair
+    const uint4* wp = a.w + lane;
+    constexpr size_t wstep = (size_t)CB * 3 * 64;
+    f32x4 acc[CB][SB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int sb = 0; sb < SB; ++sb) acc[cb][sb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 wf[2][CB][3];
+    uint4 xf[2][3];          // the B fragments of sub-block sb live in set sb & 1; the next sub-block's are read during this one's MFMAs
+    auto load_w = [&](uint4 (&dst)[CB][3]) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) dst[cb][pl] = wp[(cb * 3 + pl) * 64];
+        wp += wstep;
+    };
+    auto load_x = [&](const unsigned char* pbuf, int q, int sb) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) xf[sb & 1][pl] = *reinterpret_cast<const uint4*>(pbuf + pl * plane_bytes + aofs[sb] + tofs[q]);
+    };
+    auto mma = [&](const uint4 (&wc)[CB][3], int sb) {
+        constexpr int WI[6] = {2, 1, 0, 1, 0, 0}, XI[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb)
+                acc[cb][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wc[cb][WI[p]]),
+                                                                      __builtin_bit_cast(bf16x8, xf[sb & 1][XI[p]]), acc[cb][sb], 0, 0, 0);
+    };
+    // ---- prologue ---------------------------------------------------------------------------------------------------------------
+    load_patch(0);
+    load_w(wf[0]);
+    store_patch(0);
+    if (a.nchunks > 1) load_patch(1);
+    __syncthreads();
+    load_x(smem, 0, 0);
+    // ---- K loop: 5 pair-steps per 16-channel chunk (odd: the weight register sets swap roles from chunk to chunk) -------------------
+    auto chunk = [&](auto par, int c) {
+        constexpr int PAR = decltype(par)::value;
+        const unsigned char* pbuf = smem + (c & 1) * buf_bytes;
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) {
+            const int cur = (PAR + q) & 1;
+            load_w(wf[cur ^ 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                if (sb == SB - 1 && q == NPAIR / 2 && c + 1 < a.nchunks) store_patch((c + 1) & 1);
+                // the next sub-block's fragments (of this pair, or sub-block 0 of the next pair) are requested before this one's MFMAs
+                if (sb + 1 < SB) load_x(pbuf, q, sb + 1);
+                else if (q + 1 < NPAIR) load_x(pbuf, q + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(wf[cur], sb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __syncthreads();
+        if (c + 1 < a.nchunks) load_x(smem + ((c + 1) & 1) * buf_bytes, 0, 0);
+        if (c + 2 < a.nchunks) load_patch(c + 2);
+    };
+    int c = 0;
+    for (; c + 1 < a.nchunks; c += 2) {           // 5 steps per chunk: the register-set parity alternates per chunk
+        chunk(std::integral_constant<int, 0>{}, c);
+        chunk(std::integral_constant<int, 1>{}, c + 1);
+    }
+    if (c < a.nchunks) chunk(std::integral_constant<int, 0>{}, c);
+    // ---- epilogue: accumulator register i of a lane = channel 16 cb + 4 (lane >> 4) + i of pixel (lane & 15) -------------------------
+    bool cok[CB];
+    int cos[CB];
+    float4 b4[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int co = cb * 16 + 4 * (lane >> 4);
+        cok[cb] = co < a.Cout;
+        cos[cb] = cok[cb] ? co : 0;
+        b4[cb] = *reinterpret_cast<const float4*>(a.bias + cos[cb]);
+    }
+    size_t ypix[SB], r1pix[SB], r2pix[SB];
+    bool ook[SB];
+#pragma unroll
+    for (int sb = 0; sb < SB; ++sb) {
+        int aof_, on_, oy_, ox_;
+        sub_block(sb, aof_, on_, oy_, ox_, ook[sb]);
+        const int n_ = ook[sb] ? on_ : 0, y_ = ook[sb] ? oy_ : 0, x_ = ook[sb] ? ox_ : 0;
+        ypix[sb] = ((size_t)n_ * (a.H + a.y_pad) + y_) * (a.W + a.y_pad) + x_;
+        r1pix[sb] = ((size_t)n_ * (a.r1_H + a.r1_pad) + (y_ >> a.r1_shift)) * (a.r1_W + a.r1_pad) + (x_ >> a.r1_shift);
+        r2pix[sb] = ((size_t)n_ * (a.H + a.r2_pad) + y_) * (a.W + a.r2_pad) + x_;
+    }
+    float4 rv[SB][CB];
+    if (a.res1) {
+#pragma unroll
+        for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) rv[sb][cb] = *reinterpret_cast<const float4*>(a.res1 + r1pix[sb] * a.Cout + cos[cb]);
+    }
+#pragma unroll
+    for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const f32x4 cc = acc[cb][sb];
+            const float4 b = b4[cb];
+            float4 v = make_float4(cc[0] + b.x, cc[1] + b.y, cc[2] + b.z, cc[3] + b.w);
+            if (a.relu == PP_RELU_FIRST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            else if (a.relu >= PP_ACT_LEAKY) { v.x = split_activate(v.x, a.relu); v.y = split_activate(v.y, a.relu); v.z = split_activate(v.z, a.relu); v.w = split_activate(v.w, a.relu); }
+            if (a.res1) { v.x += rv[sb][cb].x; v.y += rv[sb][cb].y; v.z += rv[sb][cb].z; v.w += rv[sb][cb].w; }
+            rv[sb][cb] = v;
+        }
+    if (a.res2) {
+#pragma unroll
+        for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+            for (int cb = 0; cb < CB; ++cb) {
+                const float4 r = *reinterpret_cast<const float4*>(a.res2 + r2pix[sb] * a.Cout + cos[cb]);
+                rv[sb][cb].x += r.x; rv[sb][cb].y += r.y; rv[sb][cb].z += r.z; rv[sb][cb].w += r.w;
+            }
+    }
+#pragma unroll
+    for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            float4 v = rv[sb][cb];
+            if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            if (ook[sb] && cok[cb]) *reinterpret_cast<float4*>(a.y + ypix[sb] * a.Cout + cos[cb]) = v;
+        }
+}
+
+// split weights of the 48-channel form: [chunk][pair][16-channel block][plane][lane] x 16 B; lane = (k group g = lane >> 4: tap
+// 2 * pair + (g >> 1), channels 8 (g & 1) .. + 7 of the chunk; channel block row lane & 15); tap 9 (the odd half of pair 4) is zero
+__global__ __launch_bounds__(256) void split_weights48_kernel(const float* w, uint4* out, int Cin, int CoutPad, size_t total) {
+    const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;       // (chunk, pair, cb, lane)
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    size_t r = i >> 6;
+    const int cb = (int)(r % 3);
+    r /= 3;
+    const int pair = (int)(r % 5);
+    const int c = (int)(r / 5);
+    const int g = lane >> 4;
+    const int t = 2 * pair + (g >> 1);
+    const int cout = cb * 16 + (lane & 15);
+    unsigned short h[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int cin = c * 16 + (g & 1) * 8 + j;
+        const int k = t * Cin + cin;
+        float v = 0.f;
+        if (t < 9 && cout < CoutPad) v = w[((size_t)(k >> 5) * CoutPad + cout) * 32 + 8 * (k & 3) + ((k & 31) >> 2)];
+        const __bf16 q0 = (__bf16)v;
+        const float r1 = v - (float)q0;
+        const __bf16 q1 = (__bf16)r1;
+        const float r2 = r1 - (float)q1;
+        const __bf16 q2 = (__bf16)r2;
+        h[0][j] = __builtin_bit_cast(unsigned short, q0);
+        h[1][j] = __builtin_bit_cast(unsigned short, q1);
+        h[2][j] = __builtin_bit_cast(unsigned short, q2);
+    }
+    const size_t frag = (i >> 6) * 3;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        uint4 o;
+        o.x = h[pl][0] | ((unsigned)h[pl][1] << 16);
+        o.y = h[pl][2] | ((unsigned)h[pl][3] << 16);
+        o.z = h[pl][4] | ((unsigned)h[pl][5] << 16);
+        o.w = h[pl][6] | ((unsigned)h[pl][7] << 16);
+        out[(frag + pl) * 64 + lane] = o;
+    }
+}
+
 // ---- 1x1 / full-cover layers with >= 128 output channels: 8 waves, 256 x 256 (or 512 x 128) output tile --------------------------
 // A product Y[M][N] = X[M][K] W[K][N] moves 4 / (2 BN) bytes of X and 6 / (2 BM) bytes of split W per float32 FLOP through the
 // vector memory path.  With the tap kernel's 256 x 64 tile that is 0.043 B/FLOP -- 10.7 TB/s at the 250 TFLOP/s the matrix pipes
@@ -985,9 +1278,17 @@ bool pp_conv_split_eligible(const ConvArgs& a) {
 
 static int split_ncb(const ConvArgs& a) { return (a.Cout + 31) / 32; }     // odd: one block per workgroup (COB = 1), else two
 
+// 3x3 stride 1 with 33 .. 48 output channels: conv_split48_kernel (three 16-channel blocks, K = two taps x 16 channels)
+static bool split_c48(const ConvArgs& a) {
+    static const int on = env_int("POSEPIPE_SPLIT_C48", 1);
+    int taps, cin, mode;
+    return on && a.Cout > 32 && a.Cout <= 48 && split_shape(a, &taps, &cin, &mode) && mode == MODE_TILE;
+}
+
 size_t pp_conv_split_bytes(const ConvArgs& a) {
     int taps = 1, cin = a.Cin, mode = 0;
     split_shape(a, &taps, &cin, &mode);
+    if (split_c48(a)) return ((size_t)(cin / 16) * 5 + 1) * 3 * 3 * 64 * sizeof(uint4);
     return ((size_t)(cin / 16) * taps + 1) * split_ncb(a) * 3 * 64 * sizeof(uint4);      // + one spare step: the kernel fetches one step ahead
 }
 
@@ -995,6 +1296,17 @@ int pp_conv_split_weights(const ConvArgs& a, void* out, hipStream_t stream) {
     int taps = 1, cin = a.Cin, mode = 0;
     split_shape(a, &taps, &cin, &mode);
     const int ncb = split_ncb(a);
+    if (split_c48(a)) {
+        const size_t total48 = (size_t)(cin / 16) * 5 * 3 * 64;
+        hipLaunchKernelGGL(split_weights48_kernel, dim3((unsigned)((total48 + 255) / 256)), dim3(256), 0, stream, a.w, (uint4*)out, cin,
+                           a.CoutPad, total48);
+        hipError_t e48 = hipGetLastError();
+        if (e48 != hipSuccess) {
+            pp_set_error("split_weights48 launch failed: %s", hipGetErrorString(e48));
+            return PP_ERR_HIP;
+        }
+        return PP_OK;
+    }
     const size_t total = (size_t)(cin / 16) * taps * ncb * 64;
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a.w, (uint4*)out, cin,
                        taps, a.CoutPad, ncb, total);
@@ -1066,7 +1378,8 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     static const int stream_env = env_int("POSEPIPE_SPLIT_STREAM", -1);
     static const int nw8_min_blocks = env_int("POSEPIPE_SPLIT_NW8_MIN_BLOCKS", 512), nw8_min_chunks = env_int("POSEPIPE_SPLIT_NW8_MIN_CHUNKS", 16);
     unsigned gx = 0;
-    int nw = 8;
+    const bool c48 = split_c48(a);
+    int nw = c48 ? 4 : 8;
     // geometry for the 8-wave form (512-pixel tiles, one workgroup per CU); if that gives fewer than ~2 workgroups per CU (or
     // the layer is a one-tap product), the 4-wave form (256-pixel tiles, two per CU)
     for (;;) {
@@ -1111,6 +1424,31 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     dim3 grid(gx, (unsigned)(s.ncb / cob));
     s.gx = (int)grid.x; s.gy = (int)grid.y;
     if (s.xcd_remap) grid = dim3((unsigned)((s.gx + 7) / 8 * 8 * s.gy), 1);
+    if (c48) {
+        // three 16-channel blocks on v_mfma_f32_16x16x32_bf16, one channel column
+        s.gy = 1;
+        if (s.xcd_remap) grid = dim3((unsigned)((s.gx + 7) / 8 * 8), 1);
+        else grid = dim3(gx, 1);
+        const size_t lds48 = (size_t)2 * 3 * 2 * s.NPp * 16;
+#define PP_SPLIT48_LAUNCH(NS_)                                                                                          \
+    do {                                                                                                                \
+        static std::once_flag once;                                                                                     \
+        std::call_once(once, [] {                                                                                       \
+            (void)hipFuncSetAttribute((const void*)conv_split48_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
+        });                                                                                                             \
+        hipLaunchKernelGGL((conv_split48_kernel<NS_>), grid, dim3(256), lds48, stream, s);                              \
+    } while (0)
+        if (nslot <= 5) PP_SPLIT48_LAUNCH(5);
+        else if (nslot == 6) PP_SPLIT48_LAUNCH(6);
+        else if (nslot == 7) PP_SPLIT48_LAUNCH(7);
+        else PP_SPLIT48_LAUNCH(8);
+        hipError_t e48 = hipGetLastError();
+        if (e48 != hipSuccess) {
+            pp_set_error("conv_split48 launch failed: %s", hipGetErrorString(e48));
+            return PP_ERR_HIP;
+        }
+        return PP_OK;
+    }
     // 4 waves, 3x3: weights through the LDS ring with a single-buffered patch (RING4), two workgroups per CU
     static const int ring4_env = env_int("POSEPIPE_SPLIT_RING4", 1);
     const bool ring4 = ring4_env && nw == 4 && mode != MODE_GEMM && (size_t)3 * 2 * s.NPp * 16 + (size_t)4 * cob * 3072 <= 80 * 1024;
