@@ -69,19 +69,31 @@ struct SplitArgs {
     long long S;                          // STREAM: positions of the padded input stream, GEMM: output pixels
     unsigned x_bytes;
     int xcd_remap;
-    int gx, gy;                           // conv_split_gemm_kernel with xcd_remap: logical grid (pixel tiles, channel columns)
+    int gx, gy;                           // xcd_remap: logical grid (pixel tiles, channel columns) of the 1-D launch
+    int col_major;                        // xcd_remap: an XCD walks its tiles column by column (small inputs) instead of tile by tile
 };
 
 // Workgroup id -> (tile, channel column) of a 1-D launch of 8 * ceil(ntiles / 8) * ncol ids.  Consecutive ids go round-robin over
 // the 8 XCDs (each with its own L2).  XCD x owns a CONTIGUOUS run of tiles (neighbouring tiles share their halo rows in its L2)
 // and walks it tile by tile, all channel columns of a tile one after the other: the columns read the same input tile, which
 // then comes from HBM once instead of once per column (256 -> 1024 at 40x68 has 8 columns, 512 -> 2048 16).  false: idle id.
-__device__ __forceinline__ bool xcd_tile_column(unsigned L, unsigned ntiles, unsigned ncol, unsigned& tile, unsigned& col) {
+// col_major != 0 (small maps: the whole input sits in the Infinity Cache anyway, and what an XCD's L2 should keep is ONE column's
+// split weights): the XCD walks its run once per column instead -- measured on HRNet's 192 -> 192 at 24x18: 187 vs 166 TFLOP/s.
+__device__ __forceinline__ bool xcd_tile_column(unsigned L, unsigned ntiles, unsigned ncol, unsigned& tile, unsigned& col, int col_major = 0) {
     const unsigned xcd = L & 7u, j = L >> 3;
-    const unsigned tj = j / ncol;
-    col = j - tj * ncol;
     const unsigned q = ntiles >> 3, r = ntiles & 7u;
-    if (tj >= (xcd < r ? q + 1 : q)) return false;
+    const unsigned run = xcd < r ? q + 1 : q;
+    unsigned tj;
+    if (col_major) {
+        if (run == 0) return false;
+        col = j / run;
+        tj = j - col * run;
+        if (col >= ncol) return false;
+    } else {
+        tj = j / ncol;
+        col = j - tj * ncol;
+        if (tj >= run) return false;
+    }
     tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + tj;
     return true;
 }
@@ -192,7 +204,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     const int wave = tid >> 6;
     unsigned L = blockIdx.x, col = blockIdx.y;
     if (a.xcd_remap) {      // 1-D launch, see xcd_tile_column
-        if (!xcd_tile_column(blockIdx.x, (unsigned)a.gx, (unsigned)a.gy, L, col)) return;
+        if (!xcd_tile_column(blockIdx.x, (unsigned)a.gx, (unsigned)a.gy, L, col, a.col_major)) return;
     }
     const int cb0 = (int)col * COB;
     const int plane_bytes = 2 * a.NPp * 16;           // [half][pixel] x 16 B
@@ -678,10 +690,11 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    unsigned L = blockIdx.x, col_unused = 0;
+    unsigned L = blockIdx.x, col = blockIdx.y;
     if (a.xcd_remap) {
-        if (!xcd_tile_column(blockIdx.x, (unsigned)a.gx, 1u, L, col_unused)) return;
+        if (!xcd_tile_column(blockIdx.x, (unsigned)a.gx, (unsigned)a.gy, L, col, a.col_major)) return;
     }
+    const int cbase = (int)col * CB;                  // first 16-channel block of this workgroup (a.ncb blocks in all)
     const int plane_bytes = 2 * a.NPp * 16;
     const int buf_bytes = 3 * plane_bytes;
     int n = 0, x0 = 0, y0 = 0;
@@ -783,9 +796,9 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
         const int t = min(2 * q + (lane >> 5), 8);
         tofs[q] = ((t / 3) * a.PWp + (t % 3)) * 16;
     }
-    // weights: fragment (step, block cb, plane) at ((step * 3 + cb) * 3 + plane) * 64 + lane, step = chunk * 5 + pair
-    const uint4* wp = a.w + lane;
-    constexpr size_t wstep = (size_t)CB * 3 * 64;
+    // weights: fragment (step, block cb, plane) at ((step * ncb + cb) * 3 + plane) * 64 + lane, step = chunk * 5 + pair
+    const uint4* wp = a.w + (size_t)cbase * 3 * 64 + lane;
+    const size_t wstep = (size_t)a.ncb * 3 * 64;
     f32x4 acc[CB][SB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
@@ -856,7 +869,7 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
     float4 b4[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
-        const int co = cb * 16 + 4 * (lane >> 4);
+        const int co = (cbase + cb) * 16 + 4 * (lane >> 4);
         cok[cb] = co < a.Cout;
         cos[cb] = cok[cb] ? co : 0;
         b4[cb] = *reinterpret_cast<const float4*>(a.bias + cos[cb]);
@@ -912,13 +925,13 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
 
 // split weights of the 48-channel form: [chunk][pair][16-channel block][plane][lane] x 16 B; lane = (k group g = lane >> 4: tap
 // 2 * pair + (g >> 1), channels 8 (g & 1) .. + 7 of the chunk; channel block row lane & 15); tap 9 (the odd half of pair 4) is zero
-__global__ __launch_bounds__(256) void split_weights48_kernel(const float* w, uint4* out, int Cin, int CoutPad, size_t total) {
+__global__ __launch_bounds__(256) void split_weights48_kernel(const float* w, uint4* out, int Cin, int CoutPad, int ncb16, size_t total) {
     const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;       // (chunk, pair, cb, lane)
     if (i >= total) return;
     const int lane = (int)(i & 63);
     size_t r = i >> 6;
-    const int cb = (int)(r % 3);
-    r /= 3;
+    const int cb = (int)(r % ncb16);
+    r /= ncb16;
     const int pair = (int)(r % 5);
     const int c = (int)(r / 5);
     const int g = lane >> 4;
@@ -1280,15 +1293,17 @@ static int split_ncb(const ConvArgs& a) { return (a.Cout + 31) / 32; }     // od
 
 // 3x3 stride 1 with 33 .. 48 output channels: conv_split48_kernel (three 16-channel blocks, K = two taps x 16 channels)
 static bool split_c48(const ConvArgs& a) {
-    static const int on = env_int("POSEPIPE_SPLIT_C48", 1);
+    static const int on = env_int("POSEPIPE_SPLIT_C48", 1), mult = env_int("POSEPIPE_SPLIT_C48_MULT", 0);
     int taps, cin, mode;
-    return on && a.Cout > 32 && a.Cout <= 48 && split_shape(a, &taps, &cin, &mode) && mode == MODE_TILE;
+    const bool shape = (a.Cout > 32 && a.Cout <= 48) || (mult == 1 && a.Cout % 48 == 0) || (mult == 2 && a.Cout == 192);
+    return on && shape && split_shape(a, &taps, &cin, &mode) && mode == MODE_TILE;
 }
+static int split_ncb16(const ConvArgs& a) { return (a.Cout + 47) / 48 * 3; }      // 16-channel blocks, whole columns of 3
 
 size_t pp_conv_split_bytes(const ConvArgs& a) {
     int taps = 1, cin = a.Cin, mode = 0;
     split_shape(a, &taps, &cin, &mode);
-    if (split_c48(a)) return ((size_t)(cin / 16) * 5 + 1) * 3 * 3 * 64 * sizeof(uint4);
+    if (split_c48(a)) return ((size_t)(cin / 16) * 5 + 1) * split_ncb16(a) * 3 * 64 * sizeof(uint4);
     return ((size_t)(cin / 16) * taps + 1) * split_ncb(a) * 3 * 64 * sizeof(uint4);      // + one spare step: the kernel fetches one step ahead
 }
 
@@ -1297,9 +1312,9 @@ int pp_conv_split_weights(const ConvArgs& a, void* out, hipStream_t stream) {
     split_shape(a, &taps, &cin, &mode);
     const int ncb = split_ncb(a);
     if (split_c48(a)) {
-        const size_t total48 = (size_t)(cin / 16) * 5 * 3 * 64;
+        const size_t total48 = (size_t)(cin / 16) * 5 * split_ncb16(a) * 64;
         hipLaunchKernelGGL(split_weights48_kernel, dim3((unsigned)((total48 + 255) / 256)), dim3(256), 0, stream, a.w, (uint4*)out, cin,
-                           a.CoutPad, total48);
+                           a.CoutPad, split_ncb16(a), total48);
         hipError_t e48 = hipGetLastError();
         if (e48 != hipSuccess) {
             pp_set_error("split_weights48 launch failed: %s", hipGetErrorString(e48));
@@ -1344,6 +1359,9 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     }
     s.x_bytes = a.x_bytes;
     s.xcd_remap = a.xcd_remap;
+    // inputs beyond the Infinity Cache (256 MB): the columns of a tile back to back; smaller ones: column by column
+    static const int colmaj_mb = env_int("POSEPIPE_SPLIT_COLMAJOR_MB", 256);
+    s.col_major = (size_t)a.x_bytes <= (size_t)colmaj_mb << 20;
     if (const int g8 = gemm8_cfg(a, mode, cin)) {
         s.mode = MODE_GEMM;
         s.S = (long long)a.M;
@@ -1425,10 +1443,11 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     s.gx = (int)grid.x; s.gy = (int)grid.y;
     if (s.xcd_remap) grid = dim3((unsigned)((s.gx + 7) / 8 * 8 * s.gy), 1);
     if (c48) {
-        // three 16-channel blocks on v_mfma_f32_16x16x32_bf16, one channel column
-        s.gy = 1;
-        if (s.xcd_remap) grid = dim3((unsigned)((s.gx + 7) / 8 * 8), 1);
-        else grid = dim3(gx, 1);
+        // three 16-channel blocks per workgroup on v_mfma_f32_16x16x32_bf16; Cout / 48 channel columns
+        s.ncb = split_ncb16(a);
+        s.gy = s.ncb / 3;
+        if (s.xcd_remap) grid = dim3((unsigned)((s.gx + 7) / 8 * 8 * s.gy), 1);
+        else grid = dim3(gx, (unsigned)s.gy);
         const size_t lds48 = (size_t)2 * 3 * 2 * s.NPp * 16;
 #define PP_SPLIT48_LAUNCH(NS_)                                                                                          \
     do {                                                                                                                \
