@@ -17,7 +17,7 @@ def main():
         txt = f.read()
     out = json.loads(txt[txt.index("{"):].splitlines()[0])
     roof = out["roofline"]
-    fams = {"conv_split": ("conv_split_kernel", "conv_split_gemm_kernel", "conv_split_s2_kernel", "conv_split_is_kernel"),
+    fams = {"conv_split": ("conv_split_kernel", "conv_split_gemm_kernel", "conv_split_s2_kernel", "conv_split48_kernel"),
             "fp32": ("conv_igemm_kernel", "conv_p3_kernel")}
     rows = list(csv.DictReader(open(stats, newline="")))
     tot = {}
