@@ -494,7 +494,7 @@ def run_cascade_sharded(args, D, ctx, cas):
     D.barrier(ctx)
     dt_own = time.perf_counter() - t0
     dt = D.max_time(dt_own)
-    per_rank = D.gather_obj({k: round(v * 1e3, 3) for k, v in tm.items()})
+    per_rank = D.gather_obj({k: (int(v) if k == "rounds" else round(v * 1e3, 3)) for k, v in tm.items()})
     if D.rank != 0:
         return
     flops_step = B * (cas.detector.flops_per_frame + 2 * P * cas.pose_net.prog.flops)
