@@ -513,3 +513,21 @@ def test_split_1x1_with_shifted_residual(ctx, lib):
         from tests.helpers import ref_conv_op
         assert np.array_equal(exact, ref_conv_op(x, wt, b, res1=r, res1_shift=1))
         assert not np.array_equal(exact, split) and np.abs(split - exact).max() <= 1e-5 * np.abs(exact).max(), cin
+
+
+def test_split_program_replays_from_a_hip_graph(ctx, lib):
+    """a program created with the split numerics captures into a hipGraph (no allocation, no synchronisation inside its launches:
+    the split weights were built at creation) and the replay reproduces the eager run bit for bit -- HRNet-W48 layers included
+    (tile / stream / ring forms, the 48-channel kernel, product kernels, one-pass fuse sums)"""
+    spec = hrnet.HRNetSpec(48, 17, 128, 96)
+    sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(spec), seed=1)
+    rng = np.random.default_rng(9)
+    x = np.zeros((6, 128, 96, 4), np.float32)
+    x[..., :3] = rng.standard_normal((6, 128, 96, 3))
+    net = Net(ctx, hrnet.build_hrnet_program(spec, sd), max_batch=6, numerics="split")
+    assert (net.conv_kinds() == 2).sum() > 100
+    eager = net.forward(x)
+    net.capture(6)
+    assert np.array_equal(net.forward(x), eager)
+    assert np.array_equal(net.forward(x), eager)
+    net.close()
