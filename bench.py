@@ -448,6 +448,20 @@ def run_cascade(args, D):
                                          "reader thread and uploaded on a copy stream while the previous chunks compute "
                                          "(posepipeline_amd/streaming.py); whole clip timed, first (unoverlapped) upload and "
                                          "final flush included" % n_seen}
+        # the same clip as an NV12 source (a decoder's native output, half the bytes): NV12 planes through the staging buffers and
+        # over PCIe, converted to BGR on the copy stream behind the transfer (csrc/nv12.hip)
+        from posepipeline_amd.video import Nv12Video, bgr_to_nv12
+        nv_clip = Nv12Video(np.concatenate([bgr_to_nv12(frames)] * n_chunks), frames.shape[1], frames.shape[2])
+        cas.reset()
+        streamer = FrameStreamer(ctx, nv_clip, B)
+        n_seen = 0
+        t1 = time.perf_counter()
+        for o in cas.run_video(nv_clip, replay_fn=lambda first, n: rb[:n], streamer=streamer):
+            n_seen += len(o["tracks"])
+            t_last = time.perf_counter()
+        out["pcie_inclusive"]["nv12_source"] = {"value": n_seen / (t_last - t1), "unit": "frames/s",
+                                                "note": "same clip delivered as NV12 planes (3.1 MB per frame instead of 6.2): "
+                                                        "pp_upload_begin_nv12 uploads them and converts on the copy stream"}
     if vit:
         out["roofline"]["vit_stage"] = {"backbone_ms": stage["pose_backbone"], "program_tflops": pose_flops / (stage["pose_backbone"] * 1e-3) / 1e12,
                                         "note": "ViTPose-H program (bf16 GEMMs + fp32 patch embedding / head); roofline line: --workload c5"}

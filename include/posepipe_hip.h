@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 7   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
+#define PP_ABI_VERSION 8   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
                               3: PP_OP_VIT_ENCODER / PP_OP_DEPTH_TO_SPACE, bf16 building blocks, UDP top-down (post 2)
                               4: pp_memcpy_d2d, pp_net_create_mem (weights already on the device, e.g. an RCCL broadcast)
                               5: pp_buf.pad (zero halo of conv-only buffers), PP_OP_AVGPOOL, pp_crop_resize_bilinear,
@@ -84,6 +84,18 @@ int pp_memcpy_d2d(pp_ctx* ctx, void* dst, const void* src, size_t bytes);
 int pp_host_alloc(pp_ctx* ctx, size_t bytes, void** host_ptr);
 int pp_host_free(pp_ctx* ctx, void* host_ptr);
 int pp_upload_begin(pp_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
+/* ABI 8 -- NV12 frame source (a decoder's native output: Y plane [h][w], then interleaved UV [h/2][w]; half the bytes of
+ * the BGR frames cv2.VideoCapture.read() hands the reference at pose_pipeline/pipeline.py:47-87, wrappers/mmtrack.py:38-45,
+ * wrappers/mmpose.py:55-75).  h even, w a multiple of 4.  The conversion is OpenCV's cvtColor(COLOR_YUV2BGR_NV12) bit for
+ * bit (ITU-R BT.601 limited range, 20-bit fixed point; oracle/nv12.py).
+ *   pp_upload_begin_nv12  pp_upload_begin for `frames` NV12 frames: host -> tmp_nv12_device on the copy stream, then the
+ *                         conversion into dst_bgr_device ([frames][h][w][3] u8) on the same stream; pp_upload_wait /
+ *                         pp_upload_release as for pp_upload_begin.  tmp_nv12_device: frames * h * w * 3 / 2 bytes, may be
+ *                         the same buffer for every call (the copy stream is in order).
+ *   pp_nv12_to_bgr        the conversion alone, device -> device on the ctx stream. */
+int pp_upload_begin_nv12(pp_ctx* ctx, void* dst_bgr_device, void* tmp_nv12_device, const void* src_nv12_host, int frames,
+                         int height, int width);
+int pp_nv12_to_bgr(pp_ctx* ctx, const uint8_t* nv12_device, int frames, int height, int width, uint8_t* bgr_device);
 int pp_upload_wait(pp_ctx* ctx, int host_sync);
 int pp_upload_release(pp_ctx* ctx);
 

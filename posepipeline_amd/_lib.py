@@ -93,6 +93,8 @@ SIGNATURES = {
     "pp_host_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "pp_host_free": (_i, [_vp, _vp]),
     "pp_upload_begin": (_i, [_vp, _vp, _vp, _sz]),
+    "pp_upload_begin_nv12": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i]),
+    "pp_nv12_to_bgr": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "pp_upload_wait": (_i, [_vp, _i]),
     "pp_upload_release": (_i, [_vp]),
     "pp_net_create": (_i, [_vp, C.POINTER(pp_op), _i, C.POINTER(pp_buf), _i, _vp, _sz, _i, C.POINTER(_vp)]),

@@ -160,6 +160,25 @@ int pp_upload_begin(pp_ctx* ctx, void* dst, const void* src, size_t bytes) {
     return PP_OK;
 }
 
+int pp_upload_begin_nv12(pp_ctx* ctx, void* dst_bgr, void* tmp_nv12, const void* src_host, int frames, int height, int width) {
+    PP_REQUIRE(ctx && (frames == 0 || (dst_bgr && tmp_nv12 && src_host)), "pp_upload_begin_nv12: NULL argument");
+    PP_REQUIRE(frames >= 0 && height > 0 && width > 0, "pp_upload_begin_nv12: bad shape");
+    PP_HIP_CHECK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_consumed, 0));
+    const size_t bytes = (size_t)frames * height * width * 3 / 2;
+    if (bytes) PP_HIP_CHECK(hipMemcpyAsync(tmp_nv12, src_host, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    // the conversion rides the copy stream: `ev_upload` then covers the BGR frames, and the (in-order) copy stream does not
+    // overwrite tmp_nv12 with the next chunk before this kernel has read it
+    const int r = pp_launch_nv12_to_bgr((const unsigned char*)tmp_nv12, (unsigned char*)dst_bgr, frames, height, width, ctx->copy_stream);
+    if (r != PP_OK) return r;
+    PP_HIP_CHECK(hipEventRecord(ctx->ev_upload, ctx->copy_stream));
+    return PP_OK;
+}
+
+int pp_nv12_to_bgr(pp_ctx* ctx, const uint8_t* nv12, int frames, int height, int width, uint8_t* bgr) {
+    PP_REQUIRE(ctx && (frames == 0 || (nv12 && bgr)), "pp_nv12_to_bgr: NULL argument");
+    return pp_launch_nv12_to_bgr(nv12, bgr, frames, height, width, ctx->stream);
+}
+
 int pp_upload_wait(pp_ctx* ctx, int host_sync) {
     PP_REQUIRE(ctx != nullptr, "pp_upload_wait: ctx is NULL");
     PP_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev_upload, 0));

@@ -136,6 +136,8 @@ int pp_deconv_bf16_create(const float* weights, const float* bias, int h, int w,
 void pp_deconv_bf16_destroy(pp_deconv_bf16* d);
 int pp_deconv_bf16_run(pp_deconv_bf16* d, const float* x, float* out, int batch, int relu, hipStream_t stream);
 int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream);
+// NV12 -> BGR u8 (nv12.hip)
+int pp_launch_nv12_to_bgr(const unsigned char* nv12, unsigned char* bgr, int frames, int h, int w, hipStream_t stream);
 // y = LayerNorm(x [+ pos[row % pos_mod]]) over the last dim; x_out (optional) receives x + pos in fp32
 int pp_launch_layernorm(const float* x, const float* pos, int pos_mod, float* x_out, const float* gamma,
                         const float* beta, int rows, int dim, float eps, void* y, int out_bf16, hipStream_t stream);

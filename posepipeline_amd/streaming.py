@@ -9,6 +9,10 @@ own blocking host->device copy.  Here a video is read ONCE, a chunk at a time:
   compute stream  runs the cascade on chunk k (pp_upload_wait orders it after its own upload)
 
 so the PCIe transfer (6.2 MB per 1080p frame) and the file read never sit on the critical path.
+
+NV12 sources (video.Nv12Video: a decoder's native output, 3.1 MB per 1080p frame) are staged and uploaded as NV12 and converted
+to the BGR frames the stages read by a kernel on the copy stream, right behind the transfer (pp_upload_begin_nv12): half the
+host copy and half the PCIe bytes, and no conversion on the host.
 """
 from __future__ import annotations
 
@@ -34,17 +38,21 @@ class FrameStreamer:
     def __init__(self, ctx: L.Context, video, chunk: int, max_frames: int | None = None):
         self.ctx, self.video, self.chunk = ctx, video, int(chunk)
         self.h, self.w = int(video.height), int(video.width)
-        self.frame_bytes = self.h * self.w * 3
+        self.frame_bytes = self.h * self.w * 3                      # of a BGR frame on the device
+        self.nv12 = getattr(video, "pixfmt", "bgr24") == "nv12"
+        self.src_shape = (self.h * 3 // 2, self.w) if self.nv12 else (self.h, self.w, 3)
+        self.src_bytes = int(np.prod(self.src_shape))                # of a frame as the source delivers it
         self.max_frames = max_frames
-        nbytes = self.chunk * self.frame_bytes
-        self.dev = [ctx.malloc(nbytes) for _ in range(self.N_DEV)]
+        self.dev = [ctx.malloc(self.chunk * self.frame_bytes) for _ in range(self.N_DEV)]
+        self.dev_nv12 = ctx.malloc(self.chunk * self.src_bytes) if self.nv12 else None     # one: the copy stream is in order
+        nbytes = self.chunk * self.src_bytes
         self.pin_ptr, self.pin = [], []
         for _ in range(self.N_PIN):
             p = C.c_void_p()
             L.check(ctx.lib.pp_host_alloc(ctx.handle, nbytes, C.byref(p)), "pp_host_alloc")
             self.pin_ptr.append(p)
             buf = (C.c_uint8 * nbytes).from_address(p.value)
-            self.pin.append(np.frombuffer(buf, np.uint8).reshape(self.chunk, self.h, self.w, 3))
+            self.pin.append(np.frombuffer(buf, np.uint8).reshape((self.chunk,) + self.src_shape))
         self.free_q: queue.Queue = queue.Queue()
         self.ready_q: queue.Queue = queue.Queue()
         for i in range(self.N_PIN):
@@ -81,8 +89,12 @@ class FrameStreamer:
 
     def _begin(self, item, d):
         i, n, first = item
-        L.check(self.ctx.lib.pp_upload_begin(self.ctx.handle, C.c_void_p(self.dev[d]), self.pin_ptr[i],
-                                             n * self.frame_bytes), "pp_upload_begin")
+        if self.nv12:
+            L.check(self.ctx.lib.pp_upload_begin_nv12(self.ctx.handle, C.c_void_p(self.dev[d]), C.c_void_p(self.dev_nv12),
+                                                      self.pin_ptr[i], n, self.h, self.w), "pp_upload_begin_nv12")
+        else:
+            L.check(self.ctx.lib.pp_upload_begin(self.ctx.handle, C.c_void_p(self.dev[d]), self.pin_ptr[i],
+                                                 n * self.frame_bytes), "pp_upload_begin")
         return (i, n, first, d)
 
     def _wait(self, flight):
@@ -131,6 +143,6 @@ class FrameStreamer:
             self.ctx.synchronize()
             for p in self.pin_ptr:
                 self.ctx.lib.pp_host_free(self.ctx.handle, p)
-            for dptr in self.dev:
+            for dptr in self.dev + ([self.dev_nv12] if self.dev_nv12 else []):
                 self.ctx.free(dptr)
         self.pin, self.pin_ptr, self.dev = [], [], []

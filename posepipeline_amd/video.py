@@ -4,8 +4,12 @@ The reference opens every video with `cv2.VideoCapture` (wrappers/mmtrack.py:32,
 and reads BGR frames one at a time.  OpenCV is used here when it is importable; the raw containers
 below exist because neither OpenCV nor ffmpeg is installed in the build / GPU images:
   *.npy    numpy array [N][H][W][3] uint8, BGR (what cv2 would have decoded)
-  *.ppvid  32-byte header (magic 'PPVID001', N, H, W, fps*1000 as little-endian int32) + raw BGR frames
-Every source yields frames in BGR order, like `cap.read()`.
+  *.ppvid  32-byte header (magic 'PPVID001', N, H, W, fps*1000 as little-endian int32) + raw BGR frames;
+           magic 'PPVID002' carries a pixel-format word after the four ints (0 = bgr24, 1 = nv12)
+  *_<W>x<H>.nv12 / .yuv   header-less NV12 frames (`ffmpeg -i in.mp4 -pix_fmt nv12 -f rawvideo out_1920x1080.nv12`), 30 fps
+BGR sources yield frames in BGR order, like `cap.read()`.  NV12 sources (a decoder's native output: Y plane [H][W], then
+interleaved UV [H/2][W]; half the bytes) hand their raw planes to streaming.FrameStreamer, which uploads them as they are and
+converts on the device (csrc/nv12.hip, OpenCV's COLOR_YUV2BGR_NV12 arithmetic) -- there is no host conversion path.
 """
 from __future__ import annotations
 
@@ -15,6 +19,8 @@ import struct
 import numpy as np
 
 MAGIC = b"PPVID001"
+MAGIC2 = b"PPVID002"
+PIXFMT = {"bgr24": 0, "nv12": 1}
 
 
 class ArrayVideo:
@@ -53,6 +59,53 @@ class ArrayVideo:
         self.frames = None
 
 
+class Nv12Video:
+    """raw NV12 frames [N][H * 3 / 2][W] u8; `pixfmt` tells FrameStreamer to upload the planes and convert on the device"""
+    pixfmt = "nv12"
+
+    def __init__(self, planes: np.ndarray, height: int, width: int, fps: float = 30.0):
+        assert planes.dtype == np.uint8 and planes.ndim == 3 and planes.shape[1:] == (height * 3 // 2, width)
+        if height % 2 or width % 4:
+            raise ValueError(f"NV12 source {width}x{height}: height must be even and width a multiple of 4")
+        self.planes, self.height, self.width, self.fps = planes, int(height), int(width), float(fps)
+        self.pos = 0
+
+    @property
+    def num_frames(self):
+        return int(self.planes.shape[0])
+
+    def read(self):
+        raise RuntimeError("NV12 source: frames are converted on the device (streaming.FrameStreamer / pp_upload_begin_nv12); "
+                           "there is no host-side cap.read()")
+
+    def read_batch(self, n):
+        """up to n consecutive frames as raw NV12 planes [k][H * 3 / 2][W]"""
+        a = self.planes[self.pos:self.pos + n]
+        self.pos += int(a.shape[0])
+        return a
+
+    def release(self):
+        pass
+
+
+def bgr_to_nv12(frames: np.ndarray) -> np.ndarray:
+    """[N][H][W][3] u8 BGR -> [N][H * 3 / 2][W] u8 NV12, ITU-R BT.601 limited range (the encoder side: only used to WRITE
+    test / synthetic containers; chroma is the rounded mean of each 2 x 2 block)"""
+    f = np.ascontiguousarray(frames, np.uint8).astype(np.int32)
+    n, h, w, _ = f.shape
+    assert h % 2 == 0 and w % 4 == 0
+    b, g, r = f[..., 0], f[..., 1], f[..., 2]
+    y = ((66 * r + 129 * g + 25 * b + 128) >> 8) + 16
+    blk = f.reshape(n, h // 2, 2, w // 2, 2, 3).sum(axis=(2, 4))
+    bb, gg, rr = (blk[..., 0] + 2) >> 2, (blk[..., 1] + 2) >> 2, (blk[..., 2] + 2) >> 2
+    u = ((-38 * rr - 74 * gg + 112 * bb + 128) >> 8) + 128
+    v = ((112 * rr - 94 * gg - 18 * bb + 128) >> 8) + 128
+    out = np.empty((n, h * 3 // 2, w), np.uint8)
+    out[:, :h] = np.clip(y, 0, 255)
+    out[:, h:] = np.clip(np.stack([u, v], axis=-1), 0, 255).reshape(n, h // 2, w)
+    return out
+
+
 class _Cv2Video:  # pragma: no cover - OpenCV is not installed in the build image
     def __init__(self, path):
         import cv2
@@ -81,13 +134,18 @@ class _Cv2Video:  # pragma: no cover - OpenCV is not installed in the build imag
         self.cap.release()
 
 
-def write_ppvid(path, frames: np.ndarray, fps: float = 30.0):
+def write_ppvid(path, frames: np.ndarray, fps: float = 30.0, pixfmt: str = "bgr24"):
+    """frames: [N][H][W][3] BGR.  pixfmt "nv12" stores them as NV12 planes (PPVID002)."""
     frames = np.ascontiguousarray(frames, np.uint8)
     n, h, w, c = frames.shape
     assert c == 3
     with open(path, "wb") as f:
-        f.write(MAGIC + struct.pack("<iiii", n, h, w, int(round(fps * 1000))) + b"\0" * 8)
-        f.write(frames.tobytes())
+        if pixfmt == "bgr24":
+            f.write(MAGIC + struct.pack("<iiii", n, h, w, int(round(fps * 1000))) + b"\0" * 8)
+            f.write(frames.tobytes())
+        else:
+            f.write(MAGIC2 + struct.pack("<iiiii", n, h, w, int(round(fps * 1000)), PIXFMT[pixfmt]) + b"\0" * 4)
+            f.write(bgr_to_nv12(frames).tobytes())
 
 
 _ROBUST: dict = {}      # validated path -> path to read (itself, or its ffmpeg transcode)
@@ -103,7 +161,7 @@ def robust_path(path, run=None):
     `run`: subprocess.run stand-in (tests)."""
     import subprocess
     import tempfile
-    if isinstance(path, np.ndarray) or os.path.splitext(path)[1].lower() in (".npy", ".ppvid"):
+    if isinstance(path, np.ndarray) or os.path.splitext(path)[1].lower() in (".npy", ".ppvid", ".nv12", ".yuv"):
         return path
     st = os.stat(path)
     key = (os.path.abspath(path), st.st_size, st.st_mtime_ns)
@@ -167,16 +225,27 @@ def open_video(path):
     if ext == ".ppvid":
         with open(path, "rb") as f:
             head = f.read(32)
-        if head[:8] != MAGIC:
-            raise ValueError(f"{path}: not a PPVID001 file")
+        if head[:8] not in (MAGIC, MAGIC2):
+            raise ValueError(f"{path}: not a PPVID001 / PPVID002 file")
         n, h, w, fps1000 = struct.unpack("<iiii", head[8:24])
+        if head[:8] == MAGIC2 and struct.unpack("<i", head[24:28])[0] == PIXFMT["nv12"]:
+            n = max(min(n, (os.path.getsize(path) - 32) // max(h * w * 3 // 2, 1)), 0)
+            return Nv12Video(np.memmap(path, dtype=np.uint8, mode="r", offset=32, shape=(n, h * 3 // 2, w)), h, w, fps1000 / 1000.0)
         have = (os.path.getsize(path) - 32) // max(h * w * 3, 1)
         if have < n:          # truncated file: like a cv2 reader whose read() fails early, the stream simply ends there
             n = max(have, 0)
         frames = np.memmap(path, dtype=np.uint8, mode="r", offset=32, shape=(n, h, w, 3))
         return ArrayVideo(frames, fps1000 / 1000.0)
+    if ext in (".nv12", ".yuv"):
+        import re
+        m = re.search(r"_(\d+)x(\d+)$", os.path.splitext(os.path.basename(path))[0])
+        if not m:
+            raise ValueError(f"{path}: a header-less NV12 file needs its size in the name (<name>_<W>x<H>{ext})")
+        w, h = int(m.group(1)), int(m.group(2))
+        n = os.path.getsize(path) // (h * w * 3 // 2)
+        return Nv12Video(np.memmap(path, dtype=np.uint8, mode="r", shape=(n, h * 3 // 2, w)), h, w)
     try:
         import cv2  # noqa: F401
     except ImportError as e:
-        raise RuntimeError(f"cannot decode {path}: OpenCV is not installed and the file is not .npy/.ppvid") from e
+        raise RuntimeError(f"cannot decode {path}: OpenCV is not installed and the file is not .npy/.ppvid/.nv12") from e
     return _Cv2Video(path)  # pragma: no cover
