@@ -40,7 +40,8 @@ extern "C" {
                                  three-way operand split are the default where a layer is eligible)
                               7: pp_net_create_ex / pp_net_numerics: the numerics of a program are fixed when it is created (a per-net
                                  property, no longer read from the process-wide switch at launch time); pp_op gained in2 / in3 /
-                                 up2_log2 / up3_log2 (sizeof(pp_op) 104 -> 120) */
+                                 up2_log2 / up3_log2 (sizeof(pp_op) 104 -> 120)
+                              8: pp_upload_begin_nv12 / pp_nv12_to_bgr (NV12 frame source) */
 
 typedef enum {
     PP_OK = 0,
