@@ -71,6 +71,7 @@ struct SplitArgs {
     int xcd_remap;
     int gx, gy;                           // xcd_remap: logical grid (pixel tiles, channel columns) of the 1-D launch
     int col_major;                        // xcd_remap: an XCD walks its tiles column by column (small inputs) instead of tile by tile
+    int epi_lds;                          // conv_split_gemm_kernel: epilogue transposed through LDS (whole 128-byte lines per store)
 };
 
 // Workgroup id -> (tile, channel column) of a 1-D launch of 8 * ceil(ntiles / 8) * ncol ids.  Consecutive ids go round-robin over
@@ -1115,6 +1116,68 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
         __builtin_amdgcn_s_barrier();
     }
 
+    // ---- epilogue, transposed through LDS (a.epi_lds) ----------------------------------------------------------------------------
+    // A lane holds 4 consecutive channels of ONE pixel (lane & 31): stored from the registers, an instruction touches 32 pixels with
+    // 32 bytes each.  The stages are free here (every wave passed the loop's last barrier after its last fragment read), so each
+    // wave transposes its 128 pixels x 32 channels (one channel block at a time) through 16 KiB of its own ([128][128 B], 16-byte
+    // chunk ^ (pixel & 7)) and stores whole 128-byte lines, 8 pixels per instruction; residuals are read in the same lines.  The
+    // pixel -> (output, residual) offsets are computed once per pixel (two lanes' worth of divisions per wave, not per store) into
+    // a 2 KiB table beside it.  Same arithmetic per element, in the same order, as the register epilogue below: identical bits.
+    if (a.epi_lds) {
+        unsigned char* stg = smem + wave * (16384 + 2048);
+        uint4* tab = reinterpret_cast<uint4*>(stg + 16384);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = lane + 64 * i;
+            const long long m = m0 + wm * 128 + p;
+            uint4 t = make_uint4(0u, 0u, 0u, 0u);
+            if (m < a.S) {
+                const int img = (int)(m / (a.H * a.W)), rem = (int)(m - (long long)img * (a.H * a.W));
+                const int oy = rem / a.W, ox = rem - oy * a.W;
+                t.x = (unsigned)(((size_t)img * (a.H + a.y_pad) + oy) * (a.W + a.y_pad) + ox);
+                t.y = (unsigned)(((size_t)img * (a.r1_H + a.r1_pad) + (oy >> a.r1_shift)) * (a.r1_W + a.r1_pad) + (ox >> a.r1_shift));
+                t.z = (unsigned)(((size_t)img * (a.H + a.r2_pad) + oy) * (a.W + a.r2_pad) + ox);
+                t.w = 1u;
+            }
+            tab[p] = t;
+        }
+        const int rdrow = lane >> 3, rdpos = lane & 7, rdchunk = rdpos ^ rdrow;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = (cb0 + cb) * 32 + 8 * g + 4 * (lane >> 5);
+                    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
+                    const f32x16 cc = acc[cb][pb];
+                    float4 v = make_float4(cc[4 * g + 0] + b4.x, cc[4 * g + 1] + b4.y, cc[4 * g + 2] + b4.z, cc[4 * g + 3] + b4.w);
+                    if (a.relu == PP_RELU_FIRST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    else if (a.relu >= PP_ACT_LEAKY) { v.x = split_activate(v.x, a.relu); v.y = split_activate(v.y, a.relu); v.z = split_activate(v.z, a.relu); v.w = split_activate(v.w, a.relu); }
+                    *reinterpret_cast<float4*>(stg + (pb * 32 + (lane & 31)) * 128 + (((2 * g + (lane >> 5)) ^ (lane & 7)) << 4)) = v;
+                }
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 8 + rdrow;
+                float4 v = *reinterpret_cast<const float4*>(stg + row * 128 + rdpos * 16);
+                const uint4 t = tab[row];
+                if (!t.w) continue;
+                const int co = (cb0 + cb) * 32 + rdchunk * 4;
+                if (a.res1) {
+                    const float4 r = *reinterpret_cast<const float4*>(a.res1 + (size_t)t.y * a.Cout + co);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (a.res2) {
+                    const float4 r = *reinterpret_cast<const float4*>(a.res2 + (size_t)t.z * a.Cout + co);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                *reinterpret_cast<float4*>(a.y + (size_t)t.x * a.Cout + co) = v;
+            }
+        }
+        return;
+    }
+
     // ---- epilogue (as conv_split_kernel) -----------------------------------------------------------------------------------------
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) {
@@ -1372,11 +1435,15 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         s.xcd_remap = gemm_remap && s.gy > 1;
         if (s.xcd_remap) grid = dim3((unsigned)((s.gx + 7) / 8 * 8 * s.gy), 1);
         else s.xcd_remap = 0;
-        const size_t lds = (size_t)2 * (3 * 2 * (BM + 4) * 16 + BN * 6 * 16);
+        // POSEPIPE_SPLIT_GEMM_EPI (read per call: A/B on one box): 1 = epilogue transposed through LDS (18 KiB per wave), 0 = from registers
+        const char* epi_env = getenv("POSEPIPE_SPLIT_GEMM_EPI");
+        s.epi_lds = epi_env ? atoi(epi_env) : 1;
+        const int nwave = g8 == 3 ? 4 : 8;
+        const size_t lds = std::max<size_t>((size_t)2 * (3 * 2 * (BM + 4) * 16 + BN * 6 * 16), s.epi_lds ? (size_t)nwave * (16384 + 2048) : 0);
         static std::once_flag once;
         std::call_once(once, [] {
-            (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         });
         if (g8 == 1)

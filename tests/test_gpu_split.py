@@ -531,3 +531,55 @@ def test_split_program_replays_from_a_hip_graph(ctx, lib):
     assert np.array_equal(net.forward(x), eager)
     assert np.array_equal(net.forward(x), eager)
     net.close()
+
+
+def test_product_kernel_epilogues_agree_bit_for_bit(ctx, lib, monkeypatch):
+    """conv_split_gemm_kernel stores either from the registers (a lane: 4 channels of one pixel) or transposed through LDS (whole
+    128-byte lines, offsets from a per-pixel table): same arithmetic per element in the same order, so the same bits -- on the
+    8-wave 256 x 256 and 512 x 128 forms, the 4-wave form, ragged last tiles, strides, both residuals (one read with a shift),
+    ReLU first / last, halo output buffers inside a program, and fc6's full-cover product"""
+    rng = np.random.default_rng(71)
+
+    def run(fn):
+        out = []
+        for epi in ("0", "1"):
+            monkeypatch.setenv("POSEPIPE_SPLIT_GEMM_EPI", epi)
+            L.check(lib.pp_conv_exact(0), "pp_conv_exact")
+            out.append(fn())
+        L.check(lib.pp_conv_exact(1), "pp_conv_exact")
+        monkeypatch.delenv("POSEPIPE_SPLIT_GEMM_EPI")
+        assert np.isfinite(out[0]).all() and np.abs(out[0]).max() > 0
+        assert np.array_equal(out[0], out[1])
+
+    for cin, cout, h, w, n, stride in ((1024, 256, 12, 20, 3, 1), (512, 384, 21, 35, 2, 1), (256, 1024, 17, 9, 5, 1), (1024, 512, 20, 12, 2, 2)):
+        x = rng.standard_normal((n, h, w, cin)).astype(np.float32)
+        wt = (rng.standard_normal((cout, cin, 1, 1)) / np.sqrt(cin)).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+        r = rng.standard_normal((n, ho, wo, cout)).astype(np.float32)
+        for relu in (0, L.PP_RELU_FIRST, L.PP_RELU_LAST):
+            run(lambda: hip_conv_op(ctx, x, wt, b, stride=stride, relu=relu, res1=r))
+    x = rng.standard_normal((3, 21, 35, 512)).astype(np.float32)                      # shifted residual (FPN lateral)
+    wt = (rng.standard_normal((256, 512, 1, 1)) / np.sqrt(512)).astype(np.float32)
+    b = rng.standard_normal(256).astype(np.float32)
+    r = rng.standard_normal((3, 11, 18, 256)).astype(np.float32)
+    run(lambda: hip_conv_op(ctx, x, wt, b, res1=r, res1_shift=1))
+    xr = rng.standard_normal((300, 7, 7, 64)).astype(np.float32)                       # fc6 form
+    wf = (rng.standard_normal((128, 64, 7, 7)) / 56).astype(np.float32)
+    bf = rng.standard_normal(128).astype(np.float32)
+    run(lambda: hip_conv_op(ctx, xr, wf, bf, relu=L.PP_RELU_LAST))
+    # inside a program: the 1x1 writes a zero-halo buffer that a 3x3 reads (y_pad > 0), second residual
+    pb = ProgramBuilder()
+    xin_b = pb.buf(20, 12, 512, name="input")
+    y1 = pb.conv(xin_b, (rng.standard_normal((256, 512, 1, 1)) / 23).astype(np.float32), rng.standard_normal(256).astype(np.float32), relu=L.PP_RELU_LAST)
+    out = pb.buf(20, 12, 256, name="output")
+    pb.conv(y1, (rng.standard_normal((256, 256, 3, 3)) / 48).astype(np.float32), rng.standard_normal(256).astype(np.float32), pad=1, res1=y1, out=out)
+    prog = pb.build()
+    xin = rng.standard_normal((7, 20, 12, 512)).astype(np.float32)
+
+    def net_run():
+        net = Net(ctx, prog, max_batch=7, numerics="split")
+        y = net.forward(xin)
+        net.close()
+        return y
+    run(net_run)
