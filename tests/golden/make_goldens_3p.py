@@ -20,7 +20,8 @@ installed there (the script says so and exits 0 with nothing written).
 Third-party entry points exercised (the call sites that select them: pose_pipeline/wrappers/mmpose.py:28,57,75;
 wrappers/mmtrack.py:30,45; wrappers/videopose3d.py:43-50,66-82; 3rdparty/mmpose/config/.../hrnet_w48_coco_384x288_dark.py;
 3rdparty/mmtracking/_base_/models/faster_rcnn_r50_fpn.py, mot/deepsort/sort_faster-rcnn_fpn_4e_mot17-private-half.py):
-  cv2.getAffineTransform, cv2.warpAffine(INTER_LINEAR), cv2.GaussianBlur, cv2.getGaussianKernel, cv2.resize(INTER_LINEAR)
+  cv2.getAffineTransform, cv2.warpAffine(INTER_LINEAR), cv2.GaussianBlur, cv2.getGaussianKernel, cv2.resize(INTER_LINEAR),
+  cv2.cvtColor(COLOR_YUV2BGR_NV12)
   mmpose: apis.inference._box2cs, core.post_processing.{get_affine_transform, flip_back, transform_preds},
           core.evaluation.top_down_eval.keypoints_from_heatmaps, models HRNet + TopdownHeatmapSimpleHead
   mmcv:   ops.nms, ops.roi_align, imnormalize
@@ -85,6 +86,11 @@ def ref_cv2_resize(d):
     import cv2
     return {"down": cv2.resize(d["img"], tuple(int(v) for v in d["dsize"]), interpolation=cv2.INTER_LINEAR),
             "up": cv2.resize(d["img"], tuple(int(v) for v in d["dsize_up"]), interpolation=cv2.INTER_LINEAR)}
+
+
+def ref_cv2_nv12(d):
+    import cv2
+    return {"bgr": np.stack([cv2.cvtColor(np.ascontiguousarray(f), cv2.COLOR_YUV2BGR_NV12) for f in d["planes"]])}
 
 
 def _coco_flip_pairs():
@@ -189,7 +195,7 @@ def ref_nets(d):
     return out
 
 
-REFERENCE = {"cv2_affine": ref_cv2_affine, "cv2_blur": ref_cv2_blur, "cv2_resize": ref_cv2_resize, "mmpose": ref_mmpose,
+REFERENCE = {"cv2_affine": ref_cv2_affine, "cv2_blur": ref_cv2_blur, "cv2_resize": ref_cv2_resize, "cv2_nv12": ref_cv2_nv12, "mmpose": ref_mmpose,
              "mmcv": ref_mmcv, "mmtrack": ref_mmtrack, "nets": ref_nets}
 
 

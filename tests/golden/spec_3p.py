@@ -103,6 +103,23 @@ def cv2_resize_checks(d):
     return {"down": "exact", "up": "exact"}
 
 
+# ---- cv2.cvtColor(COLOR_YUV2BGR_NV12) 8-bit (the NV12 frame source: csrc/nv12.hip, oracle/nv12.py) ---------------------------
+def cv2_nv12_inputs(rng):
+    h, w = 36, 40
+    planes = rng.integers(0, 256, (3, h * 3 // 2, w)).astype(np.uint8)       # every byte value, legal range or not
+    planes[0, :2, :8] = [[0, 255, 16, 235, 81, 145, 41, 128], [15, 236, 128, 1, 90, 54, 240, 200]]
+    return {"planes": planes, "hw": np.array([h, w], np.int64)}
+
+
+def cv2_nv12_oracle(d, ref=None):
+    from oracle import nv12 as onv
+    return {"bgr": onv.nv12_to_bgr(d["planes"], int(d["hw"][0]), int(d["hw"][1]))}
+
+
+def cv2_nv12_checks(d):
+    return {"bgr": "exact"}
+
+
 # ---- mmpose 0.x: _box2cs, get_affine_transform, flip_back, keypoints_from_heatmaps, transform_preds ------------------------
 def mmpose_inputs(rng):
     n, k, h, w = 2, 17, 64, 48
@@ -240,6 +257,7 @@ SECTIONS = {
     "cv2_affine": (cv2_affine_inputs, cv2_affine_oracle, cv2_affine_checks, ["cv2"]),
     "cv2_blur": (cv2_blur_inputs, cv2_blur_oracle, cv2_blur_checks, ["cv2"]),
     "cv2_resize": (cv2_resize_inputs, cv2_resize_oracle, cv2_resize_checks, ["cv2"]),
+    "cv2_nv12": (cv2_nv12_inputs, cv2_nv12_oracle, cv2_nv12_checks, ["cv2"]),
     "mmpose": (mmpose_inputs, mmpose_oracle, mmpose_checks, ["mmpose", "cv2"]),
     "mmcv": (mmcv_inputs, mmcv_oracle, mmcv_checks, ["mmcv", "torch"]),
     "mmtrack": (mmtrack_inputs, mmtrack_oracle, mmtrack_checks, ["mmtrack", "torch"]),
