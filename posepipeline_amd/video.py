@@ -6,7 +6,7 @@ below exist because neither OpenCV nor ffmpeg is installed in the build / GPU im
   *.npy    numpy array [N][H][W][3] uint8, BGR (what cv2 would have decoded)
   *.ppvid  32-byte header (magic 'PPVID001', N, H, W, fps*1000 as little-endian int32) + raw BGR frames;
            magic 'PPVID002' carries a pixel-format word after the four ints (0 = bgr24, 1 = nv12)
-  *_<W>x<H>.nv12 / .yuv   header-less NV12 frames (`ffmpeg -i in.mp4 -pix_fmt nv12 -f rawvideo out_1920x1080.nv12`), 30 fps
+  *_<W>x<H>.nv12   header-less NV12 frames (`ffmpeg -i in.mp4 -pix_fmt nv12 -f rawvideo out_1920x1080.nv12`), 30 fps
 BGR sources yield frames in BGR order, like `cap.read()`.  NV12 sources (a decoder's native output: Y plane [H][W], then
 interleaved UV [H/2][W]; half the bytes) hand their raw planes to streaming.FrameStreamer, which uploads them as they are and
 converts on the device (csrc/nv12.hip, OpenCV's COLOR_YUV2BGR_NV12 arithmetic) -- there is no host conversion path.
@@ -161,7 +161,7 @@ def robust_path(path, run=None):
     `run`: subprocess.run stand-in (tests)."""
     import subprocess
     import tempfile
-    if isinstance(path, np.ndarray) or os.path.splitext(path)[1].lower() in (".npy", ".ppvid", ".nv12", ".yuv"):
+    if isinstance(path, np.ndarray) or os.path.splitext(path)[1].lower() in (".npy", ".ppvid", ".nv12"):
         return path
     st = os.stat(path)
     key = (os.path.abspath(path), st.st_size, st.st_mtime_ns)
@@ -236,7 +236,7 @@ def open_video(path):
             n = max(have, 0)
         frames = np.memmap(path, dtype=np.uint8, mode="r", offset=32, shape=(n, h, w, 3))
         return ArrayVideo(frames, fps1000 / 1000.0)
-    if ext in (".nv12", ".yuv"):
+    if ext == ".nv12":        # (.yuv is not accepted: by convention that is planar I420, which this reader would misread)
         import re
         m = re.search(r"_(\d+)x(\d+)$", os.path.splitext(os.path.basename(path))[0])
         if not m:
