@@ -87,7 +87,7 @@ int pp_host_free(pp_ctx* ctx, void* host_ptr);
 int pp_upload_begin(pp_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
 /* ABI 8 -- NV12 frame source (a decoder's native output: Y plane [h][w], then interleaved UV [h/2][w]; half the bytes of
  * the BGR frames cv2.VideoCapture.read() hands the reference at pose_pipeline/pipeline.py:47-87, wrappers/mmtrack.py:38-45,
- * wrappers/mmpose.py:55-75).  h even, w a multiple of 4.  The conversion is OpenCV's cvtColor(COLOR_YUV2BGR_NV12) bit for
+ * wrappers/mmpose.py:55-75).  h and w even.  The conversion is OpenCV's cvtColor(COLOR_YUV2BGR_NV12) bit for
  * bit (ITU-R BT.601 limited range, 20-bit fixed point; oracle/nv12.py).
  *   pp_upload_begin_nv12  pp_upload_begin for `frames` NV12 frames: host -> tmp_nv12_device on the copy stream, then the
  *                         conversion into dst_bgr_device ([frames][h][w][3] u8) on the same stream; pp_upload_wait /

@@ -6,7 +6,8 @@
 //
 // HBM-bound byte work (1.5 B read + 3 B written per pixel): one thread converts a 4 x 2 pixel block -- two 4-byte Y loads, one
 // 4-byte UV load (two chroma pairs), two 12-byte stores; consecutive threads cover consecutive 4-pixel groups of a row pair, so
-// every load and store instruction of a wave touches one contiguous span.
+// every load and store instruction of a wave touches one contiguous span.  Widths with w % 4 == 2 (854 x 480) take 16-bit
+// accesses (their rows are only 2-byte aligned) and a 2-pixel last group.
 #include "pp_internal.h"
 
 namespace {
@@ -17,7 +18,7 @@ __device__ __forceinline__ unsigned sat8(int v) { return (unsigned)min(max(v >> 
 
 __global__ __launch_bounds__(256) void nv12_to_bgr_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
                                                           int frames, int h, int w) {
-    const int groups = w >> 2;                                   // 4-pixel groups per row
+    const int groups = (w + 3) >> 2;                             // 4-pixel groups per row; the last one has 2 pixels when w % 4 == 2
     const long long total = (long long)frames * (h >> 1) * groups;
     const long long stride = (long long)gridDim.x * 256;
     const size_t frame_in = (size_t)h * w * 3 / 2, frame_out = (size_t)h * w * 3;
@@ -26,9 +27,25 @@ __global__ __launch_bounds__(256) void nv12_to_bgr_kernel(const unsigned char* _
         const long long r = i / groups;
         const int yp = (int)(r % (h >> 1)), f = (int)(r / (h >> 1));
         const unsigned char* fin = src + (size_t)f * frame_in;
-        const unsigned uv = *reinterpret_cast<const unsigned*>(fin + (size_t)h * w + (size_t)yp * w + 4 * g);
-        const unsigned y0 = *reinterpret_cast<const unsigned*>(fin + (size_t)(2 * yp) * w + 4 * g);
-        const unsigned y1 = *reinterpret_cast<const unsigned*>(fin + (size_t)(2 * yp + 1) * w + 4 * g);
+        const unsigned char* puv = fin + (size_t)h * w + (size_t)yp * w + 4 * g;
+        const unsigned char* py0 = fin + (size_t)(2 * yp) * w + 4 * g;
+        const unsigned char* py1 = py0 + w;
+        const bool full = 4 * g + 4 <= w;                        // rows are 2-byte aligned only when w % 4 == 2: 16-bit loads there
+        unsigned uv, y0, y1;
+        if (full && (w & 3) == 0) {
+            uv = *reinterpret_cast<const unsigned*>(puv);
+            y0 = *reinterpret_cast<const unsigned*>(py0);
+            y1 = *reinterpret_cast<const unsigned*>(py1);
+        } else {
+            uv = *reinterpret_cast<const unsigned short*>(puv);
+            y0 = *reinterpret_cast<const unsigned short*>(py0);
+            y1 = *reinterpret_cast<const unsigned short*>(py1);
+            if (full) {
+                uv |= (unsigned)*reinterpret_cast<const unsigned short*>(puv + 2) << 16;
+                y0 |= (unsigned)*reinterpret_cast<const unsigned short*>(py0 + 2) << 16;
+                y1 |= (unsigned)*reinterpret_cast<const unsigned short*>(py1 + 2) << 16;
+            }
+        }
         int ruv[2], guv[2], buv[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -48,10 +65,17 @@ __global__ __launch_bounds__(256) void nv12_to_bgr_kernel(const unsigned char* _
                 o[3 * px + 1] = (unsigned char)sat8(y + guv[p]);
                 o[3 * px + 2] = (unsigned char)sat8(y + ruv[p]);
             }
-            unsigned* d = reinterpret_cast<unsigned*>(dst + (size_t)f * frame_out + ((size_t)(2 * yp + row) * w + 4 * g) * 3);
-            d[0] = o[0] | (o[1] << 8) | (o[2] << 16) | ((unsigned)o[3] << 24);
-            d[1] = o[4] | (o[5] << 8) | (o[6] << 16) | ((unsigned)o[7] << 24);
-            d[2] = o[8] | (o[9] << 8) | (o[10] << 16) | ((unsigned)o[11] << 24);
+            unsigned char* d8 = dst + (size_t)f * frame_out + ((size_t)(2 * yp + row) * w + 4 * g) * 3;
+            if (full && (w & 3) == 0) {                          // 12 bytes at a 4-byte aligned address
+                unsigned* d = reinterpret_cast<unsigned*>(d8);
+                d[0] = o[0] | (o[1] << 8) | (o[2] << 16) | ((unsigned)o[3] << 24);
+                d[1] = o[4] | (o[5] << 8) | (o[6] << 16) | ((unsigned)o[7] << 24);
+                d[2] = o[8] | (o[9] << 8) | (o[10] << 16) | ((unsigned)o[11] << 24);
+            } else {                                             // w % 4 == 2: rows start at 2-byte aligned addresses
+                unsigned short* d = reinterpret_cast<unsigned short*>(d8);
+                const int n16 = full ? 6 : 3;
+                for (int q = 0; q < n16; ++q) d[q] = (unsigned short)(o[2 * q] | (o[2 * q + 1] << 8));
+            }
         }
     }
 }
@@ -60,9 +84,9 @@ __global__ __launch_bounds__(256) void nv12_to_bgr_kernel(const unsigned char* _
 
 int pp_launch_nv12_to_bgr(const unsigned char* nv12, unsigned char* bgr, int frames, int h, int w, hipStream_t stream) {
     PP_REQUIRE(frames >= 0 && h > 0 && w > 0, "nv12_to_bgr: bad shape %d x %d x %d", frames, h, w);
-    PP_REQUIRE(h % 2 == 0 && w % 4 == 0, "nv12_to_bgr: height %d must be even and width %d a multiple of 4", h, w);
+    PP_REQUIRE(h % 2 == 0 && w % 2 == 0, "nv12_to_bgr: height %d and width %d must be even", h, w);
     if (frames == 0) return PP_OK;
-    const long long total = (long long)frames * (h / 2) * (w / 4);
+    const long long total = (long long)frames * (h / 2) * ((w + 3) / 4);
     const unsigned grid = (unsigned)std::min<long long>((total + 255) / 256, 256 * 32);
     hipLaunchKernelGGL(nv12_to_bgr_kernel, dim3(grid), dim3(256), 0, stream, nv12, bgr, frames, h, w);
     PP_HIP_CHECK(hipGetLastError());

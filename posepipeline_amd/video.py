@@ -65,8 +65,8 @@ class Nv12Video:
 
     def __init__(self, planes: np.ndarray, height: int, width: int, fps: float = 30.0):
         assert planes.dtype == np.uint8 and planes.ndim == 3 and planes.shape[1:] == (height * 3 // 2, width)
-        if height % 2 or width % 4:
-            raise ValueError(f"NV12 source {width}x{height}: height must be even and width a multiple of 4")
+        if height % 2 or width % 2:
+            raise ValueError(f"NV12 source {width}x{height}: height and width must be even")
         self.planes, self.height, self.width, self.fps = planes, int(height), int(width), float(fps)
         self.pos = 0
 
@@ -93,7 +93,7 @@ def bgr_to_nv12(frames: np.ndarray) -> np.ndarray:
     test / synthetic containers; chroma is the rounded mean of each 2 x 2 block)"""
     f = np.ascontiguousarray(frames, np.uint8).astype(np.int32)
     n, h, w, _ = f.shape
-    assert h % 2 == 0 and w % 4 == 0
+    assert h % 2 == 0 and w % 2 == 0
     b, g, r = f[..., 0], f[..., 1], f[..., 2]
     y = ((66 * r + 129 * g + 25 * b + 128) >> 8) + 16
     blk = f.reshape(n, h // 2, 2, w // 2, 2, 3).sum(axis=(2, 4))

@@ -26,18 +26,18 @@ def _convert(ctx, planes, h, w):
     return out
 
 
-@pytest.mark.parametrize("n,h,w", [(1, 2, 4), (3, 34, 20), (2, 270, 484), (1, 1080, 1920), (5, 16, 4096)])
+@pytest.mark.parametrize("n,h,w", [(1, 2, 4), (3, 34, 20), (2, 270, 484), (1, 1080, 1920), (5, 16, 4096), (2, 480, 854), (3, 6, 2), (1, 4, 6)])
 def test_nv12_to_bgr_equals_the_oracle_on_every_code(ctx, n, h, w):
     rng = np.random.default_rng(h + w)
     planes = rng.integers(0, 256, (n, h * 3 // 2, w)).astype(np.uint8)      # every byte value, legal range or not
-    planes[0, :2, :4] = [[0, 255, 16, 235], [15, 236, 128, 1]]
+    planes[0, :2, :2] = [[0, 255], [16, 235]]
     assert np.array_equal(_convert(ctx, planes, h, w), onv.nv12_to_bgr(planes, h, w))
 
 
 def test_nv12_rejects_odd_sizes(ctx):
     d = ctx.malloc(4096)
     assert ctx.lib.pp_nv12_to_bgr(ctx.handle, C.c_void_p(d), 1, 3, 8, C.c_void_p(d)) == -1
-    assert ctx.lib.pp_nv12_to_bgr(ctx.handle, C.c_void_p(d), 1, 4, 6, C.c_void_p(d)) == -1
+    assert ctx.lib.pp_nv12_to_bgr(ctx.handle, C.c_void_p(d), 1, 4, 7, C.c_void_p(d)) == -1
     assert ctx.lib.pp_nv12_to_bgr(ctx.handle, C.c_void_p(d), 0, 4, 8, C.c_void_p(d)) == 0       # empty clip
     ctx.free(d)
 

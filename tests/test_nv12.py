@@ -76,5 +76,5 @@ def test_containers_open_as_nv12_sources(tmp_path):
     p1 = str(tmp_path / "bgr.ppvid")
     video.write_ppvid(p1, frames)
     assert getattr(video.open_video(p1), "pixfmt", "bgr24") == "bgr24"
-    with pytest.raises(ValueError, match="multiple of 4"):
-        video.Nv12Video(np.zeros((1, 3, 6), np.uint8), 2, 6)
+    with pytest.raises(ValueError, match="must be even"):
+        video.Nv12Video(np.zeros((1, 3, 5), np.uint8), 2, 5)
