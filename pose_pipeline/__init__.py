@@ -13,14 +13,21 @@ of scope and raises ImportError as an absent module should.
 """
 import os
 
-from posepipeline_amd.pipeline import (DetectedFrames, LiftingMethod, LiftingMethodLookup, LiftingPerson, PersonBbox,  # noqa: F401
-                                       PersonBboxValid, TopDownMethod, TopDownMethodLookup, TopDownPerson, TrackingBbox,
-                                       TrackingBboxMethod, TrackingBboxMethodLookup, Video, VideoInfo)
+from posepipeline_amd.pipeline import (BestDetectedFrames, DetectedFrames, LiftingMethod, LiftingMethodLookup,  # noqa: F401
+                                       LiftingPerson, PersonBbox, PersonBboxValid, TopDownMethod, TopDownMethodLookup,
+                                       TopDownPerson, TrackingBbox, TrackingBboxMethod, TrackingBboxMethodLookup, Video,
+                                       VideoInfo)
 from posepipeline_amd.weights import model_data_dir as _model_data_dir
+
+# pose_pipeline/__init__.py:19 of the reference; `pose_pipeline.env` is an attribute scripts use (scripts/process_h36m.py:7-8)
+from . import env  # noqa: E402,F401  (the sub-module replaces itself with posepipeline_amd.env)
+from posepipeline_amd.env import (add_path, pytorch_memory_limit, set_environmental_variables,  # noqa: E402,F401
+                                  tensorflow_memory_limit)
 
 # pose_pipeline/__init__.py:24-27 of the reference: $PIPELINE_3RDPARTY, else <checkout>/3rdparty
 MODEL_DATA_DIR = _model_data_dir()
 
 __all__ = ["Video", "VideoInfo", "TrackingBboxMethodLookup", "TrackingBboxMethod", "TrackingBbox", "PersonBboxValid",
-           "PersonBbox", "DetectedFrames", "TopDownMethodLookup", "TopDownMethod", "TopDownPerson", "LiftingMethodLookup",
-           "LiftingMethod", "LiftingPerson", "MODEL_DATA_DIR"]
+           "PersonBbox", "DetectedFrames", "BestDetectedFrames", "TopDownMethodLookup", "TopDownMethod", "TopDownPerson", "LiftingMethodLookup",
+           "LiftingMethod", "LiftingPerson", "MODEL_DATA_DIR", "add_path", "set_environmental_variables",
+           "pytorch_memory_limit", "tensorflow_memory_limit"]

@@ -16,7 +16,7 @@ import os
 
 import numpy as np
 
-if os.environ.get("POSEPIPE_USE_DATAJOINT") == "1":  # pragma: no cover - needs MySQL
+if os.environ.get("POSEPIPE_USE_DATAJOINT") == "1":  # the real package (MySQL); tests/test_entry_script.py runs this branch on a stand-in
     import datajoint as dj
 else:
     from . import djshim as dj
