@@ -36,10 +36,12 @@ METRIC = "frames/sec (whole node), detect->2D->3D cascade on 1080p; MPJPE vs ref
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (default: WORLD_SIZE when launched by torchrun, else 1).  N > 1 without a "
+                         "torchrun environment re-launches this script under `python -m torch.distributed.run` with N ranks")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cascade", choices=["cascade", "c2", "c5", "cascade5", "track0", "cascade0"])
+    ap.add_argument("--workload", default="cascade", choices=["cascade", "c2", "c5", "cascade5", "track0", "cascade0", "plumbing"])
     ap.add_argument("--chunk", type=int, default=64, help="cascade: frames per step per GPU (32: -4 %; 128: as 64)")
     ap.add_argument("--persons", type=int, default=1, help="cascade: tracked persons per frame")
     ap.add_argument("--batch", type=int, default=64, help="c2 / c5: person-frames per step per GPU")
@@ -48,6 +50,10 @@ def parse():
                     help="cascade: the run to put under `rocprofv3 --kernel-trace --stats`: every launch on one stream, no detector "
                          "look-ahead, no bit-exact / PCIe / CPU legs -- per-kernel durations are then additive and AverageNs of "
                          "conv_split_* x launches_per_step reproduces roofline.ms_per_step_serial")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="cascade: skip the `secondary` block (configs[2] with 4 persons, configs[1], the sharded mode on this rank; "
+                         "short runs outside the timed region)")
+    ap.add_argument("--light", action="store_true", help=argparse.SUPPRESS)   # no side legs at all (used for the secondary lines)
     ap.add_argument("--mode", default="replicas", choices=["replicas", "shard"],
                     help="N > 1: independent frame shards per rank (default, no data-path collective) or ONE clip sharded over "
                          "the ranks with the detection / 2D all_gathers of posepipeline_amd/parallel.py")
@@ -155,11 +161,27 @@ DTYPE_NOTE = ("; eligible float32 convolutions are evaluated as exact 3-way bf16
               "accumulation (float32-accurate, not bit-identical: tests/test_gpu_split.py)")
 
 
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 outside torchrun: become the launcher.  One process per GPU, rendezvous on
+    127.0.0.1 (the container hostname may not resolve), same argv; never returns."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
 class Dist:
-    def __init__(self):
+    def __init__(self, gpus=None):
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if gpus is not None and gpus != self.world:
+            raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): the line would misreport n_gpus"
+                             % (gpus, self.world))
         self.dist = None
         # POSEPIPE_DIST_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share
         # devices, collectives on CPU tensors); the real runs use RCCL ("nccl"), one rank per GPU
@@ -215,6 +237,20 @@ class Dist:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if self.backend == "nccl" else "cpu")
         self.dist.all_reduce(tt, op=self.dist.ReduceOp.MAX)
         return float(tt.item())
+
+    def describe(self):
+        """what actually ran: world size as the process group reports it, backend, and every rank's device"""
+        me = {"rank": self.rank, "local_rank": self.local_rank, "pid": os.getpid()}
+        try:
+            import torch
+            if torch.cuda.is_available():
+                me["device"] = "cuda:%d %s" % (self.local_rank, torch.cuda.get_device_name(self.local_rank))
+        except Exception:
+            pass
+        ranks = self.gather_obj(me)
+        return {"world_size": self.dist.get_world_size() if self.dist is not None else 1,
+                "backend": ("rccl (torch.distributed 'nccl')" if self.backend == "nccl" else self.backend) if self.dist is not None else None,
+                "launcher": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run", "ranks": ranks}
 
     def close(self):
         if self.dist is not None:
@@ -384,7 +420,8 @@ def run_cascade(args, D):
     # numerics are fixed at creation, ABI 7); reported beside `value` (N = 1 leg)
     exact_mode = None
     cas_exact = None
-    if D.world == 1 and not args.profile_serial:
+    side_legs = D.world == 1 and not args.profile_serial and not args.light
+    if side_legs:
         with _lib.default_numerics("exact"):
             cas_exact = Cascade(ctx, det_sd, pose_sd, lift_sd, 1080, 1920, chunk=B, max_persons=P, pose_spec=pose_spec)
 
@@ -423,7 +460,7 @@ def run_cascade(args, D):
     }
     if D.world > 1:
         out["per_rank_ms_per_step"] = per_rank
-    if D.world == 1 and not args.profile_serial:
+    if side_legs:
         # PCIe-inclusive leg (reported beside `value`, never as it): the same chunks streamed from host memory through
         # page-locked staging buffers and the copy stream (posepipeline_amd/streaming.py), upload overlapped with compute
         from posepipeline_amd.video import ArrayVideo
@@ -466,9 +503,47 @@ def run_cascade(args, D):
         out["roofline"]["vit_stage"] = {"backbone_ms": stage["pose_backbone"], "program_tflops": pose_flops / (stage["pose_backbone"] * 1e-3) / 1e12,
                                         "note": "ViTPose-H program (bf16 GEMMs + fp32 patch embedding / head); roofline line: --workload c5"}
     n_cpu = 8 if args.cpu_frames is None else args.cpu_frames
-    if n_cpu > 0 and D.world == 1 and not vit:          # the CPU baseline is a rank-0, N=1 leg (c5 carries the ViT one)
+    if n_cpu > 0 and side_legs and not vit:             # the CPU baseline is a rank-0, N=1 leg (c5 carries the ViT one)
         out["cpu_baseline"] = cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames, gt, n_cpu, {"bit_exact_mode": cas_exact, "default": cas})
-    print(json.dumps(out), flush=True)
+    if side_legs and not vit and not args.no_secondary and args.mode == "replicas":
+        del cas_exact
+        out["secondary"] = secondary_lines(args, D)
+    return out
+
+
+def secondary_lines(args, D):
+    """The other single-GPU configurations, measured in the same process right after the headline line (outside its timed
+    region; a few short steps each, no side legs), so that the driver's record holds them as measurements and not only the
+    builder's profiles/: configs[2] (4 tracked persons per 1080p frame), configs[1] (HRNet-W32 256x192, pre-cropped), and the
+    one-clip-sharded-over-ranks mode on this rank.  Each entry: value, ms_per_step and the conv kernels' roofline fraction."""
+    import copy
+    legs = (("cascade_persons4", "configs[2]: the cascade with 4 tracked persons per 1080p frame", dict(persons=4, steps=4, warmup=1)),
+            ("c2", "configs[1]: HRNet-W32 256x192, 64 pre-cropped person-frames per step", dict(workload="c2", steps=20, warmup=3)),
+            ("shard_1rank", "configs[3] in --mode shard (one clip sharded over ranks, parallel.py) on this rank", dict(mode="shard", steps=4, warmup=1)))
+    sec, t_all = {}, time.perf_counter()
+    for key, what, over in legs:
+        a = copy.copy(args)
+        a.light, a.cpu_frames, a.no_secondary = True, 0, True
+        for k, v in over.items():
+            setattr(a, k, v)
+        t0 = time.perf_counter()
+        try:
+            r = {"cascade": run_cascade, "c2": run_c2}[a.workload](a, D)
+        except Exception as e:       # a secondary leg never takes the headline line down with it
+            sec[key] = {"what": what, "error": "%s: %s" % (type(e).__name__, e)}
+            continue
+        roof = r.get("roofline", {})
+        sec[key] = {"what": what, "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                    "warmup": r["warmup"], "frames_per_step": r["config"].get("frames_per_step_per_gpu"),
+                    "persons_per_frame": r["config"].get("persons_per_frame"),
+                    "roofline": {k: roof.get(k) for k in ("kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches_per_step")
+                                 if roof.get(k) is not None},
+                    "fp32_mfma_kernels": {k: (roof.get("fp32_mfma_kernels") or {}).get(k) for k in ("achieved", "peak", "frac", "ms_per_step_serial")
+                                          } if roof.get("fp32_mfma_kernels") else None,
+                    "leg_wall_s": time.perf_counter() - t0}
+    sec["wall_s"] = time.perf_counter() - t_all
+    sec["note"] = "measured after the headline's timed region, same process and GPU; command lines: --persons 4 / --workload c2 / --mode shard"
+    return sec
 
 
 def run_cascade_sharded(args, D, ctx, cas):
@@ -512,7 +587,7 @@ def run_cascade_sharded(args, D, ctx, cas):
     if D.rank != 0:
         return
     flops_step = B * (cas.detector.flops_per_frame + 2 * P * cas.pose_net.prog.flops)
-    print(json.dumps({
+    return {
         "metric": METRIC, "value": D.world * B * K / dt, "unit": "frames/s", "n_gpus": D.world, "steps": K, "warmup": args.warmup,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" + DTYPE_NOTE, "data": "synthetic",
         "config": {"workload": "configs[3]: ONE 1080p clip of %d frames sharded over %d rank(s): detect (Faster-RCNN R50-FPN) -> all_gather of "
@@ -529,7 +604,7 @@ def run_cascade_sharded(args, D, ctx, cas):
                              "included) against the split kernel's peak; the per-kernel roofline line is the default mode's"},
         "host_cores_per_rank": (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", D.world))),
         "per_rank_phase_ms": per_rank,
-    }), flush=True)
+    }
 
 
 def _lib_check(rc):
@@ -661,7 +736,7 @@ def run_c2(args, D):
     n_cpu = 6 if args.cpu_frames is None else args.cpu_frames
     if n_cpu > 0 and D.world == 1:
         out["cpu_baseline"] = cpu_baseline_c2(sd, x[:n_cpu], cs[:n_cpu], kp[:n_cpu])
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def cpu_baseline_c2(sd, x, cs, kp_gpu):
@@ -755,7 +830,7 @@ def run_c5(args, D):
     if n_cpu > 0 and D.world == 1:
         hm_gpu = net.read("output", 2 * n).reshape(2 * n, 17, *spec.heatmap_hw)
         out["cpu_baseline"] = cpu_baseline_c5(p, spec, x[:n_cpu], cs[:n_cpu], kp[:n_cpu], hm_gpu[:n_cpu], hm_gpu[n:n + n_cpu])
-    print(json.dumps(out), flush=True)
+    return out
 
 
 def cpu_baseline_c5(p, spec, x, cs, kp_gpu, hm_gpu, hmf_gpu):
@@ -844,7 +919,7 @@ def run_track0(args, D):
     flops_step = det.prog.flops * B
     achieved = flops_step / (net_ms * 1e-3) / 1e12
     n_launch = sum(1 for op in det.prog.ops if op.type == 1)
-    print(json.dumps({
+    return {
         "metric": "frames/sec, DeepSortYOLOv4 tracking stage on 1080p (not the headline metric)",
         "value": D.world * B * args.steps / dt, "unit": "frames/s", "n_gpus": D.world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -852,10 +927,13 @@ def run_track0(args, D):
         "config": {"workload": "tracking_method 0: letterbox -> YOLOv4 416 -> decode/NMS -> mars-small128 -> DeepSORT",
                    "frames_per_step_per_gpu": B, "persons_per_frame": args.persons, "tracks_per_step": n_trk,
                    "detector_boxes": "detector + decode + NMS run on every frame; downstream boxes are replayed synthetic persons"},
-        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (%d conv launches of the YOLOv4 program; Mish epilogues in fp64)" % n_launch,
-                     "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "flops_per_launch": flops_step / n_launch, "avg_launch_ms": net_ms / n_launch},
-    }), flush=True)
+        # per kernel family, live (HIP events around every launch of one serial pass): YOLOv4's 3x3 / wide 1x1 layers run on the
+        # split kernels since round 2, so the dominant family and ITS peak are reported, not the fp32 kernels' 157.3
+        "roofline": {**roofline_families(kernel_families([(det.net, B)])), "traffic": None,
+                     "program": {"achieved": achieved, "launches": n_launch, "flops_per_launch": flops_step / n_launch,
+                                 "avg_launch_ms": net_ms / n_launch,
+                                 "note": "YOLOv4 program inside the timed region (Mish epilogues in fp64): FLOPs / wall time"}},
+    }
 
 
 def run_cascade0(args, D):
@@ -903,7 +981,7 @@ def run_cascade0(args, D):
     flops_step = B * (cas.detector.flops_per_frame + 2 * P * cas.pose_net.prog.flops)
     n_launch = len(cas.detector.prog.ops) + len(cas.pose_net.prog.ops)
     achieved = flops_step / (conv_ms * 1e-3) / 1e12
-    print(json.dumps({
+    return {
         "metric": METRIC, "value": D.world * B * K / dt, "unit": "frames/s", "n_gpus": D.world, "steps": K, "warmup": args.warmup,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
@@ -912,19 +990,42 @@ def run_cascade0(args, D):
                    "frames_per_step_per_gpu": B, "persons_per_frame": P, "gflop_per_frame": flops_step / B / 1e9,
                    "tracks_in_last_frame": len(res["tracks"][-1]),
                    "detector_boxes": "detector + decode + NMS run on every frame; downstream boxes are replayed synthetic GT (random-weight detector)"},
-        "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (%d launches per step: YOLOv4 + HRNet-W48 programs)" % n_launch,
-                     "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                     "traffic": None, "flops_per_launch": flops_step / n_launch, "avg_launch_ms": conv_ms / n_launch,
+        "roofline": {**roofline_families(kernel_families([(cas.detector.net, B), (cas.pose_net, 2 * B * P)])), "traffic": None,
+                     "programs": {"achieved": achieved, "launches": n_launch, "flops_per_launch": flops_step / n_launch,
+                                  "avg_launch_ms": conv_ms / n_launch,
+                                  "note": "YOLOv4 + HRNet-W48 programs inside the timed region: FLOPs / wall time"},
                      "stage_ms": {"yolo_backbone": st["yolo"] / K, "pose_backbone": st["pose"] / K}},
-    }), flush=True)
+    }
+
+
+def run_plumbing(args, D):
+    """No kernels: the rank plumbing of an N-rank run (launcher, process group, weight broadcast, barrier, max-over-ranks
+    clock) -- `python bench.py --gpus 2 --workload plumbing` with POSEPIPE_DIST_BACKEND=gloo rehearses the multi-GPU launch on a
+    box without GPUs (tests/test_distributed_gloo.py)."""
+    class _NoCtx:
+        def synchronize(self):
+            pass
+    blob = np.arange(4096, dtype=np.float32) * (1.0 if D.rank == 0 else -1.0)
+    got = D.bcast_blob(blob)
+    D.barrier(_NoCtx())
+    t = D.max_time(1.0 + D.rank)
+    oks = D.gather_obj(bool(np.array_equal(got, np.arange(4096, dtype=np.float32))))
+    return {"metric": "rank plumbing only (no kernels)", "value": 0.0, "unit": "frames/s", "n_gpus": D.world, "steps": args.steps,
+            "warmup": args.warmup, "slowest_rank_clock": t, "weights_identical_on_every_rank": all(oks)}
 
 
 def main():
     args = parse()
-    D = Dist()
+    if args.gpus is not None and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, sys.argv[1:])
+    D = Dist(args.gpus)
     try:
-        {"cascade": run_cascade, "c2": run_c2, "c5": run_c5, "cascade5": run_cascade, "track0": run_track0,
-         "cascade0": run_cascade0}[args.workload](args, D)
+        out = {"cascade": run_cascade, "c2": run_c2, "c5": run_c5, "cascade5": run_cascade, "track0": run_track0,
+               "cascade0": run_cascade0, "plumbing": run_plumbing}[args.workload](args, D)
+        topo = D.describe()
+        if D.rank == 0 and out is not None:
+            out["distributed"] = topo
+            print(json.dumps(out), flush=True)
     finally:
         D.close()
 
