@@ -676,10 +676,65 @@ def cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames, gt, n_frames, cascade
                          "note": "seeded-random weights: the detector's 100-of-~1000 cut and NMS sit on near-ties, heat-maps are noise "
                                  "(ill-conditioned arg-max / DARK step); the tolerance claims are tests/test_gpu_parity_modes.py "
                                  "(well-conditioned weights, margin-aware detector check)"}
+    readout["well_conditioned_end_to_end"] = parity_well_conditioned(cascades.get("default"), frames, gt, pick[:3])
     return {"value": n_timed / dt, "unit": "frames/s", "cores": clib.N_THREADS, "kind": "port",
             "sample": "%d synthetic 1080p frame(s) through the CPU restatement of detect + top-down 2D (W48, flip) + one lifting window "
                       "(%.1f s, detector %.1f s); parity readout over %d frames" % (n_timed, dt, t_det, len(ref)),
             "parity_vs_gpu": readout}
+
+
+def parity_well_conditioned(cas, frames, gt, pick):
+    """north_star's tolerance on the cascade's OUTPUT, read where it is well-posed: the same 2D -> 3D stages in the DEFAULT
+    numerics with well-conditioned weights (synth.smooth_state_dict / smooth_lifting_state_dict: single-peaked heat-maps,
+    metre-sized 3D outputs, lifting sensitivity <= 1) on blob persons pasted at the replayed boxes; oracle 2D chain -> oracle
+    lifting against the device's 2D -> 3D.  The assertion of the same figures is tests/test_gpu_parity_modes.py::
+    test_end_to_end_3d_against_the_oracle_chain; this is the readout beside the timed line."""
+    if cas is None:
+        return None
+    from oracle import decode as odec
+    from oracle import nets as onets
+    from oracle import preprocess as opre
+    from posepipeline_amd import ops
+    from posepipeline_amd.models import hrnet, synth
+    from posepipeline_amd.models import videopose3d as vp3d
+    from posepipeline_amd.program import Net
+    from posepipeline_amd.wrappers.videopose3d import lift, normalize_screen_coordinates
+    ctx, spec, lspec = cas.ctx, hrnet.hrnet_w48_384x288(), vp3d.VideoPose3DSpec()
+    pose_sd = synth.smooth_state_dict(hrnet.hrnet_param_shapes(spec), seed=11)
+    lift_sd = synth.smooth_lifting_state_dict(vp3d.videopose3d_param_shapes(lspec), seed=3)
+    net = Net(ctx, hrnet.build_hrnet_program(spec, pose_sd), max_batch=2)
+    lnet = Net(ctx, vp3d.build_videopose3d_program(lspec, lift_sd), max_batch=1)
+    td = ops.TopDown(net, 17, flip_perm=hrnet.flip_perm(17), post="unbiased", blur_kernel=17)
+    pose_model, lift_model = onets.HRNetRef(pose_sd, 48), onets.VideoPose3DRef(lift_sd)
+    rng = np.random.default_rng(9)
+    k2_dev, k2_ref = [], []
+    for fi in pick:
+        g = gt[fi][0]
+        x0, y0, x1, y1 = (int(v) for v in g[:4])
+        img = np.full_like(frames[fi], 30)
+        yy, xx = np.mgrid[0:y1 - y0, 0:x1 - x0].astype(np.float32)
+        for c in range(3):                      # one bright blob per colour plane: what a smoothing pose network peaks on
+            cy, cx, sg = rng.uniform(0.4, 0.6) * (y1 - y0), rng.uniform(0.4, 0.6) * (x1 - x0), rng.uniform(0.05, 0.09) * (y1 - y0)
+            img[y0:y1, x0:x1, c] = np.clip(30 + 190 * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * sg * sg)), 0, 255).astype(np.uint8)
+        bb = np.array([g[0], g[1], g[2] - g[0], g[3] - g[1]], np.float64)
+        kg, _ = td.run(img[None], np.zeros(1, np.int32), bb[None])
+        t, c, sc, _ = opre.top_down_input(img[:, :, ::-1], bb, (288, 384))
+        hm = pose_model.forward(t[None])
+        hmf = pose_model.forward(np.ascontiguousarray(t[None, :, :, ::-1]))
+        kp, _ = odec.decode_topdown(hm, hmf, hrnet.COCO_FLIP_PAIRS, c[None], sc[None], post_process="unbiased", kernel=17)
+        k2_dev.append(kg[0])
+        k2_ref.append(kp[0])
+    k2_dev, k2_ref = np.asarray(k2_dev), np.asarray(k2_ref)
+    norm = lambda k: normalize_screen_coordinates(k[:, :, :2].astype(np.float64), 1920, 1080).astype(np.float32)
+    k3_dev = lift(lnet, lspec, normalize_screen_coordinates(k2_dev[:, :, :2].astype(np.float64), 1920, 1080))
+    k3_ref = lift_model.forward(onets.videopose3d_windows(norm(k2_ref), 121))
+    d3, r3 = float(np.abs(k3_dev - k3_ref).max()), float(np.abs(k3_ref).max())
+    net.close()
+    lnet.close()
+    return {"numerics": net.numerics, "frames": len(pick), "max_abs_diff_2d_px": float(np.abs(k2_dev[:, :, :2] - k2_ref[:, :, :2]).max()),
+            "max_abs_diff_3d_m": d3, "max_abs_diff_3d_of_output_range": d3 / r3, "output_range_m": r3,
+            "lifting_sensitivity_bound": synth.max_norm_gain_bound(lift_sd),
+            "bars": "2D <= 1e-3 px, 3D <= 1e-6 m (1e-3 mm) and <= 1e-6 of the output range"}
 
 
 def run_c2(args, D):

@@ -34,7 +34,10 @@ from tests.test_gpu_pipeline import oracle_topdown
 pytestmark = pytest.mark.gpu
 
 TOL_PX = 1e-3          # north_star: 2D joints within 1e-3 px
-TOL_M = 1e-6           # 3D joints within 1e-3 mm; VideoPose3D's unit is the metre
+TOL_M = 1e-6           # 3D joints within 1e-3 mm.  VideoPose3D's unit is the metre -- for the trained checkpoint, and for the lifting
+                       # weights of these tests by construction (synth.smooth_lifting_state_dict: outputs span about a metre, max-norm
+                       # sensitivity <= 0.98, asserted in tests/test_weights.py); every 3D assertion ALSO holds the error to
+TOL_3D_REL = 1e-6      # this fraction of the clip's largest |coordinate|, which is unit-free
 TOL_SCORE = 1e-5       # relative to the largest score of the batch
 
 
@@ -98,7 +101,17 @@ def _blob_person(rng, h, w):
 
 
 def _lift_sd():
-    return synth.synth_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3)
+    return synth.smooth_lifting_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3)
+
+
+def assert_3d(got, ref, numerics, what=""):
+    """exact: the oracle's bits; split: 1e-3 mm AND 1e-6 of the output range"""
+    if numerics == "exact":
+        assert np.array_equal(got, ref), what
+        return 0.0
+    d = float(np.abs(got - ref).max())
+    assert d <= TOL_M and d <= TOL_3D_REL * float(np.abs(ref).max()), (what, d, float(np.abs(ref).max()))
+    return d
 
 
 def _check_tracks(outs, tracks, frames, n, h, w, pose_sd, width, image_size, lift_sd, numerics, sample):
@@ -128,11 +141,7 @@ def _check_tracks(outs, tracks, frames, n, h, w, pose_sd, width, image_size, lif
         f3, a3 = k3[tid]
         ref3 = reference_3d(a2, f2, n, w, h, lift_sd)                        # the lifting oracle on the device's own 2D track
         assert f3 == f2
-        if numerics == "exact":
-            assert np.array_equal(a3, ref3[f3:f3 + len(a3)]), tid
-        else:
-            worst3 = max(worst3, float(np.abs(a3 - ref3[f3:f3 + len(a3)]).max()))
-            assert np.abs(a3 - ref3[f3:f3 + len(a3)]).max() <= TOL_M, (tid, np.abs(a3 - ref3[f3:f3 + len(a3)]).max())
+        worst3 = max(worst3, assert_3d(a3, ref3[f3:f3 + len(a3)], numerics, tid))
     print(f"[{numerics}] {len(ids)} ids: 2D max {worst2:.2e} px, 3D max {worst3:.2e} m")
     return ids, k2
 
@@ -217,11 +226,79 @@ def test_cascade_long_clip_both_modes(ctx, numerics):
             continue
         fr3 = o["keypoints_3d_frames"][tid]
         emitted.append(len(fr3))
-        if numerics == "exact":
-            assert np.array_equal(o["keypoints_3d"][tid], ref3[fr3])
-        else:
-            assert np.abs(o["keypoints_3d"][tid] - ref3[fr3]).max() <= TOL_M
+        assert_3d(o["keypoints_3d"][tid], ref3[fr3], numerics)
     assert emitted == [0, 7, 64, 64, 64, 10, 121]                          # identical emission schedule in either mode
+
+
+# ---- (ii-b) END TO END: oracle 2D chain -> oracle lifting against the device's 3D ----------------------------------------------
+_E2E_ORACLE = {}       # the CPU chain does not depend on the numerics mode: computed once per size
+
+
+@pytest.mark.parametrize("size", ["1080p_w48", "540x960_w32_130frames"])
+def test_end_to_end_3d_against_the_oracle_chain(ctx, numerics, size):
+    """The tolerance north_star states for the OUTPUT of the cascade: the device's 3D joints against the reference's whole
+    chain evaluated by the oracle -- PersonBbox -> crop -> HRNet x 2 -> flip merge -> DARK decode for EVERY frame, then
+    normalize_screen_coordinates and one 243-frame window per frame (wrappers/mmpose.py:60-76, wrappers/videopose3d.py:77-91).
+    Unlike `_check_tracks` (which lifts the device's own 2D track with the oracle), the 2D error of the default numerics
+    propagates into this comparison.  Well-conditioned pose AND lifting weights; bars: 2D every joint <= 1e-3 px, 3D <= 1e-3 mm
+    and <= 1e-6 of the output range; exact mode: `==` throughout."""
+    from posepipeline_amd.cascade import Cascade, collect
+    from posepipeline_amd.tracking import person_bbox
+    from posepipeline_amd.wrappers.videopose3d import normalize_screen_coordinates
+    if size == "1080p_w48":
+        h, w, n, chunk, width, image_size = 1080, 1920, 6, 3, 48, (288, 384)
+        spec = hrnet.hrnet_w48_384x288()
+        box = lambda t: (640 + 9 * t, 200, 830 + 9 * t, 790)
+    else:
+        h, w, n, chunk, width, image_size = 540, 960, 130, 64, 32, (96, 128)        # > 121 frames: real (not only replicated) windows
+        spec = hrnet.HRNetSpec(32, 17, 128, 96)
+        box = lambda t: (80 + 3 * t, 80, 360 + 3 * t, 480)
+    rng = np.random.default_rng(31)
+    cell = 40 if h == 1080 else 20
+    bg = np.repeat(np.repeat(rng.integers(20, 60, (h // cell, w // cell, 3)).astype(np.uint8), cell, axis=0), cell, axis=1)
+    x0, y0, x1, y1 = box(0)
+    tex = _blob_person(rng, y1 - y0, x1 - x0)
+    frames = np.empty((n, h, w, 3), np.uint8)
+    gt = []
+    for t in range(n):
+        x0, y0, x1, y1 = box(t)
+        frames[t] = bg
+        frames[t, y0:y1, x0:x1] = np.clip(tex.astype(np.int32) + (t % 5), 0, 255).astype(np.uint8)
+        gt.append(np.array([[x0 + 0.25, y0 + 0.5, x1 - 0.25, y1, 0.9]], np.float32))
+    det_sd = synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2)
+    pose_sd = synth.smooth_state_dict(hrnet.hrnet_param_shapes(spec), seed=13)
+    lift_sd = _lift_sd()
+    cas = Cascade(ctx, det_sd, pose_sd, lift_sd, h, w, chunk=chunk, max_persons=1, pose_spec=spec)
+    assert cas.pose_net.numerics == numerics
+    outs = [cas.step(frames[i:i + chunk], replay=gt[i:i + chunk]) for i in range(0, n, chunk)] + [cas.flush()]
+    tracks = [fr_ for o in outs for fr_ in o["tracks"]]
+    ids = sorted({r[0] for fr_ in tracks for r in fr_})
+    assert len(ids) == 1
+    f2, a2 = collect(outs, "keypoints")[ids[0]]
+    f3, a3 = collect(outs, "keypoints_3d")[ids[0]]
+    assert f2 == f3 == 0 and len(a2) == len(a3) == n
+    if size not in _E2E_ORACLE:
+        dicts = [[{"track_id": r[0], "tlhw": np.array([r[1], r[2], r[3] - r[1], r[4] - r[2]], np.float64)} for r in fr_] for fr_ in tracks]
+        bbox, present = person_bbox(dicts, ids)
+        assert present.all()
+        k2 = np.asarray(oracle_topdown(pose_sd, width, frames, bbox, image_size, "unbiased", 17))
+        kn = normalize_screen_coordinates(k2[:, :, :2].astype(np.float64), w, h).astype("float32")
+        _E2E_ORACLE[size] = (k2, onets.VideoPose3DRef(lift_sd).forward(onets.videopose3d_windows(kn, 121)))
+    ref2, ref3 = _E2E_ORACLE[size]
+    d2 = float(np.abs(a2[:, :, :2] - ref2[:, :, :2]).max())
+    d3 = float(np.abs(a3 - ref3).max())
+    rng3 = float(np.abs(ref3).max())
+    print(f"[{numerics}] {size}: {n} frames end to end, 2D max {d2:.2e} px, 3D max {d3:.2e} m = {d3 / rng3:.2e} of the output range "
+          f"({rng3:.2f} m), lifting sensitivity bound {synth.max_norm_gain_bound(lift_sd):.2f}")
+    assert 0.2 < rng3 < 3.0                                                  # metre-sized outputs: the absolute bar means something
+    if numerics == "exact":
+        # the one non-integer step of the exact chain is DARK's log (numpy float32 vs the device's correctly rounded one, DESIGN 2)
+        assert d2 <= TOL_PX
+        assert np.array_equal(a2[:, :, 2], ref2[:, :, 2].astype(np.float32))
+    else:
+        assert d2 <= TOL_PX
+        assert_scores(a2[:, :, 2], ref2[:, :, 2], numerics)
+    assert d3 <= TOL_M and d3 <= TOL_3D_REL * rng3
 
 
 # ---- (iii) detector: margin-aware set equality, ids on detector-produced boxes ----------------------------------------------

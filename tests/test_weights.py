@@ -47,3 +47,26 @@ def test_checkpoint_roundtrip_and_errors(tmp_path, monkeypatch):
     syn = weights.get_state_dict("mmpose/checkpoints/absent.pth", shapes, seed=3)
     assert all(np.array_equal(syn[k], sd[k]) for k in shapes)
     assert os.path.samefile(weights.model_data_dir(), tmp_path)
+
+
+def test_smooth_lifting_weights_are_metre_sized_contractions():
+    """synth.smooth_lifting_state_dict (the lifting weights of the 3D tolerance tests): max-norm sensitivity <= 1 by construction
+    (product of the layers' row sums) and measured, outputs metre-sized on screen-normalised inputs -- so "1e-3 mm" is a
+    statement about the arithmetic, not about a weight scale."""
+    from oracle import nets as onets
+    from posepipeline_amd.models import videopose3d as vp3d
+    sd = synth.smooth_lifting_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3)
+    bound = synth.max_norm_gain_bound(sd)
+    assert 0.9 < bound <= 1.0
+    model = onets.VideoPose3DRef(sd)
+    rng = np.random.default_rng(0)
+    t = np.arange(12)[:, None, None]
+    kn = (rng.uniform(-0.5, 0.5, (1, 17, 2)) + 0.002 * t * rng.uniform(-1, 1, (1, 17, 2))).astype(np.float32)
+    y = model.forward(onets.videopose3d_windows(kn, 121))
+    assert 0.3 < np.abs(y).max() < 2.0 and y.std() > 0.1
+    d = (rng.uniform(-1, 1, kn.shape) * 1e-3).astype(np.float32)
+    y2 = model.forward(onets.videopose3d_windows(kn + d, 121))
+    gain = np.abs(y2 - y).max() / np.abs(d).max()
+    assert 0.05 < gain <= bound
+    # the seeded He-normal weights the other tests use are NOT contractions (why they cannot carry a millimetre claim)
+    assert synth.max_norm_gain_bound(synth.synth_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3)) > 10
