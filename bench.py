@@ -422,8 +422,7 @@ def run_cascade(args, D):
     cas_exact = None
     side_legs = D.world == 1 and not args.profile_serial and not args.light
     if side_legs:
-        with _lib.default_numerics("exact"):
-            cas_exact = Cascade(ctx, det_sd, pose_sd, lift_sd, 1080, 1920, chunk=B, max_persons=P, pose_spec=pose_spec)
+        cas_exact = Cascade(ctx, det_sd, pose_sd, lift_sd, 1080, 1920, chunk=B, max_persons=P, pose_spec=pose_spec, numerics="exact")
 
         def step_exact(more=False):
             return cas_exact.step(None, frames_dev=(dptr, B), replay=replay_boxes(), prefetch=(None, (dptr, B)) if more else None)

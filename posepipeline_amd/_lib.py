@@ -177,7 +177,9 @@ import contextlib
 @contextlib.contextmanager
 def default_numerics(mode):
     """Process-wide default numerics ("exact" / "split" / None = the environment's) for the nets CREATED inside the block -- composite
-    objects (Cascade, Detector, TopDown wrappers) create theirs in their constructors.  A net keeps what it was created with."""
+    objects (Cascade, Detector, TopDown wrappers) create theirs in their constructors.  A net keeps what it was created with.
+    NOT thread-safe (one process-wide switch): code that builds nets on several threads passes `numerics=` to the constructors
+    (Net, Cascade, Detector, the YOLO / ReID encoders) instead; this context manager is for single-threaded tests."""
     lib = load_library()
     prev = _DEFAULT_NUMERICS[0]
     check(lib.pp_conv_exact({None: -1, "default": -1, "exact": 1, "split": 0}[mode]), "pp_conv_exact")

@@ -44,7 +44,7 @@ class Cascade:
     def __init__(self, ctx: L.Context, det_sd, pose_sd: dict, lift_sd: dict, src_h: int, src_w: int,
                  chunk: int = 8, max_persons: int = 1, pose_spec=None, post="unbiased", blur_kernel=17,
                  tracking: str = "MMTrack_deepsort", keep_tracks=None, flip_pairs=None, blob_fn=None, reid_sd=None,
-                 overlap_detector: bool | None = None):
+                 overlap_detector: bool | None = None, numerics=None):
         """blob_fn(name, program) -> (device pointer, n_floats) or None, name in "det_a", "det_b", "pose", "lift" (called in
         that order): a weight blob that is already resident on the device -- parallel.broadcast_blob_device delivers rank
         0's over RCCL; the *_sd arguments then only define the program structure (ops, buffers, blob offsets).
@@ -55,6 +55,8 @@ class Cascade:
         resident input tensor of the CURRENT chunk).  None = automatic: on when the host has at least 4 cores per local rank
         (the worker thread spends its time inside a synchronous GPU call, and HIP's waits spin), POSEPIPE_OVERLAP_DETECTOR=0/1
         overrides."""
+        # numerics: "exact" / "split" / None (= the process default at this moment) for EVERY program this cascade creates, passed
+        # down explicitly -- two threads building cascades in different modes do not interfere (unlike _lib.default_numerics)
         self.ctx = ctx
         self.det_ctx = ctx
         self._pending = None          # (chunk key, Future of _det_job) started by step(prefetch=...)
@@ -69,8 +71,8 @@ class Cascade:
         self.reid = None
         if tracking == "DeepSortYOLOv4":
             from .models import mars, yolov4
-            self.detector = yolov4.YoloV4Detector(ctx, det_sd[0], src_h, src_w, max_frames=chunk)
-            self.encoder = mars.MarsEncoder(ctx, det_sd[1], src_h, src_w, max_patches=max(64, chunk * max_persons))
+            self.detector = yolov4.YoloV4Detector(ctx, det_sd[0], src_h, src_w, max_frames=chunk, numerics=numerics)
+            self.encoder = mars.MarsEncoder(ctx, det_sd[1], src_h, src_w, max_patches=max(64, chunk * max_persons), numerics=numerics)
         else:
             assert tracking == "MMTrack_deepsort", tracking
             if overlap_detector is None:
@@ -78,10 +80,10 @@ class Cascade:
                 ranks = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
                 overlap_detector = (env != "0") if env is not None else (os.cpu_count() or 1) >= 4 * ranks
             self.det_ctx = L.Context(ctx.device) if (overlap_detector and reid_sd is None) else ctx
-            self.detector = fr.Detector(self.det_ctx, det_sd, src_h, src_w, max_frames=chunk, blob_fn=blob_fn)
+            self.detector = fr.Detector(self.det_ctx, det_sd, src_h, src_w, max_frames=chunk, blob_fn=blob_fn, numerics=numerics)
             if reid_sd is not None:
                 from .models import reid_r50
-                self.reid = reid_r50.ReidEncoder(ctx, reid_sd, self.detector, max_crops=max(64, chunk * max_persons), blob_fn=blob_fn)
+                self.reid = reid_r50.ReidEncoder(ctx, reid_sd, self.detector, max_crops=max(64, chunk * max_persons), blob_fn=blob_fn, numerics=numerics)
         self.pose_spec = pose_spec or hrnet.hrnet_w48_384x288()
         if isinstance(self.pose_spec, vitpose.VitPoseSpec):     # BASELINE.json configs[4]: ViTPose 2D stage (UDP, bf16 MFMA)
             pose_prog = vitpose.build_vitpose_program(self.pose_spec, pose_sd)
@@ -91,14 +93,14 @@ class Cascade:
             pose_prog = hrnet.build_hrnet_program(self.pose_spec, pose_sd)
             shift = True
             self.k = int(self.pose_spec.num_joints)
-        self.pose_net = Net(ctx, pose_prog, max_batch=2 * chunk * max_persons, blob_dev=blob_fn("pose", pose_prog))
+        self.pose_net = Net(ctx, pose_prog, max_batch=2 * chunk * max_persons, blob_dev=blob_fn("pose", pose_prog), numerics=numerics)
         if flip_pairs is None:
             flip_pairs = {17: hrnet.COCO_FLIP_PAIRS, 133: hrnet.WHOLEBODY_FLIP_PAIRS, 136: hrnet.HALPE_FLIP_PAIRS}[self.k]
         self.topdown = ops.TopDown(self.pose_net, self.k, flip_perm=hrnet.flip_perm(self.k, flip_pairs), shift_heatmap=shift,
                                    post=post, blur_kernel=blur_kernel)
         self.lift_spec = vp3d.VideoPose3DSpec()
         lift_prog = vp3d.build_videopose3d_program(self.lift_spec, lift_sd)
-        self.lift_net = Net(ctx, lift_prog, max_batch=max(1, max_persons), blob_dev=blob_fn("lift", lift_prog))
+        self.lift_net = Net(ctx, lift_prog, max_batch=max(1, max_persons), blob_dev=blob_fn("lift", lift_prog), numerics=numerics)
         self.frame_bytes = src_h * src_w * 3
         self.tail_dev = None          # device copy of the last FILL_LIMIT frames (slot = frame % FILL_LIMIT)
         self.tail_host = None

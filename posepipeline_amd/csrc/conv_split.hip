@@ -1299,7 +1299,9 @@ TileGeom pick_tile(int H, int W, int max_np, int pxb) {
 }  // namespace
 
 // how the split kernel sees the layer: taps (9 / 1) and channels per tap (a full-cover 'valid' conv is a 1x1 over KH*KW*Cin)
-static bool split_shape(const ConvArgs& a, int* taps, int* cin, int* mode) {
+// committed: the layer was selected when its split weights were built (pp_net_create_ex / the caller of pp_conv_split_eligible), so
+// the launch path derives the SAME form from the shape alone -- no knob is read at launch time (ABI 7: nothing is decided at launch)
+static bool split_shape(const ConvArgs& a, int* taps, int* cin, int* mode, bool committed = false) {
     const bool k3 = a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_h == 1 && a.pad_w == 1 && a.dil_h == 1 && a.dil_w == 1 &&
                     a.Hout == a.Hin && a.Wout == a.Win;
     const bool k1 = a.KH == 1 && a.KW == 1 && a.pad_h == 0 && a.pad_w == 0;
@@ -1311,9 +1313,10 @@ static bool split_shape(const ConvArgs& a, int* taps, int* cin, int* mode) {
     // channels or ONE channel block per workgroup (Cout 96) it LOSES to the fp32 kernels (48 -> 96: 95 -> 58), so: from 128 input
     // channels, two channel blocks.  (What these layers want is the patch form with a strided patch: 4x the LDS per tile.)
     static const int s2_on = env_int("POSEPIPE_SPLIT_S2", 1);
-    // POSEPIPE_SPLIT_S2_MIN_CIN (read per call): tests set it to run the form on every shape it supports, whatever the launcher would pick
-    const char* s2_env = getenv("POSEPIPE_SPLIT_S2_MIN_CIN");
-    const bool s2_pick = s2_env ? a.Cin >= atoi(s2_env) : (a.Cin >= 128 && (((a.Cout + 31) / 32) & 1) == 0);
+    // POSEPIPE_SPLIT_S2_MIN_CIN (read per SELECTION, i.e. at net creation: tests set it to run the form on every shape it supports,
+    // whatever the selection rule would pick); a committed layer keeps the form it was created with
+    const char* s2_env = committed ? nullptr : getenv("POSEPIPE_SPLIT_S2_MIN_CIN");
+    const bool s2_pick = committed || (s2_env ? a.Cin >= atoi(s2_env) : (a.Cin >= 128 && (((a.Cout + 31) / 32) & 1) == 0));
     const bool k3s2 = s2_on && a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad_h == 1 && a.pad_w == 1 && a.dil_h == 1 && a.dil_w == 1 && !full && s2_pick;
     if (!(k3 || k1 || full || k3s2)) return false;
     *taps = (k3 || k3s2) ? 9 : 1;
@@ -1398,7 +1401,7 @@ int pp_conv_split_weights(const ConvArgs& a, void* out, hipStream_t stream) {
 
 int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     int taps = 1, cin = a.Cin, mode = 0;
-    if (!split_shape(a, &taps, &cin, &mode)) {
+    if (!a.wsplit || !split_shape(a, &taps, &cin, &mode, true)) {
         pp_set_error("conv_split: layer not eligible");
         return PP_ERR_ARG;
     }
@@ -1435,7 +1438,9 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         s.xcd_remap = gemm_remap && s.gy > 1;
         if (s.xcd_remap) grid = dim3((unsigned)((s.gx + 7) / 8 * 8 * s.gy), 1);
         else s.xcd_remap = 0;
-        // POSEPIPE_SPLIT_GEMM_EPI (read per call: A/B on one box): 1 = epilogue transposed through LDS (18 KiB per wave), 0 = from registers
+        // POSEPIPE_SPLIT_GEMM_EPI: 1 = epilogue transposed through LDS (18 KiB per wave), 0 = from registers.  The one knob still read per
+        // launch: it selects between two store orders of the SAME values (bit-identical, tests/test_gpu_split.py A/Bs them in one
+        // process), needs no creation-time state and cannot make a created net ineligible
         const char* epi_env = getenv("POSEPIPE_SPLIT_GEMM_EPI");
         s.epi_lds = epi_env ? atoi(epi_env) : 1;
         const int nwave = g8 == 3 ? 4 : 8;

@@ -184,7 +184,7 @@ class Detector:
     MAX_ROIS = 1000
     MAX_DET = 100
 
-    def __init__(self, ctx, sd, src_h, src_w, max_frames=4, prefix="detector.", blob_fn=None):
+    def __init__(self, ctx, sd, src_h, src_w, max_frames=4, prefix="detector.", blob_fn=None, numerics=None):
         """blob_fn(name, program) -> (device pointer, n_floats) or None: where the program's weight blob is already resident
         on the device ("det_a" = image program, "det_b" = RoI head; RCCL broadcast, posepipeline_amd/parallel.py)"""
         from ..program import Net
@@ -194,8 +194,8 @@ class Detector:
         self.nh, self.nw, self.hp, self.wp = detector_input_size(src_h, src_w)
         self.prog_a = build_image_program(sd, self.hp, self.wp, prefix)
         self.prog_b = build_roi_program(sd, prefix)
-        self.net_a = Net(ctx, self.prog_a, max_batch=max_frames, blob_dev=blob_fn("det_a", self.prog_a))
-        self.net_b = Net(ctx, self.prog_b, max_batch=max_frames * self.MAX_ROIS, blob_dev=blob_fn("det_b", self.prog_b))
+        self.net_a = Net(ctx, self.prog_a, max_batch=max_frames, blob_dev=blob_fn("det_a", self.prog_a), numerics=numerics)
+        self.net_b = Net(ctx, self.prog_b, max_batch=max_frames * self.MAX_ROIS, blob_dev=blob_fn("det_b", self.prog_b), numerics=numerics)
         na = self.prog_a.named
         bufs_a = np.array([na["input"]] + [na[f"rpn_cls{l}"] for l in range(5)] + [na[f"rpn_reg{l}"] for l in range(5)] +
                           [na[f"p{i}"] for i in range(2, 6)], np.int32)

@@ -133,10 +133,10 @@ def patch_rect(bbox_tlwh, image_hw, patch_hw=PATCH_HW):
 class MarsEncoder:
     """create_box_encoder: (frames, boxes) -> unit-norm 128-d features (float64 rows, generate_detections.py:80)."""
 
-    def __init__(self, ctx: L.Context, sd: dict, src_h: int, src_w: int, max_patches: int = 64):
+    def __init__(self, ctx: L.Context, sd: dict, src_h: int, src_w: int, max_patches: int = 64, numerics=None):
         self.ctx, self.src = ctx, (src_h, src_w)
         self.prog = build_mars_program(sd)
-        self.net = Net(ctx, self.prog, max_batch=max_patches)
+        self.net = Net(ctx, self.prog, max_batch=max_patches, numerics=numerics)
         self.max_patches = max_patches
 
     def encode(self, frames, boxes_per_frame, frames_dev=None):

@@ -70,11 +70,11 @@ def crop_rects(boxes_xyxy, scale_factor, img_hw):
 class ReidEncoder:
     """128-d appearance embeddings of detections, computed from the detector's resident input tensor"""
 
-    def __init__(self, ctx, sd: dict, detector, max_crops: int = 128, blob_fn=None):
+    def __init__(self, ctx, sd: dict, detector, max_crops: int = 128, blob_fn=None, numerics=None):
         self.ctx, self.det = ctx, detector
         self.prog = build_reid_program(sd)
         self.max_crops = int(max_crops)
-        self.net = Net(ctx, self.prog, max_batch=self.max_crops, blob_dev=(blob_fn or (lambda n, p: None))("reid", self.prog))
+        self.net = Net(ctx, self.prog, max_batch=self.max_crops, blob_dev=(blob_fn or (lambda n, p: None))("reid", self.prog), numerics=numerics)
         self.in_ptr, _, _ = self.net.buffer("input")
         h, w = detector.src
         self.sf = np.array([detector.nw / w, detector.nh / h, detector.nw / w, detector.nh / h], np.float32)

@@ -265,13 +265,13 @@ class YoloV4Detector:
     """yolo.YOLO.detect_image on chunks of frames: letterbox -> program -> decode -> NMS -> person boxes."""
 
     def __init__(self, ctx: L.Context, sd: dict, src_h: int, src_w: int, max_frames: int = 8, size: int = 416,
-                 num_classes: int = 80, score: float = 0.5, iou: float = 0.5, max_boxes: int = 200, anchors=ANCHORS):
+                 num_classes: int = 80, score: float = 0.5, iou: float = 0.5, max_boxes: int = 200, anchors=ANCHORS, numerics=None):
         self.ctx, self.size, self.nc = ctx, size, num_classes
         self.src = (src_h, src_w)
         self.score, self.iou, self.max_boxes = score, iou, max_boxes
         self.anchors = np.asarray(anchors, np.float32)
         self.prog = build_yolov4_program(sd, size, num_classes)
-        self.net = Net(ctx, self.prog, max_batch=max_frames)
+        self.net = Net(ctx, self.prog, max_batch=max_frames, numerics=numerics)
         self.max_frames = max_frames
         self.nw, self.nh = letterbox_geometry(src_h, src_w, size)
         self.xtab, self.kx = pil_bicubic_table(src_w, self.nw)

@@ -181,7 +181,7 @@ class YoloXDetector:
     """mmdet YOLOX.simple_test(rescale=True) on chunks of frames: resize / pad -> program -> decode -> NMS."""
 
     def __init__(self, ctx: L.Context, sd: dict, src_h: int, src_w: int, max_frames: int = 4, scale=(800, 1440),
-                 score_thr: float = 0.01, iou_thr: float = 0.7):
+                 score_thr: float = 0.01, iou_thr: float = 0.7, numerics=None):
         self.ctx, self.src = ctx, (src_h, src_w)
         dims = [C.c_int32() for _ in range(4)]
         L.check(ctx.lib.pp_rescale_size(src_h, src_w, max(scale), min(scale), 32, *[C.byref(d) for d in dims]), "pp_rescale_size")
@@ -189,7 +189,7 @@ class YoloXDetector:
         self.scale_factor = np.array([self.nw / src_w, self.nh / src_h, self.nw / src_w, self.nh / src_h], np.float32)
         self.score_thr, self.iou_thr = score_thr, iou_thr
         self.prog = build_yolox_program(sd, self.hp, self.wp)
-        self.net = Net(ctx, self.prog, max_batch=max_frames)
+        self.net = Net(ctx, self.prog, max_batch=max_frames, numerics=numerics)
         self.max_frames = max_frames
         self.lut = np.ascontiguousarray(np.tile(np.arange(256, dtype=np.float32), (3, 1)))     # mean 0, std 1
         self.priors = []

@@ -102,8 +102,11 @@ class _Gather:
         import torch
         self.world = dist.get_world_size()
         self.shape = local.shape
-        t = torch.from_numpy(np.ascontiguousarray(local, np.float32)).to(device, non_blocking=True).reshape(-1)
-        self.out = torch.empty(self.world * t.numel(), dtype=torch.float32, device=device)
+        # the slab keeps its dtype when torch can carry it (float32 / float64 / int64 / int32); anything else travels as float32
+        if local.dtype not in (np.float32, np.float64, np.int64, np.int32):
+            local = local.astype(np.float32)
+        t = torch.from_numpy(np.ascontiguousarray(local)).to(device, non_blocking=True).reshape(-1)
+        self.out = torch.empty(self.world * t.numel(), dtype=t.dtype, device=device)
         self.src = t                       # kept alive until the collective has finished
         fn = getattr(dist, "all_gather_into_tensor", None)
         if fn is not None:
@@ -120,12 +123,22 @@ class _Gather:
 
 def all_gather_ragged(local: np.ndarray, counts, dist, device="cpu") -> np.ndarray:
     """all_gather of per-rank arrays whose leading dim differs (counts[r] rows on rank r): pad to the max,
-    one collective, trim.  Returns the concatenation in rank order."""
+    one collective, trim.  Returns the concatenation in rank order, in the INPUT's dtype (float32 / float64 / int32 / int64
+    travel as they are -- indices stay exact; other dtypes are gathered as float32)."""
     m = max(max(counts), 1)
-    pad = np.zeros((m,) + local.shape[1:], dtype=np.float32)
+    local = np.asarray(local)
+    pad = np.zeros((m,) + local.shape[1:], dtype=local.dtype if local.dtype in (np.float32, np.float64, np.int64, np.int32) else np.float32)
     pad[: local.shape[0]] = local
     got = _Gather(dist, device, pad).result()
     return np.concatenate([got[r][: counts[r]] for r in range(len(counts))], axis=0)
+
+
+def _takes_need(fn) -> bool:
+    import inspect
+    try:
+        return "need" in inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
 
 
 def process_video_sharded(dist, n_frames, chunks_fn, detect_fn, associate_fn, topdown_fn, lift_fn, src_hw, device="cpu",
@@ -133,10 +146,14 @@ def process_video_sharded(dist, n_frames, chunks_fn, detect_fn, associate_fn, to
     """Run the cascade on frames [0, n_frames) sharded over the ranks of `dist` (rank r owns the contiguous frames
     [b_r, b_{r+1})).
 
-    chunks_fn(lo, hi)              -> this rank's frames as an ITERABLE of (first_frame, n, handle) chunks covering [lo, hi) in
+    chunks_fn(lo, hi[, need=])     -> this rank's frames as an ITERABLE of (first_frame, n, handle) chunks covering [lo, hi) in
                                       order.  It is called twice -- once for the detection pass, once for the 2D pass -- and
                                       may be lazy (a generator over a FrameStreamer): then only the chunk being processed
                                       (and the one being uploaded) is resident.  Resident shards return the same handles twice.
+                                      If it takes a keyword `need`, the 2D pass passes a list of booleans, one per chunk of the
+                                      first pass: chunk i holds a person-frame of this rank or not.  A lazy source then yields
+                                      (first, n, None) for a chunk that is not needed WITHOUT reading or uploading it (without
+                                      the keyword a lazy source re-reads and re-uploads such chunks just to have them skipped).
     detect_fn(handle, first, n)    -> list (per frame) of [m][5] float32 (x1, y1, x2, y2, score), m <= 100
     associate_fn(dets_all_frames)  -> per frame, tracker rows (track_id, x1, y1, x2, y2, score[, tlwh]); sequential
     topdown_fn(handle, n, idx, boxes) -> [len(idx)][K][3] key points of the person-frames (chunk-local frame idx, tlwh)
@@ -150,6 +167,8 @@ def process_video_sharded(dist, n_frames, chunks_fn, detect_fn, associate_fn, to
     Returns on every rank: dict(tracks = per-frame rows, keypoints / keypoints_3d = {track_id: (first_frame, array)})."""
     import time
     rank, world = dist.get_rank(), dist.get_world_size()
+    # the round slabs carry frame indices and job indices next to float32 payload in ONE float32 tensor per collective: exact below 2^24
+    assert n_frames < 2 ** 24, "frame indices travel in float32 slabs: shard clips of 16.7 M frames or more into several calls"
     b = shard_bounds(n_frames, world)
     lo, hi = b[rank], b[rank + 1]
     t0 = time.perf_counter()
@@ -177,6 +196,7 @@ def process_video_sharded(dist, n_frames, chunks_fn, detect_fn, associate_fn, to
                     round_of[f] = k
         return more
 
+    my_chunks = []                                             # (first, n) of this rank's chunks, in order (what `need` refers to)
     prev, k = None, 0
     while True:
         slab = np.full((max(rows, 1), width), -1.0, np.float32)
@@ -184,6 +204,7 @@ def process_video_sharded(dist, n_frames, chunks_fn, detect_fn, associate_fn, to
         if cur is not None:
             first, n, handle = cur
             assert first == covered and n <= rows, (first, covered, n, rows)
+            my_chunks.append((first, n))
             ta = time.perf_counter()
             dets = detect_fn(handle, first, n)
             t_det += time.perf_counter() - ta
@@ -220,6 +241,7 @@ def process_video_sharded(dist, n_frames, chunks_fn, detect_fn, associate_fn, to
         # ---- pass 2: 2D on the own shard's person-frames, chunk by chunk; every round's rows are gathered asynchronously ---------
         ta = time.perf_counter()
         t_wait = 0.0
+        assert len(jobs) < 2 ** 24, "job indices travel in float32 slabs"
         job_frames = np.array([j[1] for j in jobs], np.int64)
         owner = np.searchsorted(np.asarray(b[1:]), job_frames, side="right")
         # slab height: the most person-frames any (rank, round) computes -- known everywhere: every rank knows every job and,
@@ -238,16 +260,18 @@ def process_video_sharded(dist, n_frames, chunks_fn, detect_fn, associate_fn, to
                     if i >= 0:
                         out[i] = row[:-1].reshape(num_joints, 3).copy()
 
-        it2 = iter(chunks_fn(lo, hi))
+        mine = np.sort(job_frames[owner == rank])
+        need = [bool(np.searchsorted(mine, f0 + n0) > np.searchsorted(mine, f0)) for f0, n0 in my_chunks]
+        it2 = iter(chunks_fn(lo, hi, need=need) if _takes_need(chunks_fn) else chunks_fn(lo, hi))
         prev2 = None
         for k in range(rounds):
             slab = np.full((cap, num_joints * 3 + 1), -1.0, np.float32)
             ks = np.flatnonzero((owner == rank) & (round_of[job_frames] == k))
             if len(ks):
                 first, n, handle = next(it2)
-                while first + n <= job_frames[ks].min():       # chunks without a person-frame are skipped, never uploaded twice
+                while first + n <= job_frames[ks].min():       # chunks without a person-frame are passed over (see `need`)
                     first, n, handle = next(it2)
-                assert ((job_frames[ks] >= first) & (job_frames[ks] < first + n)).all()
+                assert handle is not None and ((job_frames[ks] >= first) & (job_frames[ks] < first + n)).all()
                 idx = (job_frames[ks] - first).astype(np.int32)
                 boxes = np.array([jobs[i][2] for i in ks], np.float64)
                 rows_k = np.asarray(topdown_fn(handle, n, idx, boxes), np.float32).reshape(len(ks), -1)

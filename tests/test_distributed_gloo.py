@@ -169,13 +169,18 @@ def _worker_rounds(rank, world, port, outdir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        events, calls = [], []
+        events, calls, needs = [], [], []
 
-        def lazy_chunks(lo, hi):
+        def lazy_chunks(lo, hi, need=None):
             calls.append((lo, hi))
+            needs.append(need)
 
             def gen():
-                for f in range(lo, hi, 6):
+                for i, f in enumerate(range(lo, hi, 6)):
+                    if need is not None and not need[i]:      # the 2D pass has no person-frame in this chunk: not read, not uploaded
+                        events.append(("skip", f))
+                        yield f, min(6, hi - f), None
+                        continue
                     events.append(("upload", f))
                     yield f, min(6, hi - f), np.arange(f, min(f + 6, hi))
             return gen()
@@ -192,6 +197,13 @@ def _worker_rounds(rank, world, port, outdir):
                                              max_persons=3, timings=tm)
         b = parallel.shard_bounds(N_FRAMES, world)
         assert calls == [(b[rank], b[rank + 1])] * 2 and tm["rounds"] == 4
+        # the second pass told the source which chunks it needs (one flag per chunk of the first pass); a chunk it does not need
+        # was neither uploaded again nor handed to the 2D stage
+        n_chunks = len(range(b[rank], b[rank + 1], 6))
+        assert needs[0] is None and len(needs[1]) == n_chunks
+        second = events[[i for i, e in enumerate(events) if e[0] == "detect"][-1] + 1:]
+        assert {e[1] for e in second if e[0] == "skip"} == {b[rank] + 6 * i for i in range(n_chunks) if not needs[1][i]}
+        assert not {e[1] for e in second if e[0] == "2d"} & {e[1] for e in second if e[0] == "skip"}
         # a chunk is requested only after the previous one was processed (bounded residency): uploads and work alternate
         det = [e for e in events if e[0] in ("upload", "detect")][: 2 * len(range(b[rank], b[rank + 1], 6))]
         assert [e[0] for e in det[:2]] == ["upload", "detect"]
