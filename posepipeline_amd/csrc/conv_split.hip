@@ -34,6 +34,9 @@
 #include <map>
 #include <mutex>
 #include <type_traits>
+#include <vector>
+#include <cstring>
+#include <cstdio>
 
 #include "pp_internal.h"
 
@@ -72,7 +75,50 @@ struct SplitArgs {
     int gx, gy;                           // xcd_remap: logical grid (pixel tiles, channel columns) of the 1-D launch
     int col_major;                        // xcd_remap: an XCD walks its tiles column by column (small inputs) instead of tile by tile
     int epi_lds;                          // conv_split_gemm_kernel: epilogue transposed through LDS (whole 128-byte lines per store)
+    // host-made reciprocals (make_magic / pp_udiv) of the divisors of the tap kernels' index arithmetic: round 4's timeline showed
+    // the ~700 instructions of a workgroup's set-up -- ten 32 / 64-bit division sequences among them -- taking 3.5 - 5k cycles
+    // before the first load was even requested (profiles/r04_w48_timeline_before.txt)
+    unsigned dv_per[2], dv_row[2];        // positions per image / per row of the output-coordinate decode (STREAM: the padded input stream)
+    unsigned dv_tx[2], dv_ty[2], dv_pw[2];   // MODE_TILE: tiles_x, tiles_y, patch pitch
+    unsigned dv_ncol[2], dv_run0[2], dv_run1[2];   // xcd_tile_column: gy, ntiles / 8, ntiles / 8 + 1
+    unsigned dv_ktaps[2], dv_kw[2];       // tap-gather product: ktaps, KW
+#ifdef PP_SPLIT_TIMELINE
+    unsigned long long* dbg;              // diagnosis builds only (tools/build_variant.sh tl -DPP_SPLIT_TIMELINE): 16 x u64 per workgroup
+#endif
 };
+
+// Diagnosis builds (-DPP_SPLIT_TIMELINE, never the shipped library): every workgroup of the tap kernels records s_memtime at entry,
+// after its prologue, after its K loop and at its end, plus where it ran (HW_ID / XCC_ID); the launcher synchronises after each
+// launch and appends the records to $POSEPIPE_SPLIT_TIMELINE (tools/split_timeline.py reads them).
+#ifdef PP_SPLIT_TIMELINE
+#define PP_TL_DECL unsigned long long tl_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PP_TL_MARK(i) do { if (a.dbg) tl_t[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define PP_TL_FLUSH()                                                                                                    \
+    do {                                                                                                                 \
+        if (a.dbg && threadIdx.x == 0) {                                                                                 \
+            unsigned hw, xcc;                                                                                            \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                                            \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                                          \
+            unsigned long long* r = a.dbg + (size_t)blockIdx.x * 16;                                                     \
+            r[0] = blockIdx.x; r[1] = ((unsigned long long)xcc << 32) | hw;                                              \
+            r[2] = tl_t[0]; r[3] = tl_t[1]; r[4] = tl_t[2]; r[5] = tl_t[3]; r[6] = L; r[7] = col;                       \
+            for (int i_ = 4; i_ < 10; ++i_) r[4 + i_] = tl_t[i_];                                                        \
+        }                                                                                                                \
+    } while (0)
+#else
+#define PP_TL_DECL
+#define PP_TL_MARK(i)
+#define PP_TL_FLUSH()
+#endif
+
+// n / d for any 32-bit n through the host-made pair {m, sh} = make_magic(d) (Granlund - Montgomery: k = ceil(log2 d),
+// m = floor(2^32 (2^k - d) / d) + 1, q = (t + ((n - t) >> 1)) >> (k - 1) with t = mulhi(m, n); d == 1 is flagged by sh >= 32):
+// five integer instructions instead of the ~40 of a 32-bit and the ~150 of a 64-bit division sequence
+__device__ __forceinline__ unsigned pp_udiv(unsigned n, const unsigned (&dv)[2]) {
+    const unsigned t = __umulhi(n, dv[0]);
+    const unsigned q = (t + ((n - t) >> 1)) >> (dv[1] & 31u);
+    return dv[1] >= 32u ? n : q;
+}
 
 // Workgroup id -> (tile, channel column) of a 1-D launch of 8 * ceil(ntiles / 8) * ncol ids.  Consecutive ids go round-robin over
 // the 8 XCDs (each with its own L2).  XCD x owns a CONTIGUOUS run of tiles (neighbouring tiles share their halo rows in its L2)
@@ -80,18 +126,19 @@ struct SplitArgs {
 // then comes from HBM once instead of once per column (256 -> 1024 at 40x68 has 8 columns, 512 -> 2048 16).  false: idle id.
 // col_major != 0 (small maps: the whole input sits in the Infinity Cache anyway, and what an XCD's L2 should keep is ONE column's
 // split weights): the XCD walks its run once per column instead -- measured on HRNet's 192 -> 192 at 24x18: 187 vs 166 TFLOP/s.
-__device__ __forceinline__ bool xcd_tile_column(unsigned L, unsigned ntiles, unsigned ncol, unsigned& tile, unsigned& col, int col_major = 0) {
+__device__ __forceinline__ bool xcd_tile_column(unsigned L, const SplitArgs& a, unsigned& tile, unsigned& col) {
+    const unsigned ntiles = (unsigned)a.gx, ncol = (unsigned)a.gy;
     const unsigned xcd = L & 7u, j = L >> 3;
     const unsigned q = ntiles >> 3, r = ntiles & 7u;
     const unsigned run = xcd < r ? q + 1 : q;
     unsigned tj;
-    if (col_major) {
+    if (a.col_major) {
         if (run == 0) return false;
-        col = j / run;
+        col = xcd < r ? pp_udiv(j, a.dv_run1) : pp_udiv(j, a.dv_run0);
         tj = j - col * run;
         if (col >= ncol) return false;
     } else {
-        tj = j / ncol;
+        tj = pp_udiv(j, a.dv_ncol);
         col = j - tj * ncol;
         if (tj >= run) return false;
     }
@@ -204,32 +251,50 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     const int lane = tid & 63;
     const int wave = tid >> 6;
     unsigned L = blockIdx.x, col = blockIdx.y;
+    PP_TL_DECL;
+    PP_TL_MARK(0);
     if (a.xcd_remap) {      // 1-D launch, see xcd_tile_column
-        if (!xcd_tile_column(blockIdx.x, (unsigned)a.gx, (unsigned)a.gy, L, col, a.col_major)) return;
+        if (!xcd_tile_column(blockIdx.x, a, L, col)) return;
     }
     const int cb0 = (int)col * COB;
     const int plane_bytes = 2 * a.NPp * 16;           // [half][pixel] x 16 B
     const int buf_bytes = 3 * plane_bytes;
 
-    // tile origin
+    // tile origin (32-bit throughout: one launch addresses < 4 GiB of input, so positions and pixels stay below 2^30)
     int n = 0, x0 = 0, y0 = 0;
-    long long s0 = 0;                                  // STREAM: first stream position, GEMM: first output pixel
+    unsigned s0 = 0;                                   // STREAM: first stream position, GEMM: first output pixel
     if (a.mode == MODE_TILE) {
-        const int tx = (int)(L % (unsigned)a.tiles_x);
-        const unsigned L2 = L / (unsigned)a.tiles_x;
-        const int ty = (int)(L2 % (unsigned)a.tiles_y);
-        n = (int)(L2 / (unsigned)a.tiles_y);
+        const unsigned L2 = pp_udiv(L, a.dv_tx);
+        const int tx = (int)(L - L2 * (unsigned)a.tiles_x);
+        n = (int)pp_udiv(L2, a.dv_ty);
+        const int ty = (int)(L2 - (unsigned)n * (unsigned)a.tiles_y);
         x0 = tx * a.TW;
         y0 = ty * a.TH;
     } else {
-        s0 = (long long)L * (32 * PXB * NW);
+        s0 = L * (unsigned)(32 * PXB * NW);
     }
 
     // ---- patch loader: slot j of this thread = (patch pixel p, channel quad) -----------------------------------------
+    // Set-up order (round 4): what the FIRST LOADS need comes first and is lean -- the loads are requested before the rest of the
+    // index arithmetic (fragment addresses, output coordinates), whose cost then hides behind their latency
     unsigned goff[NSLOT];
     unsigned vmask[T == 1 ? NSLOT : 1];               // GEMM with taps: bit t = tap t of this slot's pixel lies inside the image
     // LDS byte offset (plane 0) of slot j: woff0 + (NT / 4) * 16 j (NT / 4 pixels further, same quad)
     const int woff0 = ((((tid & 3) >> 1) * a.NPp + (tid >> 2)) * 16 + (tid & 1) * 8);
+    if (a.mode == MODE_STREAM) {
+        // position of slot j = pos0 + (NT / 4) j.  Positions before the stream (first tile only) are masked; positions past it
+        // need no test: their byte offset is past the descriptor's range and reads as zero (x_bytes = the stream's size), and
+        // a slot past the patch (only the last one can be) is loaded but never stored
+        const int pos0 = (int)s0 - a.PWp - 1 + (tid >> 2);
+        const unsigned cin4 = (unsigned)a.Cin * 4u;
+        const unsigned base = (unsigned)pos0 * cin4 + (unsigned)(tid & 3) * 16u;
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) goff[j] = pos0 + (NT / 4) * j < 0 ? 0xffffffffu : base + (unsigned)((NT / 4) * j) * cin4;
+        if constexpr (T == 1) {
+#pragma unroll
+            for (int j = 0; j < NSLOT; ++j) vmask[j] = 0;
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
         const int u = tid + NT * j;
@@ -237,27 +302,24 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         const bool in_patch = p < a.NP;
         unsigned off = 0xffffffffu;
         if (a.mode == MODE_TILE) {
-            const int pr = p / a.PWp, pc = p - pr * a.PWp;
+            const int pr = (int)pp_udiv((unsigned)p, a.dv_pw), pc = p - pr * a.PWp;
             const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
             if (in_patch && pc < a.TW + 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                 off = (unsigned)(((n * a.xp_h + iy) * a.xp_w + ix) * a.Cin) * 4u;
-        } else if (a.mode == MODE_STREAM) {
-            const long long pos = s0 - a.PWp - 1 + p;
-            if (in_patch && pos >= 0 && pos < a.S) off = (unsigned)pos * (unsigned)a.Cin * 4u;
         } else {
-            const long long m = s0 + p;
+            const unsigned m = s0 + (unsigned)p;
             if constexpr (T == 1) vmask[j] = 0;
-            if (in_patch && m < a.S) {
-                const int img = (int)(m / (a.H * a.W)), rem = (int)(m - (long long)img * (a.H * a.W));
-                const int ho = rem / a.W, wo = rem - ho * a.W;
+            if (in_patch && m < (unsigned)a.S) {
+                const int img = (int)pp_udiv(m, a.dv_per), rem = (int)(m - (unsigned)img * (unsigned)(a.H * a.W));
+                const int ho = (int)pp_udiv((unsigned)rem, a.dv_row), wo = rem - ho * a.W;
                 if (T == 1 && a.ktaps > 1) {
                     // origin of the pixel's window (may lie before the image: the offset wraps, a valid tap's sum is exact again)
                     const int iy0 = ho * a.stride - a.pad, ix0 = wo * a.stride - a.pad;
                     off = (unsigned)(((img * a.xp_h + iy0) * a.xp_w + ix0) * a.Cin) * 4u;
                     unsigned vm = 0;
-                    for (int t = 0; t < a.ktaps; ++t) {
-                        const int dy = t / a.KW, dx = t - dy * a.KW;
+                    for (int t = 0, dy = 0, dx = 0; t < a.ktaps; ++t) {
                         if ((unsigned)(iy0 + dy) < (unsigned)a.Hin && (unsigned)(ix0 + dx) < (unsigned)a.Win) vm |= 1u << t;
+                        if (++dx == a.KW) { dx = 0; ++dy; }
                     }
                     if constexpr (T == 1) vmask[j] = vm;
                     if (off == 0xffffffffu) off = 0xfffffffeu;      // (never a multiple of 16; keeps the sentinel unambiguous)
@@ -268,14 +330,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         }
         goff[j] = off == 0xffffffffu ? off : off + (unsigned)quad * 16u;
     }
+    }
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
     float4 xr[NSLOT];
     auto load_patch = [&](int c) {
         unsigned add = (unsigned)c * 64u;
         int tbit = -1;
         if (T == 1 && a.ktaps > 1) {                  // step c = (channel chunk c / ktaps, tap c % ktaps)
-            const int cc = c / a.ktaps, t = c - cc * a.ktaps;
-            const int dy = t / a.KW, dx = t - dy * a.KW;
+            const int cc = (int)pp_udiv((unsigned)c, a.dv_ktaps), t = c - cc * a.ktaps;
+            const int dy = (int)pp_udiv((unsigned)t, a.dv_kw), dx = t - dy * a.KW;
             add = (unsigned)(((dy * a.xp_w + dx) * a.Cin + 16 * cc) * 4);
             tbit = t;
         }
@@ -305,8 +368,50 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
             *reinterpret_cast<uint2*>(d + 2 * plane_bytes) = p2;
         }
     };
+    // ---- the first requests: weights of the first steps (DMA ring) / first step (registers), patch of chunk 0 -----------------
+    PP_TL_MARK(4);
+    constexpr int WSLOT = COB * 3 * 1024;
+    constexpr int NDMA = (COB * 3 + NW - 1) / NW;  // 1 KB fragments each wave copies per step (8 waves: 1; 4 waves: 2 / 1 for COB 2 / 1)
+    const unsigned wring = (unsigned)((RING4 ? 1 : 2) * buf_bytes);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int nsteps = a.nchunks * T;
+    const size_t wstep = (size_t)a.ncb * 3 * 64;       // uint4 per step
+    // step s = chunk * T + tap.  Ring slot s & 3 holds the COB x 3 fragments of step s.
+    auto issue_w = [&](int step) {
+        if (step >= nsteps) return;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int myslab = (wave + NW * i) % (COB * 3);      // (waves past COB * 3 copy a duplicate: same bytes, same place)
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + wring + (unsigned)((step & 3) * WSLOT + myslab * 1024));
+            const uint4* g = a.w + (size_t)cb0 * 192 + myslab * 64 + lane + (size_t)step * wstep;
+            // raw instruction, see conv_split_gemm_kernel: the builtin makes the compiler order every later ds_read behind vmcnt(0)
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory", "m0");
+        }
+    };
+    // weights: fragment (step, channel block cb, plane) at ((step * ncb + cb) * 3 + plane) * 64 + lane, step = chunk * T + tap
+    const uint4* wlane = a.w + (size_t)cb0 * 3 * 64 + lane;
+    uint4 wf[2][COB][3];
+    uint4 xf[PXB][3];
+    const uint4* wp = wlane;                           // weights of the next step to fetch (one spare step at the end of the buffer)
+    auto load_w = [&](uint4 (&dst)[COB][3]) {
+#pragma unroll
+        for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) dst[cb][pl] = wp[(cb * 3 + pl) * 64];
+        wp += wstep;
+    };
+    if constexpr (WLDS) {
+        issue_w(0);
+        issue_w(1);
+        issue_w(2);
+        load_patch(0);
+    } else {
+        load_patch(0);
+        load_w(wf[0]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- operand addresses and output pixels -------------------------------------------------------------------------------
+    // ---- operand addresses and output pixels (behind the first loads) ------------------------------------------------------------
     int aofs[PXB];           // LDS byte offset of this lane's pixel (tap (0,0), plane 0) per pixel block
     int on[PXB], oy[PXB], ox[PXB];
     bool ook[PXB];
@@ -326,25 +431,26 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
             ook[pb] = oy[pb] < a.H && ox[pb] < a.W;
         }
     } else {
+        // STREAM: (image, row, column) of a position of the padded input stream; GEMM: of an output pixel (dv_per / dv_row hold
+        // the reciprocals of the positions per image / per row of that mode)
+        const unsigned per = a.mode == MODE_STREAM ? (unsigned)(a.xp_h * a.PWp) : (unsigned)(a.H * a.W);
+        const unsigned row = a.mode == MODE_STREAM ? (unsigned)a.PWp : (unsigned)a.W;
 #pragma unroll
         for (int pb = 0; pb < PXB; ++pb) {
             const int pl = (wave * PXB + pb) * 32 + (lane & 31);
             aofs[pb] = (((lane >> 5) * a.NPp) + pl) * 16;
-            const long long s = s0 + pl;
-            const bool in = s < a.S;
-            const long long sc = in ? s : 0;
-            const int per = a.mode == MODE_STREAM ? a.xp_h * a.PWp : a.H * a.W;
-            const int row = a.mode == MODE_STREAM ? a.PWp : a.W;
-            on[pb] = (int)(sc / per);
-            const int rem = (int)(sc - (long long)on[pb] * per);
-            oy[pb] = rem / row;
-            ox[pb] = rem - oy[pb] * row;
+            const unsigned sp = s0 + (unsigned)pl;
+            const bool in = sp < (unsigned)a.S;
+            const unsigned sc = in ? sp : 0u;
+            const unsigned img = pp_udiv(sc, a.dv_per);
+            const unsigned rem = sc - img * per;
+            const unsigned yy = pp_udiv(rem, a.dv_row);
+            on[pb] = (int)img;
+            oy[pb] = (int)yy;
+            ox[pb] = (int)(rem - yy * row);
             ook[pb] = in && oy[pb] < a.H && ox[pb] < a.W;
         }
     }
-    // weights: fragment (step, channel block cb, plane) at ((step * ncb + cb) * 3 + plane) * 64 + lane, step = chunk * T + tap
-    const uint4* wlane = a.w + (size_t)cb0 * 3 * 64 + lane;
-    const size_t wstep = (size_t)a.ncb * 3 * 64;       // uint4 per step
 
     f32x16 acc[COB][PXB];
 #pragma unroll
@@ -354,16 +460,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
 
-    uint4 wf[2][COB][3];
-    uint4 xf[PXB][3];
-    const uint4* wp = wlane;                           // weights of the next step to fetch (one spare step at the end of the buffer)
-    auto load_w = [&](uint4 (&dst)[COB][3]) {
-#pragma unroll
-        for (int cb = 0; cb < COB; ++cb)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) dst[cb][pl] = wp[(cb * 3 + pl) * 64];
-        wp += wstep;
-    };
     auto load_x = [&](const unsigned char* pbuf, int t, int pb) {
         const int toff = T == 9 ? ((t / 3) * a.PWp + (t % 3)) * 16 : 0;
 #pragma unroll
@@ -372,9 +468,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
 
     // ---- prologue (4 waves; the 8-wave form has its own below) -------------------------------------------------------------
     if constexpr (!WLDS) {
-        load_patch(0);
-        load_w(wf[0]);
-        store_patch(0, 0, NSLOT);
+        store_patch(0, 0, NSLOT);                      // (patch 0 and the first weights were requested above)
+        PP_TL_MARK(5);
         if (a.nchunks > 1) load_patch(1);
         __syncthreads();
 #pragma unroll
@@ -399,22 +494,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         // s + 1 are read into the other register set (they landed before the barrier that ended step s - 1), the DMA of step
         // s + 3 is issued into the slot step s - 1 used, and before the closing barrier the DMA of step s + 2 is awaited -- by
         // counting: vmcnt is in issue order, so "all but the DMA of s + 3 and the patch loads issued after it" have landed.
-        constexpr int WSLOT = COB * 3 * 1024;
-        constexpr int NDMA = (COB * 3 + NW - 1) / NW;  // 1 KB fragments each wave copies per step (8 waves: 1; 4 waves: 2 / 1 for COB 2 / 1)
-        const unsigned wring = (unsigned)((RING4 ? 1 : 2) * buf_bytes);
-        const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-        const int nsteps = a.nchunks * T;
-        auto issue_w = [&](int step) {
-            if (step >= nsteps) return;
-#pragma unroll
-            for (int i = 0; i < NDMA; ++i) {
-                const int myslab = (wave + NW * i) % (COB * 3);      // (waves past COB * 3 copy a duplicate: same bytes, same place)
-                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + wring + (unsigned)((step & 3) * WSLOT + myslab * 1024));
-                const uint4* g = a.w + (size_t)cb0 * 192 + myslab * 64 + lane + (size_t)step * wstep;
-                // raw instruction, see conv_split_gemm_kernel: the builtin makes the compiler order every later ds_read behind vmcnt(0)
-                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory", "m0");
-            }
-        };
         auto read_w = [&](int step, uint4 (&dst)[COB][3]) {
             const unsigned char* base = smem + wring + (step & 3) * WSLOT + lane * 16;
 #pragma unroll
@@ -432,11 +511,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
             else if (n == NDMA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         };
-        issue_w(0);
-        issue_w(1);
-        issue_w(2);
-        load_patch(0);
+        // (the DMAs of steps 0 - 2 and patch 0 were requested above, in this order)
         store_patch(0, 0, NSLOT);                      // waits for patch 0, hence (in order) for the three DMAs before it
+        PP_TL_MARK(5);
         if (a.nchunks > 1) load_patch(1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -528,6 +605,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
                 for (int pb = 0; pb < PXB; ++pb) load_x(smem, 0, pb);
             }
         };
+        PP_TL_MARK(1);
         if constexpr (RING4) {
             int c4 = 0;
             for (; c4 + 1 < a.nchunks; c4 += 2) {
@@ -588,6 +666,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         if (c + 2 < a.nchunks) load_patch(c + 2);
 #endif
     };
+    PP_TL_MARK(1);
     int c = 0;
     for (; c + 1 < a.nchunks; c += 2) {
         chunk(std::integral_constant<int, 0>{}, c);
@@ -595,6 +674,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     }
     if (c < a.nchunks) chunk(std::integral_constant<int, 0>{}, c);
     }   // !WLDS
+    PP_TL_MARK(2);
 
     // ---- epilogue: bias, residuals, ReLU; accumulator register i of a lane = channel 8 (i / 4) + 4 (lane / 32) + i % 4 ---
 #if (PP_SPLIT_ABLATE & 32)
@@ -649,6 +729,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
                 if (a.res1) { v.x += rv[pb][cb][g].x; v.y += rv[pb][cb][g].y; v.z += rv[pb][cb][g].z; v.w += rv[pb][cb][g].w; }
                 rv[pb][cb][g] = v;
             }
+    PP_TL_MARK(6);
     if (a.res2) {
 #pragma unroll
         for (int pb = 0; pb < PXB; ++pb)
@@ -670,6 +751,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
                 if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 if (ook[pb] && cok[cb][g]) *reinterpret_cast<float4*>(a.y + ypix[pb] * a.Cout + cos[cb][g]) = v;
             }
+    PP_TL_MARK(3);
+#ifdef PP_SPLIT_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_TL_MARK(7);
+#endif
+    PP_TL_FLUSH();
 }
 
 // ---- 3x3 layers with 33 .. 48 output channels (HRNet-W48's first branch: 27 % of the program) -----------------------------------
@@ -692,43 +779,48 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
     const int lane = tid & 63;
     const int wave = tid >> 6;
     unsigned L = blockIdx.x, col = blockIdx.y;
+    PP_TL_DECL;
+    PP_TL_MARK(0);
     if (a.xcd_remap) {
-        if (!xcd_tile_column(blockIdx.x, (unsigned)a.gx, (unsigned)a.gy, L, col, a.col_major)) return;
+        if (!xcd_tile_column(blockIdx.x, a, L, col)) return;
     }
     const int cbase = (int)col * CB;                  // first 16-channel block of this workgroup (a.ncb blocks in all)
     const int plane_bytes = 2 * a.NPp * 16;
     const int buf_bytes = 3 * plane_bytes;
     int n = 0, x0 = 0, y0 = 0;
-    long long s0 = 0;
+    unsigned s0 = 0;
     if (a.mode == MODE_TILE) {
-        const int tx = (int)(L % (unsigned)a.tiles_x);
-        const unsigned L2 = L / (unsigned)a.tiles_x;
-        const int ty = (int)(L2 % (unsigned)a.tiles_y);
-        n = (int)(L2 / (unsigned)a.tiles_y);
+        const unsigned L2 = pp_udiv(L, a.dv_tx);
+        const int tx = (int)(L - L2 * (unsigned)a.tiles_x);
+        n = (int)pp_udiv(L2, a.dv_ty);
+        const int ty = (int)(L2 - (unsigned)n * (unsigned)a.tiles_y);
         x0 = tx * a.TW;
         y0 = ty * a.TH;
     } else {
-        s0 = (long long)L * 256;
+        s0 = L * 256u;
     }
-    // ---- patch loader (as conv_split_kernel) ------------------------------------------------------------------------------------
+    // ---- patch loader (as conv_split_kernel: the first loads are requested before the rest of the index arithmetic) -------------
     unsigned goff[NSLOT];
     const int woff0 = ((((tid & 3) >> 1) * a.NPp + (tid >> 2)) * 16 + (tid & 1) * 8);
+    if (a.mode == MODE_STREAM) {
+        const int pos0 = (int)s0 - a.PWp - 1 + (tid >> 2);
+        const unsigned cin4 = (unsigned)a.Cin * 4u;
+        const unsigned base = (unsigned)pos0 * cin4 + (unsigned)(tid & 3) * 16u;
 #pragma unroll
-    for (int j = 0; j < NSLOT; ++j) {
-        const int u = tid + NT * j;
-        const int p = u >> 2, quad = u & 3;
-        const bool in_patch = p < a.NP;
-        unsigned off = 0xffffffffu;
-        if (a.mode == MODE_TILE) {
-            const int pr = p / a.PWp, pc = p - pr * a.PWp;
+        for (int j = 0; j < NSLOT; ++j) goff[j] = pos0 + (NT / 4) * j < 0 ? 0xffffffffu : base + (unsigned)((NT / 4) * j) * cin4;
+    } else {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) {
+            const int u = tid + NT * j;
+            const int p = u >> 2, quad = u & 3;
+            const bool in_patch = p < a.NP;
+            unsigned off = 0xffffffffu;
+            const int pr = (int)pp_udiv((unsigned)p, a.dv_pw), pc = p - pr * a.PWp;
             const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
             if (in_patch && pc < a.TW + 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                 off = (unsigned)(((n * a.xp_h + iy) * a.xp_w + ix) * a.Cin) * 4u;
-        } else {
-            const long long pos = s0 - a.PWp - 1 + p;
-            if (in_patch && pos >= 0 && pos < a.S) off = (unsigned)pos * (unsigned)a.Cin * 4u;
+            goff[j] = off == 0xffffffffu ? off : off + (unsigned)quad * 16u;
         }
-        goff[j] = off == 0xffffffffu ? off : off + (unsigned)quad * 16u;
     }
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
     float4 xr[NSLOT];
@@ -752,6 +844,22 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
             *reinterpret_cast<uint2*>(d + 2 * plane_bytes) = p2;
         }
     };
+    // weights: fragment (step, block cb, plane) at ((step * ncb + cb) * 3 + plane) * 64 + lane, step = chunk * 5 + pair
+    const uint4* wp = a.w + (size_t)cbase * 3 * 64 + lane;
+    const size_t wstep = (size_t)a.ncb * 3 * 64;
+    uint4 wf[2][CB][3];
+    auto load_w = [&](uint4 (&dst)[CB][3]) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) dst[cb][pl] = wp[(cb * 3 + pl) * 64];
+        wp += wstep;
+    };
+    // ---- the first requests ---------------------------------------------------------------------------------------------------------
+    PP_TL_MARK(4);
+    load_patch(0);
+    load_w(wf[0]);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- operand addresses and output pixels: sub-block sb = 2 * (32-pixel block of the wave) + half ------------------------------
     // (the output coordinates are recomputed in the epilogue: 16 registers less across the K loop)
     const int khalf = (lane >> 4) & 1;
@@ -771,14 +879,15 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
         } else {
             const int pl = b * 32 + r;
             aof = ((khalf * a.NPp) + pl) * 16;
-            const long long sp = s0 + pl;
-            const bool in = sp < a.S;
-            const long long sc = in ? sp : 0;
-            const int per = a.xp_h * a.PWp, row = a.PWp;
-            on_ = (int)(sc / per);
-            const int rem = (int)(sc - (long long)on_ * per);
-            oy_ = rem / row;
-            ox_ = rem - oy_ * row;
+            const unsigned sp = s0 + (unsigned)pl;
+            const bool in = sp < (unsigned)a.S;
+            const unsigned sc = in ? sp : 0u;
+            const unsigned img = pp_udiv(sc, a.dv_per);
+            const unsigned rem = sc - img * (unsigned)(a.xp_h * a.PWp);
+            const unsigned yy = pp_udiv(rem, a.dv_row);
+            on_ = (int)img;
+            oy_ = (int)yy;
+            ox_ = (int)(rem - yy * (unsigned)a.PWp);
             ok = in && oy_ < a.H && ox_ < a.W;
         }
     };
@@ -797,23 +906,12 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
         const int t = min(2 * q + (lane >> 5), 8);
         tofs[q] = ((t / 3) * a.PWp + (t % 3)) * 16;
     }
-    // weights: fragment (step, block cb, plane) at ((step * ncb + cb) * 3 + plane) * 64 + lane, step = chunk * 5 + pair
-    const uint4* wp = a.w + (size_t)cbase * 3 * 64 + lane;
-    const size_t wstep = (size_t)a.ncb * 3 * 64;
     f32x4 acc[CB][SB];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int sb = 0; sb < SB; ++sb) acc[cb][sb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint4 wf[2][CB][3];
     uint4 xf[2][3];          // the B fragments of sub-block sb live in set sb & 1; the next sub-block's are read during this one's MFMAs
-    auto load_w = [&](uint4 (&dst)[CB][3]) {
-#pragma unroll
-        for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) dst[cb][pl] = wp[(cb * 3 + pl) * 64];
-        wp += wstep;
-    };
     auto load_x = [&](const unsigned char* pbuf, int q, int sb) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) xf[sb & 1][pl] = *reinterpret_cast<const uint4*>(pbuf + pl * plane_bytes + aofs[sb] + tofs[q]);
@@ -828,9 +926,8 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
                                                                       __builtin_bit_cast(bf16x8, xf[sb & 1][XI[p]]), acc[cb][sb], 0, 0, 0);
     };
     // ---- prologue ---------------------------------------------------------------------------------------------------------------
-    load_patch(0);
-    load_w(wf[0]);
-    store_patch(0);
+    store_patch(0);              // (patch 0 and the first weights were requested above)
+    PP_TL_MARK(5);
     if (a.nchunks > 1) load_patch(1);
     __syncthreads();
     load_x(smem, 0, 0);
@@ -858,12 +955,14 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
         if (c + 1 < a.nchunks) load_x(smem + ((c + 1) & 1) * buf_bytes, 0, 0);
         if (c + 2 < a.nchunks) load_patch(c + 2);
     };
+    PP_TL_MARK(1);
     int c = 0;
     for (; c + 1 < a.nchunks; c += 2) {           // 5 steps per chunk: the register-set parity alternates per chunk
         chunk(std::integral_constant<int, 0>{}, c);
         chunk(std::integral_constant<int, 1>{}, c + 1);
     }
     if (c < a.nchunks) chunk(std::integral_constant<int, 0>{}, c);
+    PP_TL_MARK(2);
     // ---- epilogue: accumulator register i of a lane = channel 16 cb + 4 (lane >> 4) + i of pixel (lane & 15) -------------------------
     bool cok[CB];
     int cos[CB];
@@ -905,6 +1004,7 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
             if (a.res1) { v.x += rv[sb][cb].x; v.y += rv[sb][cb].y; v.z += rv[sb][cb].z; v.w += rv[sb][cb].w; }
             rv[sb][cb] = v;
         }
+    PP_TL_MARK(6);
     if (a.res2) {
 #pragma unroll
         for (int sb = 0; sb < SB; ++sb)
@@ -922,6 +1022,12 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
             if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             if (ook[sb] && cok[cb]) *reinterpret_cast<float4*>(a.y + ypix[sb] * a.Cout + cos[cb]) = v;
         }
+    PP_TL_MARK(3);
+#ifdef PP_SPLIT_TIMELINE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_TL_MARK(7);
+#endif
+    PP_TL_FLUSH();
 }
 
 // split weights of the 48-channel form: [chunk][pair][16-channel block][plane][lane] x 16 B; lane = (k group g = lane >> 4: tap
@@ -990,9 +1096,13 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     unsigned bx = blockIdx.x, by = blockIdx.y;
+    PP_TL_DECL;
+    PP_TL_MARK(0);
     if (a.xcd_remap) {      // 1-D launch, see xcd_tile_column
-        if (!xcd_tile_column(blockIdx.x, (unsigned)a.gx, (unsigned)a.gy, bx, by)) return;
+        if (!xcd_tile_column(blockIdx.x, a, bx, by)) return;
     }
+    const unsigned L = bx, col = by;      // (names the timeline record uses)
+    (void)L; (void)col;
     const long long m0 = (long long)bx * BM;
     const int cbB = by * (BN / 32);                  // first channel block of the workgroup
     const int cb0 = cbB + wn * 2;                    // ... of this wave
@@ -1005,8 +1115,8 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
         const long long m = m0 + (u >> 2);
         unsigned off = 0xffffffffu;
         if (m < a.S) {
-            const int img = (int)(m / (a.H * a.W)), rem = (int)(m - (long long)img * (a.H * a.W));
-            const int ho = rem / a.W, wo = rem - ho * a.W;
+            const int img = (int)pp_udiv((unsigned)m, a.dv_per), rem = (int)((unsigned)m - (unsigned)img * (unsigned)(a.H * a.W));
+            const int ho = (int)pp_udiv((unsigned)rem, a.dv_row), wo = rem - ho * a.W;
             off = (unsigned)(((img * a.xp_h + ho * a.stride) * a.xp_w + wo * a.stride) * a.Cin) * 4u + (unsigned)(u & 3) * 16u;
         }
         goff[j] = off;
@@ -1068,13 +1178,16 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
 
     // vmcnt counts in issue order: a stage issues its weight DMA first and its pixel loads (for the stage after next) after it, so
     // "all but the XS youngest" = the DMA has landed while the pixel loads keep flying across the barrier
+    PP_TL_MARK(4);
     issue_w(0, 0);
     load_x(0);
     store_x(0);
+    PP_TL_MARK(5);
     if (a.nchunks > 1) load_x(1);
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(XS) : "memory");
     if (a.nchunks <= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    PP_TL_MARK(1);
 
     for (int c = 0; c < a.nchunks; ++c) {
         const unsigned char* sb = smem + (c & 1) * STAGE;
@@ -1116,6 +1229,8 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
         __builtin_amdgcn_s_barrier();
     }
 
+    PP_TL_MARK(2);
+    PP_TL_MARK(6);
     // ---- epilogue, transposed through LDS (a.epi_lds) ----------------------------------------------------------------------------
     // A lane holds 4 consecutive channels of ONE pixel (lane & 31): stored from the registers, an instruction touches 32 pixels with
     // 32 bytes each.  The stages are free here (every wave passed the loop's last barrier after its last fragment read), so each
@@ -1132,8 +1247,8 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
             const long long m = m0 + wm * 128 + p;
             uint4 t = make_uint4(0u, 0u, 0u, 0u);
             if (m < a.S) {
-                const int img = (int)(m / (a.H * a.W)), rem = (int)(m - (long long)img * (a.H * a.W));
-                const int oy = rem / a.W, ox = rem - oy * a.W;
+                const int img = (int)pp_udiv((unsigned)m, a.dv_per), rem = (int)((unsigned)m - (unsigned)img * (unsigned)(a.H * a.W));
+                const int oy = (int)pp_udiv((unsigned)rem, a.dv_row), ox = rem - oy * a.W;
                 t.x = (unsigned)(((size_t)img * (a.H + a.y_pad) + oy) * (a.W + a.y_pad) + ox);
                 t.y = (unsigned)(((size_t)img * (a.r1_H + a.r1_pad) + (oy >> a.r1_shift)) * (a.r1_W + a.r1_pad) + (ox >> a.r1_shift));
                 t.z = (unsigned)(((size_t)img * (a.H + a.r2_pad) + oy) * (a.W + a.r2_pad) + ox);
@@ -1156,25 +1271,42 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
                     else if (a.relu >= PP_ACT_LEAKY) { v.x = split_activate(v.x, a.relu); v.y = split_activate(v.y, a.relu); v.z = split_activate(v.z, a.relu); v.w = split_activate(v.w, a.relu); }
                     *reinterpret_cast<float4*>(stg + (pb * 32 + (lane & 31)) * 128 + (((2 * g + (lane >> 5)) ^ (lane & 7)) << 4)) = v;
                 }
+            // the 16 residual lines of this channel block are requested back to back (from clamped, always valid addresses) before
+            // any of them is consumed: ONE memory round trip per residual and channel block instead of sixteen in a row -- round
+            // 4's timeline put the epilogue of the residual layers (256 -> 1024 at 40x68) at the length of their K loop
+            const int co = (cb0 + cb) * 32 + rdchunk * 4;
+            const unsigned* tabw = reinterpret_cast<const unsigned*>(tab);
+            float4 vv[16];
+#pragma unroll
+            for (int it = 0; it < 16; ++it) vv[it] = *reinterpret_cast<const float4*>(stg + (it * 8 + rdrow) * 128 + rdpos * 16);
+            if (a.res1) {
+                float4 rv[16];
+#pragma unroll
+                for (int it = 0; it < 16; ++it) rv[it] = *reinterpret_cast<const float4*>(a.res1 + (size_t)tabw[(it * 8 + rdrow) * 4 + 1] * a.Cout + co);
+#pragma unroll
+                for (int it = 0; it < 16; ++it) { vv[it].x += rv[it].x; vv[it].y += rv[it].y; vv[it].z += rv[it].z; vv[it].w += rv[it].w; }
+            }
+            if (a.res2) {
+                float4 rv[16];
+#pragma unroll
+                for (int it = 0; it < 16; ++it) rv[it] = *reinterpret_cast<const float4*>(a.res2 + (size_t)tabw[(it * 8 + rdrow) * 4 + 2] * a.Cout + co);
+#pragma unroll
+                for (int it = 0; it < 16; ++it) { vv[it].x += rv[it].x; vv[it].y += rv[it].y; vv[it].z += rv[it].z; vv[it].w += rv[it].w; }
+            }
 #pragma unroll
             for (int it = 0; it < 16; ++it) {
-                const int row = it * 8 + rdrow;
-                float4 v = *reinterpret_cast<const float4*>(stg + row * 128 + rdpos * 16);
-                const uint4 t = tab[row];
-                if (!t.w) continue;
-                const int co = (cb0 + cb) * 32 + rdchunk * 4;
-                if (a.res1) {
-                    const float4 r = *reinterpret_cast<const float4*>(a.res1 + (size_t)t.y * a.Cout + co);
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                }
-                if (a.res2) {
-                    const float4 r = *reinterpret_cast<const float4*>(a.res2 + (size_t)t.z * a.Cout + co);
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                }
+                float4 v = vv[it];
                 if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                *reinterpret_cast<float4*>(a.y + (size_t)t.x * a.Cout + co) = v;
+                const uint2 t = *reinterpret_cast<const uint2*>(tabw + (it * 8 + rdrow) * 4);     // .x: output pixel; then (.w via the next read)
+                if (tabw[(it * 8 + rdrow) * 4 + 3]) *reinterpret_cast<float4*>(a.y + (size_t)t.x * a.Cout + co) = v;
             }
         }
+        PP_TL_MARK(3);
+#ifdef PP_SPLIT_TIMELINE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PP_TL_MARK(7);
+#endif
+        PP_TL_FLUSH();
         return;
     }
 
@@ -1183,8 +1315,8 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
     for (int pb = 0; pb < 4; ++pb) {
         const long long m = m0 + wm * 128 + pb * 32 + (lane & 31);
         if (m >= a.S) continue;
-        const int img = (int)(m / (a.H * a.W)), rem = (int)(m - (long long)img * (a.H * a.W));
-        const int oy = rem / a.W, ox = rem - oy * a.W;
+        const int img = (int)pp_udiv((unsigned)m, a.dv_per), rem = (int)((unsigned)m - (unsigned)img * (unsigned)(a.H * a.W));
+        const int oy = (int)pp_udiv((unsigned)rem, a.dv_row), ox = rem - oy * a.W;
         const size_t ypix = ((size_t)img * (a.H + a.y_pad) + oy) * (a.W + a.y_pad) + ox;
         const size_t r1pix = ((size_t)img * (a.r1_H + a.r1_pad) + (oy >> a.r1_shift)) * (a.r1_W + a.r1_pad) + (ox >> a.r1_shift);
         const size_t r2pix = ((size_t)img * (a.H + a.r2_pad) + oy) * (a.W + a.r2_pad) + ox;
@@ -1253,6 +1385,15 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* w, uint
         o.w = h[pl][6] | ((unsigned)h[pl][7] << 16);
         out[(frag + pl) * 64 + lane] = o;
     }
+}
+
+// {m, sh} for pp_udiv (device): n / d for every 32-bit n; d == 1 is flagged by sh = 32
+void make_magic(unsigned d, unsigned (&dv)[2]) {
+    if (d <= 1) { dv[0] = 0; dv[1] = 32; return; }
+    unsigned k = 0;
+    while ((1ull << k) < d) ++k;                                   // k = ceil(log2 d), 1 <= k <= 32
+    dv[0] = (unsigned)((((1ull << k) - d) << 32) / d + 1);
+    dv[1] = k - 1;
 }
 
 int env_int(const char* name, int dflt) {
@@ -1399,6 +1540,60 @@ int pp_conv_split_weights(const ConvArgs& a, void* out, hipStream_t stream) {
     return PP_OK;
 }
 
+#ifdef PP_SPLIT_TIMELINE
+// diagnosis builds: one record buffer, sized for the largest grid; tl_begin hands it to the launch, tl_end synchronises and appends
+// "launch header + records" to the file named by $POSEPIPE_SPLIT_TIMELINE (only layers with Cin == $POSEPIPE_SPLIT_TIMELINE_CIN if set)
+static unsigned long long* tl_buf = nullptr;
+static const size_t TL_MAX_WG = 1 << 19;
+static unsigned long long* tl_begin(const ConvArgs& a, hipStream_t stream) {
+    static const char* path = getenv("POSEPIPE_SPLIT_TIMELINE");
+    static const int only_cin = env_int("POSEPIPE_SPLIT_TIMELINE_CIN", 0);
+    static const int max_launches = env_int("POSEPIPE_SPLIT_TIMELINE_MAX", 300);
+    static int recorded = 0;
+    if (!path || (only_cin && a.Cin != only_cin) || recorded >= max_launches) return nullptr;
+    ++recorded;
+    if (!tl_buf && hipMalloc(&tl_buf, TL_MAX_WG * 128) != hipSuccess) return nullptr;
+    (void)hipMemsetAsync(tl_buf, 0, TL_MAX_WG * 128, stream);
+    return tl_buf;
+}
+static void tl_end(const ConvArgs& a, const SplitArgs& s, const char* kernel, unsigned nwg, hipStream_t stream) {
+    if (!s.dbg) return;
+    (void)hipStreamSynchronize(stream);
+    nwg = std::min<unsigned>(nwg, TL_MAX_WG);
+    std::vector<unsigned long long> h((size_t)nwg * 16);
+    (void)hipMemcpy(h.data(), tl_buf, h.size() * 8, hipMemcpyDeviceToHost);
+    static int launch = 0;
+    FILE* f = fopen(getenv("POSEPIPE_SPLIT_TIMELINE"), "ab");
+    if (!f) return;
+    long long hdr[16] = {0x54494d454c494e45ll, launch++, (long long)nwg, a.N, a.Hout, a.Wout, a.Cin, a.Cout, s.mode, s.nchunks, s.gx, s.gy,
+                         a.res1 != nullptr, a.res2 != nullptr, 0, 0};
+    memcpy(&hdr[14], kernel, std::min<size_t>(strlen(kernel), 15));
+    fwrite(hdr, 8, 16, f);
+    fwrite(h.data(), 8, h.size(), f);
+    fclose(f);
+}
+#define PP_TL_BEGIN() s.dbg = tl_begin(a, stream)
+#define PP_TL_END(name, nwg) tl_end(a, s, name, nwg, stream)
+#else
+#define PP_TL_BEGIN()
+#define PP_TL_END(name, nwg)
+#endif
+
+// the reciprocals the kernels divide by (pp_udiv), from the launch's final geometry
+static void fill_divisors(SplitArgs& s) {
+    const bool stream_mode = s.mode == MODE_STREAM;
+    make_magic(stream_mode ? (unsigned)(s.xp_h * s.PWp) : (unsigned)(s.H * s.W), s.dv_per);
+    make_magic(stream_mode ? (unsigned)s.PWp : (unsigned)s.W, s.dv_row);
+    make_magic((unsigned)std::max(s.tiles_x, 1), s.dv_tx);
+    make_magic((unsigned)std::max(s.tiles_y, 1), s.dv_ty);
+    make_magic((unsigned)std::max(s.PWp, 1), s.dv_pw);
+    make_magic((unsigned)std::max(s.gy, 1), s.dv_ncol);
+    make_magic((unsigned)std::max(s.gx >> 3, 1), s.dv_run0);
+    make_magic((unsigned)((s.gx >> 3) + 1), s.dv_run1);
+    make_magic((unsigned)std::max(s.ktaps, 1), s.dv_ktaps);
+    make_magic((unsigned)std::max(s.KW, 1), s.dv_kw);
+}
+
 int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     int taps = 1, cin = a.Cin, mode = 0;
     if (!a.wsplit || !split_shape(a, &taps, &cin, &mode, true)) {
@@ -1425,12 +1620,14 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     }
     s.x_bytes = a.x_bytes;
     s.xcd_remap = a.xcd_remap;
+    PP_TL_BEGIN();
     // inputs beyond the Infinity Cache (256 MB): the columns of a tile back to back; smaller ones: column by column
     static const int colmaj_mb = env_int("POSEPIPE_SPLIT_COLMAJOR_MB", 256);
     s.col_major = (size_t)a.x_bytes <= (size_t)colmaj_mb << 20;
     if (const int g8 = gemm8_cfg(a, mode, cin)) {
         s.mode = MODE_GEMM;
         s.S = (long long)a.M;
+        s.col_major = 0;                     // the product kernel walks tile by tile, all columns of a tile back to back
         const int BM = g8 == 2 ? 512 : 256, BN = g8 == 1 ? 256 : 128;
         dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)(a.Cout / BN));
         s.gx = (int)grid.x; s.gy = (int)grid.y;
@@ -1444,6 +1641,7 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         const char* epi_env = getenv("POSEPIPE_SPLIT_GEMM_EPI");
         s.epi_lds = epi_env ? atoi(epi_env) : 1;
         const int nwave = g8 == 3 ? 4 : 8;
+        fill_divisors(s);
         const size_t lds = std::max<size_t>((size_t)2 * (3 * 2 * (BM + 4) * 16 + BN * 6 * 16), s.epi_lds ? (size_t)nwave * (16384 + 2048) : 0);
         static std::once_flag once;
         std::call_once(once, [] {
@@ -1457,6 +1655,7 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
             hipLaunchKernelGGL((conv_split_gemm_kernel<4, 2>), grid, dim3(512), lds, stream, s);
         else
             hipLaunchKernelGGL((conv_split_gemm_kernel<2, 2>), grid, dim3(256), lds, stream, s);
+        PP_TL_END(g8 == 1 ? "g256x256" : g8 == 2 ? "g512x128" : "g256x128", grid.x * grid.y);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             pp_set_error("conv_split_gemm launch failed: %s", hipGetErrorString(e));
@@ -1520,6 +1719,7 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         s.gy = s.ncb / 3;
         if (s.xcd_remap) grid = dim3((unsigned)((s.gx + 7) / 8 * 8 * s.gy), 1);
         else grid = dim3(gx, (unsigned)s.gy);
+        fill_divisors(s);
         const size_t lds48 = (size_t)2 * 3 * 2 * s.NPp * 16;
 #define PP_SPLIT48_LAUNCH(NS_)                                                                                          \
     do {                                                                                                                \
@@ -1533,6 +1733,7 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         else if (nslot == 6) PP_SPLIT48_LAUNCH(6);
         else if (nslot == 7) PP_SPLIT48_LAUNCH(7);
         else PP_SPLIT48_LAUNCH(8);
+        PP_TL_END("c48", grid.x * grid.y);
         hipError_t e48 = hipGetLastError();
         if (e48 != hipSuccess) {
             pp_set_error("conv_split48 launch failed: %s", hipGetErrorString(e48));
@@ -1544,6 +1745,7 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     static const int ring4_env = env_int("POSEPIPE_SPLIT_RING4", 1);
     const bool ring4 = ring4_env && nw == 4 && mode != MODE_GEMM && (size_t)3 * 2 * s.NPp * 16 + (size_t)4 * cob * 3072 <= 80 * 1024;
     const size_t lds = (size_t)(ring4 ? 1 : 2) * 3 * 2 * s.NPp * 16 + ((nw == 8 || ring4) ? (size_t)4 * cob * 3072 : 0);
+    fill_divisors(s);
 #define PP_SPLIT_LAUNCH(T_, NS_, NW_, R4_)                                                                              \
     do {                                                                                                                \
         static std::once_flag once;                                                                                     \
@@ -1574,6 +1776,7 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         PP_SPLIT_LAUNCH(9, 7, 4, false);
     else
         PP_SPLIT_LAUNCH(9, 8, 4, false);
+    PP_TL_END(mode == MODE_GEMM ? "gemm4" : nw == 8 ? "nw8" : ring4 ? "ring4" : "nw4", grid.x * grid.y);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         pp_set_error("conv_split launch failed: %s", hipGetErrorString(e));
