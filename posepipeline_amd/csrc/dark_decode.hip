@@ -223,6 +223,293 @@ __global__ __launch_bounds__(256) void flip_merge_decode_kernel(DecodeArgs a) {
     }
 }
 
+
+// ---- round 4: the same decode at HBM speed --------------------------------------------------------------------------------------
+// flip_merge_decode_kernel above spends its time in the blur, not in memory: every output of the two separable passes re-reads its
+// 17 inputs from LDS behind a bounds test (2 x 17 ds_read_b32 + selects per pixel; 238 us per 64 persons = 0.25 TB/s).  Same
+// arithmetic, same order of operations per output (row pass: g0 v0, then + g_j v_j for j = 1 .. ks-1; column pass: g_r c, then
+// + g_{r+j} (down_j + up_j); no contraction) -- identical bits -- but organised for the hardware:
+//   * the merged map sits in LDS with an 8-pixel zero (or reflected) frame, so no tap is ever tested, and ROW PAIRS interleaved
+//     ([y / 2][x][y & 1]): a thread computes 8 consecutive outputs of TWO rows from 24 x 2 inputs held in registers
+//     (12 ds_read_b128 for 16 outputs instead of 272 ds_read_b32) with packed float32 arithmetic (v_pk_mul_f32 / v_pk_add_f32: the two
+//     rows are the two halves of every operand);
+//   * the row pass writes its result COLUMN-PAIR interleaved ([x / 2][y][x & 1]) so that the column pass is the same kernel body
+//     along y; the blurred map is never stored: the column pass keeps the running maximum (the rescale factor) and drops the 5 x 5
+//     neighbourhood of the arg-max -- all the Taylor stencil reads -- into a 25-float table;
+//   * loads: a thread requests all its lines of both maps (float4 straight, the mirrored map element-wise) before it consumes one.
+// Maps with odd sizes, w % 4 != 0, sizes over 128 or blur kernels other than 11 / 17 keep the generic kernel.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+struct FastGeom {
+    int wpa, hpb;            // padded pitches: A rows hold wpa pixel pairs, B columns hpb
+    int load_tasks, c4;      // (row pair, 4-pixel chunk) tasks; chunks per row
+    int row_tasks, nseg;     // (row pair, 8-pixel segment)
+    int col_tasks, nsegy;    // (column pair, 8-row segment)
+    float inv_c4, inv_nseg, inv_nsegy;
+};
+
+template <int KS>
+__global__ __launch_bounds__(512) void flip_merge_decode_fast_kernel(DecodeArgs a, FastGeom g) {
+    // 512 threads: the 432 row / column tasks of a 96 x 72 map are ONE round (with 256 threads: two, the second 69 % full, and the
+    // load, row and column phases of a CU's two workgroups ran in lock-step instead of overlapping -- measured, n = 256: 152 us of
+    // which loads 59, the two passes 63, frames 9); two workgroups per CU = 4 waves per SIMD
+    constexpr int R = KS / 2, NTH = 512, LU = 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = a.h, W = a.w;
+    float* A = smem;                                            // [H / 2][wpa][2]
+    float* B = A + (H / 2) * g.wpa * 2;                         // [W8 / 2][hpb][2]
+    float* ST = B + (KS ? ((W + 7) / 8 * 4) * g.hpb * 2 : 0);   // 5 x 5 blurred values around the arg-max
+    __shared__ float s_v[8];
+    __shared__ int s_i[8];
+    const int tid = threadIdx.x;
+    const int k = blockIdx.x % a.k;
+    const int n = blockIdx.x / a.k;
+    const int HW = H * W;
+    const float* src = a.hm + ((size_t)n * a.k + k) * HW;
+    const float* fsrc = a.hm_flip ? a.hm_flip + ((size_t)n * a.k + a.flip_perm[k]) * HW : nullptr;
+    float* mdst = a.merged ? a.merged + ((size_t)n * a.k + k) * HW : nullptr;
+
+    // ---- 0. the frames: zero (the reflected frame of post 2 is filled from the merged map below) -----------------------------------
+    if (KS) {
+        // A: per row pair 8 pixel pairs left of the map and wpa - W - 8 right of it (16 B = 2 pixel pairs); B: 8 rows above, hpb - H - 8 below
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int aq = (g.wpa - W) / 2;                         // float4 units per row pair: 4 left + the rest right
+        for (int yp = tid / 16; yp < H / 2; yp += NTH / 16) {
+            const int q = tid & 15;
+            if (q < aq) *reinterpret_cast<float4*>(A + ((yp * g.wpa) + (q < 4 ? 2 * q : 8 + W + 2 * (q - 4))) * 2) = z;
+        }
+        const int ncp = (W + 7) / 8 * 4, bq = (g.hpb - H) / 2;  // column pairs the row pass writes; units per column pair
+        for (int xp = tid / 16; xp < ncp; xp += NTH / 16) {
+            const int q = tid & 15;
+            if (q < bq) *reinterpret_cast<float4*>(B + ((xp * g.hpb) + (q < 4 ? 2 * q : 8 + H + 2 * (q - 4))) * 2) = z;
+        }
+    }
+
+    // ---- 1. flip-merge into LDS + arg-max; four tasks' loads in flight per thread ---------------------------------------------------
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    for (int t0 = tid; t0 < g.load_tasks; t0 += NTH * LU) {
+        float4 s[LU][2];
+        float f[LU][2][4];
+        int yp_[LU], c_[LU];
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            const int t = t0 + NTH * u;
+            const int tc = t < g.load_tasks ? t : 0;                       // clamped: the loads of a task past the end are valid and ignored
+            yp_[u] = (int)(((float)tc + 0.5f) * g.inv_c4);
+            c_[u] = tc - yp_[u] * g.c4;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int y = 2 * yp_[u] + r;
+                s[u][r] = *reinterpret_cast<const float4*>(src + y * W + 4 * c_[u]);
+                if (fsrc) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int x = 4 * c_[u] + e;
+                        // flipped back: column W-1-x'; shifted right by one: x' = max(x-1, 0)
+                        const int xs = a.shift_heatmap ? (x > 0 ? x - 1 : 0) : x;
+                        f[u][r][e] = fsrc[y * W + (W - 1 - xs)];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < LU; ++u) {
+            if (t0 + NTH * u >= g.load_tasks) continue;
+            float v[2][4];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const float sv[4] = {s[u][r].x, s[u][r].y, s[u][r].z, s[u][r].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[r][e] = fsrc ? __fmul_rn(__fadd_rn(sv[e], f[u][r][e]), 0.5f) : sv[e];
+                    argmax_combine(best, besti, v[r][e], (2 * yp_[u] + r) * W + 4 * c_[u] + e);
+                }
+                if (mdst) *reinterpret_cast<float4*>(mdst + (2 * yp_[u] + r) * W + 4 * c_[u]) = make_float4(v[r][0], v[r][1], v[r][2], v[r][3]);
+            }
+            float* d = A + ((yp_[u] * g.wpa) + 4 * c_[u] + 8) * 2;
+            *reinterpret_cast<float4*>(d) = make_float4(v[0][0], v[1][0], v[0][1], v[1][1]);
+            *reinterpret_cast<float4*>(d + 4) = make_float4(v[0][2], v[1][2], v[0][3], v[1][3]);
+        }
+    }
+    block_argmax(best, besti, s_v, s_i);            // (its barriers also publish A)
+    const float maxval = best;
+    const int idx = besti;
+    int px = idx % W, py = idx / W;
+    const bool has_peak = maxval > 0.0f;
+    float cxp = has_peak ? (float)px : -1.0f;       // mmpose: preds = -1 where maxval <= 0
+    float cyp = has_peak ? (float)py : -1.0f;
+    if (!has_peak) {
+        px = -1;
+        py = -1;
+    }
+    auto Aat = [&](int y, int x) -> float { return A[(((y >> 1) * g.wpa) + x + 8) * 2 + (y & 1)]; };
+
+    if (KS && (a.post == 1 || a.post == 2)) {
+        const bool reflect = a.post == 2;
+        if (reflect) {
+            // BORDER_REFLECT_101 frame of the merged map: A(y, -j) = A(y, j), A(y, W-1+j) = A(y, W-1-j), j = 1 .. R
+            for (int i = tid; i < H * 2 * R; i += NTH) {
+                const int y = i / (2 * R), r = i - y * (2 * R), j = (r >> 1) + 1;
+                const int xd = (r & 1) ? W - 1 + j : -j, xs = (r & 1) ? W - 1 - j : j;
+                A[(((y >> 1) * g.wpa) + xd + 8) * 2 + (y & 1)] = Aat(y, xs);
+            }
+            __syncthreads();
+        }
+        // ---- 2. row pass: 8 outputs x 2 rows per task ----------------------------------------------------------------------------------
+        for (int t = tid; t < g.row_tasks; t += NTH) {
+            const int yp = (int)(((float)t + 0.5f) * g.inv_nseg), seg = t - yp * g.nseg;
+            const float4* in4 = reinterpret_cast<const float4*>(A + ((yp * g.wpa) + 8 * seg) * 2);
+            v2f in[24];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const float4 v = in4[q];
+                in[2 * q] = v2f{v.x, v.y};
+                in[2 * q + 1] = v2f{v.z, v.w};
+            }
+            v2f out[8];
+#pragma unroll
+            for (int xi = 0; xi < 8; ++xi) {
+                v2f sacc = in[xi + 8 - R] * a.gk[0];
+#pragma unroll
+                for (int j = 1; j < KS; ++j) sacc = sacc + in[xi + j + 8 - R] * a.gk[j];
+                out[xi] = sacc;
+            }
+            const int y0 = 2 * yp;
+#pragma unroll
+            for (int xq = 0; xq < 4; ++xq) {
+                const int xpair = 4 * seg + xq;
+                *reinterpret_cast<float4*>(B + ((xpair * g.hpb) + y0 + 8) * 2) = make_float4(out[2 * xq].x, out[2 * xq + 1].x, out[2 * xq].y, out[2 * xq + 1].y);
+            }
+        }
+        __syncthreads();
+        if (reflect) {
+            const int ncp2 = W;                        // columns
+            for (int i = tid; i < ncp2 * 2 * R; i += NTH) {
+                const int x = i / (2 * R), r = i - x * (2 * R), j = (r >> 1) + 1;
+                const int yd = (r & 1) ? H - 1 + j : -j, ys = (r & 1) ? H - 1 - j : j;
+                B[(((x >> 1) * g.hpb) + yd + 8) * 2 + (x & 1)] = B[(((x >> 1) * g.hpb) + ys + 8) * 2 + (x & 1)];
+            }
+            __syncthreads();
+        }
+        // ---- 3. column pass: 8 outputs x 2 columns per task; running maximum + the 5 x 5 neighbourhood of the arg-max --------------------
+        float bmax = -INFINITY;
+        for (int t = tid; t < g.col_tasks; t += NTH) {
+            const int xp = (int)(((float)t + 0.5f) * g.inv_nsegy), sy = t - xp * g.nsegy;
+            const float4* in4 = reinterpret_cast<const float4*>(B + ((xp * g.hpb) + 8 * sy) * 2);
+            v2f in[24];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) {
+                const float4 v = in4[q];
+                in[2 * q] = v2f{v.x, v.y};
+                in[2 * q + 1] = v2f{v.z, v.w};
+            }
+            const bool near_peak = has_peak && 2 * xp + 1 >= px - 2 && 2 * xp <= px + 2 && 8 * sy + 7 >= py - 2 && 8 * sy <= py + 2;
+#pragma unroll
+            for (int yi = 0; yi < 8; ++yi) {
+                v2f sacc = in[yi + 8] * a.gk[R];
+#pragma unroll
+                for (int j = 1; j <= R; ++j) sacc = sacc + (in[yi + 8 + j] + in[yi + 8 - j]) * a.gk[R + j];
+                const int y = 8 * sy + yi;
+                if (y < H) {
+                    bmax = fmaxf(bmax, fmaxf(sacc.x, sacc.y));
+                    if (near_peak && y >= py - 2 && y <= py + 2) {
+                        const int dx0 = 2 * xp - px + 2;
+                        if (dx0 >= 0 && dx0 < 5) ST[(y - py + 2) * 5 + dx0] = sacc.x;
+                        if (dx0 + 1 >= 0 && dx0 + 1 < 5) ST[(y - py + 2) * 5 + dx0 + 1] = sacc.y;
+                    }
+                }
+            }
+        }
+        int dummy = tid;
+        block_argmax(bmax, dummy, s_v, s_i);       // maximum of the blurred map (the index is not used); publishes ST
+        auto Bl = [&](int yy, int xx) -> float { return ST[(yy - py + 2) * 5 + (xx - px + 2)]; };
+        // The logarithms of the stencil (correctly rounded float32 log = a double-precision log each, ~150 dependent instructions) are
+        // taken by one LANE EACH and handed over through LDS: with all of them on thread 0 they were the longest stretch of the whole
+        // workgroup (13 in a row, ~3 us, while 511 threads waited)
+        float* LT = ST + 32;
+        if (a.post == 2) {
+            if (has_peak) {
+                if (tid < 9) {
+                    const int yy = min(max(py + tid / 3 - 1, 0), H - 1), xx = min(max(px + tid % 3 - 1, 0), W - 1);
+                    const float v = fminf(fmaxf(Bl(yy, xx), 0.001f), 50.0f);
+                    LT[tid] = (float)log((double)v);
+                }
+                __syncthreads();
+            }
+            if (tid == 0 && has_peak) {
+                auto L = [&](int dy, int dx) -> float { return LT[(dy + 1) * 3 + dx + 1]; };   // (clamped coordinates were applied above)
+                const float i_ = L(0, 0), ix1 = L(0, 1), iy1 = L(1, 0), ix1y1 = L(1, 1);
+                const float ix1_y1_ = L(-1, -1), ix1_ = L(0, -1), iy1_ = L(-1, 0);
+                const float dx = __fmul_rn(0.5f, __fsub_rn(ix1, ix1_)), dy = __fmul_rn(0.5f, __fsub_rn(iy1, iy1_));
+                const float dxx = __fadd_rn(__fsub_rn(ix1, __fmul_rn(2.0f, i_)), ix1_);
+                const float dyy = __fadd_rn(__fsub_rn(iy1, __fmul_rn(2.0f, i_)), iy1_);
+                float t = __fsub_rn(ix1y1, ix1);
+                t = __fsub_rn(t, iy1); t = __fadd_rn(t, i_); t = __fadd_rn(t, i_);
+                t = __fsub_rn(t, ix1_); t = __fsub_rn(t, iy1_); t = __fadd_rn(t, ix1_y1_);
+                const float dxy = __fmul_rn(0.5f, t);
+                const double eps = 1.1920928955078125e-07;
+                const double h00 = (double)dxx + eps, h01 = (double)dxy, h11 = (double)dyy + eps;
+                const double det = h00 * h11 - h01 * h01;
+                const double ox = (h11 * (double)dx - h01 * (double)dy) / det;
+                const double oy = (h00 * (double)dy - h01 * (double)dx) / det;
+                cxp = (float)((double)cxp - ox);
+                cyp = (float)((double)cyp - oy);
+            }
+        } else if (1 < px && px < W - 2 && 1 < py && py < H - 2) {      // (uniform: px, py are the workgroup's arg-max)
+            const float scale = maxval / bmax;     // float32 / float32
+            if (tid < 25) {
+                float v = __fmul_rn(ST[tid], scale);
+                v = fmaxf(v, 1e-10f);
+                LT[tid] = (float)log((double)v);   // correctly rounded float32 log
+            }
+            __syncthreads();
+            if (tid == 0) {
+                auto L = [&](int yy, int xx) -> float { return LT[(yy - py + 2) * 5 + (xx - px + 2)]; };
+                const float l00 = L(py, px);
+                const float lxp = L(py, px + 1), lxm = L(py, px - 1), lyp = L(py + 1, px), lym = L(py - 1, px);
+                const float lxpp = L(py, px + 2), lxmm = L(py, px - 2), lypp = L(py + 2, px), lymm = L(py - 2, px);
+                const float lpp = L(py + 1, px + 1), lmp = L(py - 1, px + 1), lpm = L(py + 1, px - 1), lmm = L(py - 1, px - 1);
+                const double dx = 0.5 * (double)__fsub_rn(lxp, lxm);
+                const double dy = 0.5 * (double)__fsub_rn(lyp, lym);
+                const double dxx = 0.25 * (((double)lxpp - 2.0 * (double)l00) + (double)lxmm);
+                const double dyy = 0.25 * (((double)lypp - 2.0 * (double)l00) + (double)lymm);
+                const double dxy = 0.25 * (double)__fadd_rn(__fsub_rn(__fsub_rn(lpp, lmp), lpm), lmm);
+                const double det = dxx * dyy - dxy * dxy;
+                if (det != 0.0) {
+                    const double i00 = dyy / det, i01 = -dxy / det, i11 = dxx / det;
+                    const double ox = -(i00 * dx + i01 * dy);
+                    const double oy = -(i01 * dx + i11 * dy);
+                    cxp = (float)((double)cxp + ox);
+                    cyp = (float)((double)cyp + oy);
+                }
+            }
+        }
+    } else if (a.post == 0) {
+        if (tid == 0 && 1 < px && px < W - 1 && 1 < py && py < H - 1) {
+            const float ddx = __fsub_rn(Aat(py, px + 1), Aat(py, px - 1));
+            const float ddy = __fsub_rn(Aat(py + 1, px), Aat(py - 1, px));
+            const float sx = ddx > 0.f ? 1.f : (ddx < 0.f ? -1.f : 0.f);
+            const float sy = ddy > 0.f ? 1.f : (ddy < 0.f ? -1.f : 0.f);
+            cxp = __fadd_rn(cxp, sx * 0.25f);
+            cyp = __fadd_rn(cyp, sy * 0.25f);
+        }
+    }
+
+    // ---- transform_preds (float32 array arithmetic with float64 scalars cast to float32), as the generic kernel -----------------------
+    if (tid == 0) {
+        const float* cs = a.center_scale + 4 * n;
+        const float s200x = __fmul_rn(cs[2], 200.0f), s200y = __fmul_rn(cs[3], 200.0f);
+        const float scale_x = (float)((double)s200x / (a.post == 2 ? (double)W - 1.0 : (double)W));
+        const float scale_y = (float)((double)s200y / (a.post == 2 ? (double)H - 1.0 : (double)H));
+        const float hx = (float)((double)s200x * 0.5), hy = (float)((double)s200y * 0.5);
+        float* o = a.kpts + ((size_t)n * a.k + k) * 3;
+        o[0] = __fsub_rn(__fadd_rn(__fmul_rn(cxp, scale_x), cs[0]), hx);
+        o[1] = __fsub_rn(__fadd_rn(__fmul_rn(cyp, scale_y), cs[1]), hy);
+        o[2] = maxval;
+    }
+}
+
 }  // namespace
 
 static void fill_gaussian_taps(DecodeArgs& a) {
@@ -257,6 +544,40 @@ int pp_enqueue_decode(hipStream_t s, const DecodeParams& p, const float* hm, con
     if (p.post >= 1) fill_gaussian_taps(a);
     a.hm = hm; a.hm_flip = hm_flip; a.flip_perm = flip_perm; a.center_scale = center_scale;
     a.kpts = kpts; a.merged = merged;
+    // the fast form (see flip_merge_decode_fast_kernel): even maps with w % 4 == 0 up to 128 x 128, blur kernels 11 / 17 (or no blur)
+    const char* gen_env = getenv("POSEPIPE_DECODE_GENERIC");      // A/B and test knob (both kernels give identical bits: tests/test_gpu_decode_fast.py)
+    const bool fast_off = gen_env && atoi(gen_env) != 0;
+    const bool blur = p.post >= 1;
+    const bool fast_ok = !fast_off && p.h % 2 == 0 && p.w % 4 == 0 && p.h <= 128 && p.w <= 128 && p.h >= 8 && p.w >= 8 &&
+                         (!blur || p.blur_kernel == 11 || p.blur_kernel == 17);
+    if (fast_ok) {
+        FastGeom g{};
+        const int w8 = (p.w + 7) / 8 * 8, h8 = (p.h + 7) / 8 * 8;
+        g.wpa = w8 + 16;
+        g.hpb = h8 + 16;
+        g.c4 = p.w / 4;
+        g.load_tasks = (p.h / 2) * g.c4;
+        g.nseg = w8 / 8;
+        g.row_tasks = (p.h / 2) * g.nseg;
+        g.nsegy = h8 / 8;
+        g.col_tasks = (p.w / 2) * g.nsegy;
+        g.inv_c4 = 1.0f / (float)g.c4;
+        g.inv_nseg = 1.0f / (float)g.nseg;
+        g.inv_nsegy = 1.0f / (float)g.nsegy;
+        const size_t lds_fast = ((size_t)(p.h / 2) * g.wpa * 2 + (blur ? (size_t)(w8 / 2) * g.hpb * 2 + 64 : 0)) * sizeof(float);
+        static bool fast_attr = false;
+        if (!fast_attr) {
+            PP_HIP_CHECK(hipFuncSetAttribute((const void*)flip_merge_decode_fast_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+            PP_HIP_CHECK(hipFuncSetAttribute((const void*)flip_merge_decode_fast_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+            PP_HIP_CHECK(hipFuncSetAttribute((const void*)flip_merge_decode_fast_kernel<17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
+            fast_attr = true;
+        }
+        if (!blur) hipLaunchKernelGGL(flip_merge_decode_fast_kernel<0>, dim3(p.n * p.k), dim3(512), lds_fast, s, a, g);
+        else if (p.blur_kernel == 11) hipLaunchKernelGGL(flip_merge_decode_fast_kernel<11>, dim3(p.n * p.k), dim3(512), lds_fast, s, a, g);
+        else hipLaunchKernelGGL(flip_merge_decode_fast_kernel<17>, dim3(p.n * p.k), dim3(512), lds_fast, s, a, g);
+        PP_HIP_CHECK(hipGetLastError());
+        return PP_OK;
+    }
     static bool attr_set = false;
     if (!attr_set && lds > 64 * 1024) {
         PP_HIP_CHECK(hipFuncSetAttribute((const void*)flip_merge_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));

@@ -214,219 +214,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, min_blocks(WAVES_M * WAVES_
     gemm_epilogue<WM, WN>(a, acc, m0 + wm * WM * 16, n0 + wn * WN * 16, r16, kg);
 }
 
-// Register-pipelined form (configuration 9): 8 waves of 128 x 64, 256 x 256 block tile, two LDS stages.  The fragments
-// of the NEXT half K step are read from LDS before the 32 MFMAs of the current one are issued, so no MFMA ever waits for
-// an LDS read; the barrier sits in the middle of a K step (after the reads of its second half), where it also frees the
-// stage for the tile after next -- global loads fly for one and a half K steps.
-template <int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void gemm_bf16_pipelined_kernel(GemmArgs a) {
-    constexpr int WM = 8, WN = 4;
-    constexpr int NW = WAVES_M * WAVES_N, BK = 64, ROWB = 128, RS = 8;
-    constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
-    constexpr int NLA = BM / (RS * NW), NLB = BN / (RS * NW);
-    constexpr int STAGE = (BM + BN) * ROWB;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    unsigned char* ldsA = lds;
-    unsigned char* ldsB = lds + BM * ROWB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
-    const int tiles_n = a.N / BN, tiles_m = (a.M + BM - 1) / BM;
-    int pid = blockIdx.x;
-    {
-        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, xcd = pid & 7, loc = pid >> 3;
-        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int GM = a.group_m, per_group = GM * tiles_n;
-    const int grp = pid / per_group, in_grp = pid - grp * per_group;
-    const int rows_here = min(GM, tiles_m - grp * GM);
-    const int tn = in_grp / rows_here, tm = grp * GM + (in_grp - tn * rows_here);
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int lrow = lane >> 3, slot = lane & 7;
-    const __bf16* gA[NLA];
-    const __bf16* gB[NLB];
-#pragma unroll
-    for (int i = 0; i < NLA; ++i) {
-        const int row = (i * NW + wave) * RS + lrow;
-        gA[i] = reinterpret_cast<const __bf16*>(a.A) + (size_t)min(m0 + row, a.M - 1) * a.K + (slot ^ ((row >> 1) & 7)) * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < NLB; ++i) {
-        const int row = (i * NW + wave) * RS + lrow;
-        gB[i] = reinterpret_cast<const __bf16*>(a.B) + (size_t)(n0 + row) * a.K + (slot ^ ((row >> 1) & 7)) * 8;
-    }
-    auto issue = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < NLA; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gA[i],
-                                             (__attribute__((address_space(3))) void*)(ldsA + stage * STAGE + (i * NW + wave) * 1024),
-                                             16, 0, 0);
-            gA[i] += BK;
-        }
-#pragma unroll
-        for (int i = 0; i < NLB; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gB[i],
-                                             (__attribute__((address_space(3))) void*)(ldsB + stage * STAGE + (i * NW + wave) * 1024),
-                                             16, 0, 0);
-            gB[i] += BK;
-        }
-    };
-    const int r16 = lane & 15, kg = lane >> 4, sw = (r16 >> 1) & 7;
-    const unsigned char* rdA = ldsA + (wm * WM * 16 + r16) * ROWB;
-    const unsigned char* rdB = ldsB + (wn * WN * 16 + r16) * ROWB;
-    const int c0 = ((0 + kg) ^ sw) << 4, c1 = ((4 + kg) ^ sw) << 4;
-
-    f32x4_t acc[WM][WN];
-#pragma unroll
-    for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    bf16x8_t fa0[WM], fb0[WN], fa1[WM], fb1[WN];
-    auto read = [&](bf16x8_t (&fa)[WM], bf16x8_t (&fb)[WN], int off) {
-#pragma unroll
-        for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8_t*>(rdA + mi * 16 * ROWB + off);
-#pragma unroll
-        for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const bf16x8_t*>(rdB + ni * 16 * ROWB + off);
-    };
-    auto mma = [&](bf16x8_t (&fa)[WM], bf16x8_t (&fb)[WN]) {
-#pragma unroll
-        for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < WN; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
-    };
-
-    const int nk = a.K / BK;
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (nk > 1) issue(1);
-    read(fa0, fb0, c0);                                   // (tile 0, first half)
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = (kt & 1) * STAGE, nxt = STAGE - cur;
-        read(fa1, fb1, c1 + cur);                         // second half of this K step
-        __builtin_amdgcn_sched_barrier(0);
-        mma(fa0, fb0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own part of tile kt + 1 landed; stage `cur` fully read
-        __builtin_amdgcn_s_barrier();
-        if (kt + 2 < nk) issue(kt & 1);                   // tile kt + 2 into the stage just freed
-        if (kt + 1 < nk) read(fa0, fb0, c0 + nxt);        // first half of the next K step
-        __builtin_amdgcn_sched_barrier(0);
-        mma(fa1, fb1);
-    }
-    gemm_epilogue<WM, WN>(a, acc, m0 + wm * WM * 16, n0 + wn * WN * 16, r16, kg);
-}
-
-// Persistent form of the two-stage kernel: one block per CU walks the tile list; the first K tile of the NEXT output tile
-// is requested (global_load_lds is asynchronous and needs no registers) before the epilogue of the current one, so the
-// epilogue's loads / math / stores overlap that fetch instead of being followed by a cold pipeline start.
-template <int WAVES_M, int WAVES_N, int WM, int WN>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 1) void gemm_bf16_persistent_kernel(GemmArgs a) {
-    constexpr int NW = WAVES_M * WAVES_N, BK = 64, ROWB = 128, CH = 8, RS = 8;
-    constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
-    constexpr int NLA = BM / (RS * NW), NLB = BN / (RS * NW);
-    constexpr int STAGE = (BM + BN) * ROWB;
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];   // 2 x STAGE
-    unsigned char* ldsA = lds;
-    unsigned char* ldsB = lds + BM * ROWB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WAVES_N, wn = wave - wm * WAVES_N;
-    const int tiles_n = a.N / BN, tiles_m = (a.M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
-    const int lrow = lane >> 3, slot = lane & 7;
-    const int r16 = lane & 15, kg = lane >> 4, sw = (r16 >> 1) & 7;
-    const unsigned char* rdA = ldsA + (wm * WM * 16 + r16) * ROWB;
-    const unsigned char* rdB = ldsB + (wn * WN * 16 + r16) * ROWB;
-    const int c0 = ((0 + kg) ^ sw) << 4, c1 = ((4 + kg) ^ sw) << 4;
-    const int nk = a.K / BK;
-
-    const __bf16* gA[NLA];
-    const __bf16* gB[NLB];
-    // virtual tile id -> (m0, n0): the XCD-aware grouped order of the non-persistent kernel over the whole tile list; a
-    // block's ids are congruent mod 8 (the grid is a multiple of 8), so it stays on its XCD's range
-    auto locate = [&](int vp, int& m0, int& n0) {
-        const int q = ntiles >> 3, r = ntiles & 7, xcd = vp & 7, loc = vp >> 3;
-        const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-        const int GM = a.group_m, per_group = GM * tiles_n;
-        const int grp = pid / per_group, in_grp = pid - grp * per_group;
-        const int rows_here = min(GM, tiles_m - grp * GM);
-        const int tn = in_grp / rows_here, tm = grp * GM + (in_grp - tn * rows_here);
-        m0 = tm * BM;
-        n0 = tn * BN;
-    };
-    auto point = [&](int m0, int n0) {
-#pragma unroll
-        for (int i = 0; i < NLA; ++i) {
-            const int row = (i * NW + wave) * RS + lrow;
-            gA[i] = reinterpret_cast<const __bf16*>(a.A) + (size_t)min(m0 + row, a.M - 1) * a.K + (slot ^ ((row >> 1) & 7)) * 8;
-        }
-#pragma unroll
-        for (int i = 0; i < NLB; ++i) {
-            const int row = (i * NW + wave) * RS + lrow;
-            gB[i] = reinterpret_cast<const __bf16*>(a.B) + (size_t)(n0 + row) * a.K + (slot ^ ((row >> 1) & 7)) * 8;
-        }
-    };
-    auto issue = [&](int stage) {
-#pragma unroll
-        for (int i = 0; i < NLA; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gA[i],
-                                             (__attribute__((address_space(3))) void*)(ldsA + stage * STAGE + (i * NW + wave) * 1024),
-                                             16, 0, 0);
-            gA[i] += BK;
-        }
-#pragma unroll
-        for (int i = 0; i < NLB; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gB[i],
-                                             (__attribute__((address_space(3))) void*)(ldsB + stage * STAGE + (i * NW + wave) * 1024),
-                                             16, 0, 0);
-            gB[i] += BK;
-        }
-    };
-
-    int vp = blockIdx.x;
-    if (vp >= ntiles) return;
-    int m0, n0, st = 0;             // st: the LDS stage that holds (or will hold) the K tile about to be multiplied
-    locate(vp, m0, n0);
-    point(m0, n0);
-    issue(st);
-    while (true) {
-        f32x4_t acc[WM][WN];
-#pragma unroll
-        for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();      // K tile kt has landed in stage st; nobody reads stage st ^ 1 any more
-            if (kt + 1 < nk) issue(st ^ 1);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int co = (kk ? c1 : c0) + st * STAGE;
-                bf16x8_t fa[WM], fb[WN];
-#pragma unroll
-                for (int mi = 0; mi < WM; ++mi) fa[mi] = *reinterpret_cast<const bf16x8_t*>(rdA + mi * 16 * ROWB + co);
-#pragma unroll
-                for (int ni = 0; ni < WN; ++ni) fb[ni] = *reinterpret_cast<const bf16x8_t*>(rdB + ni * 16 * ROWB + co);
-#pragma unroll
-                for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < WN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[ni], fa[mi], acc[mi][ni], 0, 0, 0);
-            }
-            st ^= 1;
-        }
-        // here st names the stage that was read at step nk - 2: every wave has passed the barrier of step nk - 1 since,
-        // so it is free for the first K tile of the next output tile
-        const int cm0 = m0, cn0 = n0;
-        vp += gridDim.x;
-        const bool more = vp < ntiles;
-        if (more) {
-            locate(vp, m0, n0);
-            point(m0, n0);
-            issue(st);
-        }
-        gemm_epilogue<WM, WN>(a, acc, cm0 + wm * WM * 16, cn0 + wn * WN * 16, r16, kg);
-        if (!more) break;
-    }
-}
 
 // Ping-pong form (configuration 10): 256 x 256 tile, K step 64, 8 waves of 128 (m) x 64 (n), v_mfma_f32_32x32x16_bf16, two
 // 64 KiB LDS buffers, one workgroup per CU.  The waves form two groups (waves 0-3 / 4-7:
@@ -718,41 +505,6 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     return PP_OK;
 }
 
-template <int WAVES_M, int WAVES_N>
-int launch_pipelined(const GemmArgs& a, hipStream_t stream) {
-    constexpr int BM = WAVES_M * 128, BN = WAVES_N * 64;
-    constexpr int lds = 2 * (BM + BN) * 128;
-    auto* kern = &gemm_bf16_pipelined_kernel<WAVES_M, WAVES_N>;
-    static bool configured = false;
-    if (!configured) {
-        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured = true;
-    }
-    const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, stream, a);
-    PP_HIP_CHECK(hipGetLastError());
-    return PP_OK;
-}
-
-template <int WAVES_M, int WAVES_N, int WM, int WN>
-int launch_persistent(const GemmArgs& a, hipStream_t stream) {
-    constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
-    constexpr int lds = 2 * (BM + BN) * 128;
-    auto* kern = &gemm_bf16_persistent_kernel<WAVES_M, WAVES_N, WM, WN>;
-    static int n_cu = 0;
-    if (n_cu == 0) {
-        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        int dev = 0;
-        PP_HIP_CHECK(hipGetDevice(&dev));
-        PP_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        n_cu = std::max(8, n_cu / 8 * 8);        // a multiple of 8 keeps a block's tile ids on one XCD
-    }
-    const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
-    hipLaunchKernelGGL(kern, dim3(std::min(tiles, n_cu)), dim3(64 * WAVES_M * WAVES_N), lds, stream, a);
-    PP_HIP_CHECK(hipGetLastError());
-    return PP_OK;
-}
-
 template <int D4, int D1, int D2>
 int launch_pingpong(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = 128 * 1024;          // two 64 KiB operand buffers (the epilogue stages through them)
@@ -783,14 +535,13 @@ int pp_launch_f32_to_bf16(const float* x, void* y, size_t n, hipStream_t stream)
 //   0  128 x 128, 4 waves (64 x 64 each), 1 stage,  32 KiB LDS -> 4 blocks / CU
 //   1  256 x 128, 8 waves (64 x 64 each), 1 stage,  48 KiB LDS -> 2 blocks / CU, 3/4 of the L2 -> LDS bytes per FLOP
 //   2  256 x 256, 16 waves (64 x 64 each), 2 stages, 128 KiB LDS -> 1 block / CU, 1/2 of the bytes, in-block prefetch
-//   3  256 x 128, 4 waves (128 x 64 each), 1 stage,  48 KiB LDS -> 2 blocks / CU, 3/4 of the LDS reads per FLOP
-//   4  128 x 128, 4 waves, 2 stages, 64 KiB LDS
-//   5  256 x 256, 8 waves (128 x 64 each), 2 stages, 128 KiB LDS -> 1 block / CU
-//   6  256 x 128, 8 waves, 2 stages of K step 32, 48 KiB LDS -> 2 blocks / CU with the in-block prefetch
-//   7  128 x 128, 4 waves, 2 stages of K step 32, 32 KiB LDS -> 4 blocks / CU
-//   8  configuration 2 as a persistent kernel (one block per CU, next tile's first loads issued before the epilogue)
-//   9  256 x 256, 8 waves (128 x 64 each), register-pipelined fragments, barrier mid K step: 821 / 671 / 747 / 1020
-//  10  ping-pong form (gemm_bf16_pingpong_kernel), LDS-DMA requests spread 4-2-2 over the load segments; 11: 4-4-0; 12: 2-3-3
+//  10  ping-pong form (gemm_bf16_pingpong_kernel): THE form of every problem with N % 256 == 0 and K % 128 == 0 -- i.e. of every
+//      GEMM of the ViT-B / L / H encoders and of the deconvolution head, at every batch size, so that results do not depend on
+//      which batch size selected which kernel (0 .. 2 are bit-identical to each other; 10 sums K in steps of 16 with the bias
+//      first).  0 .. 2 remain for the shapes 10 does not take.
+// Round 4 removed the forms that had lost their A/Bs and were reachable only through the knob (measured in rounds 1 - 3, numbers
+// in DESIGN.md 5b): 256 x 128 with 128 x 64 wave tiles, two-stage 128 x 128, 256 x 256 with 8 fat waves, K step 32, a persistent
+// tile loop, a register-pipelined form, and the 4-4-0 / 2-3-3 DMA placements of the ping-pong form.
 // set the dynamic-LDS attribute of the default large-tile kernel outside any hipGraph capture (called when an encoder /
 // deconvolution object is created)
 int pp_gemm_bf16_prepare() {
@@ -809,30 +560,20 @@ int pp_launch_gemm_bf16(const GemmArgs& a_in, hipStream_t stream) {
     PP_REQUIRE(a.K % 64 == 0, "gemm_bf16: K = %d must be a multiple of 64", a.K);
     PP_REQUIRE(a.N % 128 == 0, "gemm_bf16: N = %d must be a multiple of 128", a.N);
     const char* env_cfg = getenv("POSEPIPE_GEMM_CFG");
-    // default (measured on the ViT-H shapes at M = 12288, qkv / proj / fc1 / fc2 in TFLOP/s): 256 x 256 two-stage tiles
-    // 867 / 743 / 730 / 997, 256 x 128 tiles 831 / 721 / 720 / 931, 128 x 128 tiles 785 / 673 / 716 / 844; small problems
-    // keep the smaller tiles for the larger grid.  The ping-pong form (10) is opt-in: isolated launches at M = 24576 run 952 /
-    // 806 / 855 / 913 against 840 / 750 / 774 / 877 for (2) on the same box, but inside the encoder (operands warm in L2 / MALL)
-    // the GEMMs of a step take 32.8 ms against 33.7 (c5: 1538 vs 1517 frames/s), and its other summation order (16 k per MFMA,
-    // bias first) would make results depend on which batch sizes select it -- (0) .. (9) are bit-identical to each other.
+    // measured on the ViT-H shapes (qkv / proj / fc1 / fc2, TFLOP/s): ping-pong form at M = 24576 952 / 806 / 855 / 913 against 840 /
+    // 750 / 774 / 877 for (2) on the same box; inside the encoder the GEMMs of a step take 32.8 ms against 33.7.  Shapes it does not
+    // take: 256 x 256 two-stage tiles where they fill the chip, else the smaller tiles for the larger grid.
     const long rows256 = (a.M + 255) / 256;
+    const bool pingpong_ok = a.N % 256 == 0 && a.K % 128 == 0 && !(a.qkv_tokens > 0 && (a.qkv_hd % 8 != 0 || a.qkv_tokens % 8 != 0));
     int cfg = env_cfg ? atoi(env_cfg)
+                      : pingpong_ok ? 10
                       : (a.N % 256 == 0 && rows256 * (a.N / 256) >= 128) ? 2 : (rows256 * (a.N / 128) >= 256 ? 1 : 0);
-    if ((cfg == 2 || cfg == 5 || cfg == 8 || cfg == 9 || cfg >= 10) && a.N % 256 != 0) cfg = 1;
-    if (cfg >= 10 && (a.K % 128 != 0 || (a.qkv_tokens > 0 && (a.qkv_hd % 8 != 0 || a.qkv_tokens % 8 != 0)))) cfg = 2;
+    if ((cfg == 2 || cfg == 10) && a.N % 256 != 0) cfg = 1;
+    if (cfg == 10 && !pingpong_ok) cfg = 2;
     switch (cfg) {
         case 1: return launch_cfg<4, 2, 4, 4, 1>(a, stream);
         case 2: return launch_cfg<4, 4, 4, 4, 2>(a, stream);
-        case 3: return launch_cfg<2, 2, 8, 4, 1>(a, stream);
-        case 4: return launch_cfg<2, 2, 4, 4, 2>(a, stream);
-        case 5: return launch_cfg<2, 4, 8, 4, 2>(a, stream);
-        case 6: return launch_cfg<4, 2, 4, 4, 2, 32>(a, stream);
-        case 7: return launch_cfg<2, 2, 4, 4, 2, 32>(a, stream);
-        case 8: return launch_persistent<4, 4, 4, 4>(a, stream);
-        case 9: return launch_pipelined<2, 4>(a, stream);
         case 10: return launch_pingpong<4, 2, 2>(a, stream);
-        case 11: return launch_pingpong<4, 4, 0>(a, stream);
-        case 12: return launch_pingpong<2, 3, 3>(a, stream);
         default: return launch_cfg<2, 2, 4, 4, 1>(a, stream);
     }
 }

@@ -58,14 +58,17 @@ def _close_bf16(got_bits, ref_f32, ulps=1.0):
     (384, 384, 1280, 1, False, 0, 1),        # GELU, bf16 out
     (576, 1280, 640, 0, True, 192, 0),       # residual broadcast over row % 192 (position embedding form)
     (1100, 640, 2560, 0, True, 0, 0),        # in-place residual stream form, ragged 256-row tiles
-    (256, 256, 128, 0, False, 0, 0),         # N % 256 == 0 and K % 128 == 0: the shapes the ping-pong form (10 - 12) takes; 2 K tiles
+    (256, 256, 128, 0, False, 0, 0),         # N % 256 == 0 and K % 128 == 0: the shapes the ping-pong form (10, the default there) takes; 2 K tiles
     (300, 512, 256, 0, True, 0, 0),          # ... ragged M
     (640, 512, 1280, 1, False, 0, 1),        # ... GELU, bf16 out
     (1100, 768, 2560, 0, True, 0, 0),        # ... 40 K tiles, residual
 ])
-@pytest.mark.parametrize("cfg", ["0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "11", "12"])     # every tile configuration of gemm_bf16.hip
+@pytest.mark.parametrize("cfg", ["", "0", "1", "2", "10"])     # the default selection and every tile configuration of gemm_bf16.hip
 def test_gemm_bf16(ctx, monkeypatch, cfg, m, n, k, act, use_res, res_mod, out_bf16):
-    monkeypatch.setenv("POSEPIPE_GEMM_CFG", cfg)
+    if cfg:
+        monkeypatch.setenv("POSEPIPE_GEMM_CFG", cfg)
+    else:
+        monkeypatch.delenv("POSEPIPE_GEMM_CFG", raising=False)
     rng = np.random.default_rng(m + n + k)
     a = rng.standard_normal((m, k), dtype=np.float32)
     w = rng.standard_normal((n, k), dtype=np.float32) / np.float32(np.sqrt(k))
@@ -238,7 +241,7 @@ def test_deconv_bf16_op(ctx):
     net.close()
 
 
-@pytest.mark.parametrize("cfg", ["2", "8", "9", "10", "11", "12"])
+@pytest.mark.parametrize("cfg", ["2", "10"])
 def test_two_stage_schedules_are_race_free_and_bit_equal_to_single_stage(ctx, monkeypatch, cfg):
     """The pipelined schedules (loads of K tile k + 1 in flight while tile k is multiplied; one barrier per K step) on a
     chip-filling problem, 25 launches: every launch must reproduce the first bit for bit, and all of them the plain
