@@ -1466,19 +1466,18 @@ static bool split_shape(const ConvArgs& a, int* taps, int* cin, int* mode, bool 
     return true;
 }
 
-// 8-wave product kernel for 1x1 / full-cover layers: 1 = 256 x 256 tile (Cout % 256 == 0), 2 = 512 x 128 (Cout % 128 == 0), 0 = no
+// product kernel (conv_split_gemm_kernel) for 1x1 / full-cover layers: 3 = 256 x 128 tile, 4 waves, two workgroups per CU; 0 = no.
+// Round 4: ONE form.  The per-workgroup timeline (tools/split_timeline.py) showed these layers bound by the CU's memory path, with the
+// epilogue as long as the K loop (256 -> 1024 at 40x68: 64k cycles of loop, 57k of epilogue) -- the 8-wave forms (256 x 256, 512 x 128: one
+// workgroup per CU) had nothing to run beside it.  With the residual lines of the epilogue requested back to back, the two-per-CU
+// form wins on EVERY layer of the detector (per 64 frames, 8-wave form -> this one): 512 -> 2048 1.76 -> 1.48 ms, 512 -> 128 1.74 -> 1.52,
+// 512 -> 256 2.00 -> 1.88, 1024 -> 256 2.88 -> 2.76, 2048 -> 512 1.13 -> 0.90, fc6 (K = 12544) 6.41 -> 6.24 (264 TFLOP/s), and
+// 128 -> 512 leaves the fp32 kernels for it (4.06 -> 3.74); 64 -> 256 stays there (5.59 vs 5.91): profiles/r04_product_kernel_forms.txt.
 static int gemm8_cfg(const ConvArgs& a, int mode, int cin) {
-    // Measured (profiles/r02_conv_split_layers.txt, 32 frames): fc6 (K = 12544) 130 (fp32 kernel) -> 216 TFLOP/s, fc7 126 -> 171,
-    // 1024 -> 256 at 40x68 126 -> 155, 512 -> 256 at 80x136 120 -> 139; a tie at 256 input channels (256 -> 1024: 109 / 110) and a
-    // loss below (64 -> 256: 63 -> 55, 128 -> 512: 87 -> 79: four or eight 16-channel stages do not amortise a 256 x 256 tile's
-    // start-up and 256 KB epilogue at one workgroup per CU).  Hence: from 512 input channels; at 256 input channels the 4-wave form
-    // (256 x 128 tile, two workgroups per CU: 256 -> 1024 97 -> 108, others even); below, the fp32 kernel (64 -> 256: 62 vs 47).
-    static const int on = env_int("POSEPIPE_SPLIT_GEMM8", 1), min_c = env_int("POSEPIPE_SPLIT_GEMM8_MIN_C", 512),
-                     min_c4 = env_int("POSEPIPE_SPLIT_GEMM4_MIN_C", 256);
+    static const int on = env_int("POSEPIPE_SPLIT_GEMM8", 1), min_c4 = env_int("POSEPIPE_SPLIT_GEMM4_MIN_C", 128);
     const bool tap_gather = a.KH * a.KW > 1 && cin == a.Cin;        // 3x3 stride 2: the tap kernel's product form, not this one
     if (!on || mode != MODE_GEMM || tap_gather) return 0;
-    if (cin < min_c) return (cin >= min_c4 && a.Cout % 128 == 0) ? 3 : 0;       // 3: 4 waves, 256 x 128 tile, two workgroups per CU
-    return a.Cout % 256 == 0 ? 1 : a.Cout % 128 == 0 ? 2 : 0;
+    return (cin >= min_c4 && a.Cout % 128 == 0) ? 3 : 0;
 }
 
 bool pp_conv_split_eligible(const ConvArgs& a) {
@@ -1628,7 +1627,7 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         s.mode = MODE_GEMM;
         s.S = (long long)a.M;
         s.col_major = 0;                     // the product kernel walks tile by tile, all columns of a tile back to back
-        const int BM = g8 == 2 ? 512 : 256, BN = g8 == 1 ? 256 : 128;
+        const int BM = 256, BN = 128;
         dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)(a.Cout / BN));
         s.gx = (int)grid.x; s.gy = (int)grid.y;
         static const int gemm_remap = env_int("POSEPIPE_SPLIT_GEMM_REMAP", 1);
@@ -1640,22 +1639,15 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         // process), needs no creation-time state and cannot make a created net ineligible
         const char* epi_env = getenv("POSEPIPE_SPLIT_GEMM_EPI");
         s.epi_lds = epi_env ? atoi(epi_env) : 1;
-        const int nwave = g8 == 3 ? 4 : 8;
+        const int nwave = 4;
         fill_divisors(s);
         const size_t lds = std::max<size_t>((size_t)2 * (3 * 2 * (BM + 4) * 16 + BN * 6 * 16), s.epi_lds ? (size_t)nwave * (16384 + 2048) : 0);
         static std::once_flag once;
         std::call_once(once, [] {
-            (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         });
-        if (g8 == 1)
-            hipLaunchKernelGGL((conv_split_gemm_kernel<2, 4>), grid, dim3(512), lds, stream, s);
-        else if (g8 == 2)
-            hipLaunchKernelGGL((conv_split_gemm_kernel<4, 2>), grid, dim3(512), lds, stream, s);
-        else
-            hipLaunchKernelGGL((conv_split_gemm_kernel<2, 2>), grid, dim3(256), lds, stream, s);
-        PP_TL_END(g8 == 1 ? "g256x256" : g8 == 2 ? "g512x128" : "g256x128", grid.x * grid.y);
+        hipLaunchKernelGGL((conv_split_gemm_kernel<2, 2>), grid, dim3(256), lds, stream, s);
+        PP_TL_END("g256x128", grid.x * grid.y);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             pp_set_error("conv_split_gemm launch failed: %s", hipGetErrorString(e));

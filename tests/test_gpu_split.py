@@ -506,8 +506,8 @@ def test_split_stride_2_inside_a_program(ctx, lib, monkeypatch):
 
 
 def test_split_1x1_with_shifted_residual(ctx, lib):
-    """FPN's lateral convs: 1x1 + (top-down map read at (y >> 1, x >> 1)) -- on the product kernels (256 -> 256: the 4-wave form,
-    512 / 1024 -> 256: the 8-wave form) the coarse residual is read with the shift in the epilogue, odd fine maps included"""
+    """FPN's lateral convs: 1x1 + (top-down map read at (y >> 1, x >> 1)) -- on the product kernel the coarse residual is read with
+    the shift in the epilogue, odd fine maps included"""
     rng = np.random.default_rng(61)
     for cin, h, w in ((256, 40, 68), (512, 21, 35), (1024, 10, 17)):
         x = rng.standard_normal((3, h, w, cin)).astype(np.float32)
@@ -540,8 +540,7 @@ def test_split_program_replays_from_a_hip_graph(ctx, lib):
 
 def test_product_kernel_epilogues_agree_bit_for_bit(ctx, lib, monkeypatch):
     """conv_split_gemm_kernel stores either from the registers (a lane: 4 channels of one pixel) or transposed through LDS (whole
-    128-byte lines, offsets from a per-pixel table): same arithmetic per element in the same order, so the same bits -- on the
-    8-wave 256 x 256 and 512 x 128 forms, the 4-wave form, ragged last tiles, strides, both residuals (one read with a shift),
+    128-byte lines, offsets from a per-pixel table): same arithmetic per element in the same order, so the same bits -- ragged last tiles, strides, both residuals (one read with a shift),
     ReLU first / last, halo output buffers inside a program, and fc6's full-cover product"""
     rng = np.random.default_rng(71)
 

@@ -52,6 +52,20 @@ def bench_decode(ctx, n=64, k=17, h=96, w=72, post=1, ks=17):
           f"permutation and the stream synchronisation of the C entry point]")
 
 
+def bench_nv12(ctx, n=64, h=1080, w=1920):
+    rng = np.random.default_rng(1)
+    nv = rng.integers(0, 256, (n, h * 3 // 2, w), dtype=np.uint8)
+    d_in, d_out = ctx.malloc(nv.nbytes), ctx.malloc(n * h * w * 3)
+    ctx.h2d(d_in, nv)
+
+    def run():
+        L.check(ctx.lib.pp_nv12_to_bgr(ctx.handle, C.c_void_p(d_in), n, h, w, C.c_void_p(d_out)), "nv12")
+    med, best = timed(ctx, run)
+    nbytes = nv.nbytes + n * h * w * 3
+    print(f"nv12_to_bgr {n} x {h}x{w}: {med * 1e3:8.1f} us (best {best * 1e3:.1f})  {nbytes / 1e6:.1f} MB  {nbytes / med / 1e9:.3f} TB/s algorithmic = "
+          f"{nbytes / med / 1e9 / 8.0:.3f} of 8 TB/s")
+
+
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "all"
     ctx = L.Context(0)
@@ -63,6 +77,9 @@ def main():
         bench_decode(ctx, h=64, w=48, post=0)  # configs[1]: W32 256x192, 'default'
         bench_decode(ctx, h=64, w=48, post=2, ks=11)   # ViTPose: UDP
         bench_decode(ctx, n=256)               # 4 persons per frame
+    if what in ("nv12", "all"):
+        bench_nv12(ctx)
+        bench_nv12(ctx, h=480, w=854)          # w % 4 == 2: the 16-bit path
 
 
 if __name__ == "__main__":
