@@ -530,9 +530,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
             for (int t = 0; t < T; ++t) {
                 const int cur = (PAR + t) & 1;
                 const int st = st0 + t;
-                if (st + 1 < nsteps) read_w(st + 1, wf[cur ^ 1]);
-                if (t != T / 2) issue_w(st + 3);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int pb = 0; pb < PXB; ++pb) {
                     if (pb == PXB - 1 && t == T / 2) {
@@ -543,6 +540,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
                     }
                     mma(wf[cur], pb);
                     __builtin_amdgcn_sched_barrier(0);
+                    if (pb == 0) {
+                        // (round 4) the next step's fragment reads and the DMA request sit BEHIND the first MFMAs of the step: straight
+                        // after the barrier both waves of a SIMD are here at once, and everything issued before the first MFMA is
+                        // matrix-pipe idle time.  Same-box A/B (profile_net det 64 / w48 128): 256 -> 256 at 160x272 259.9 -> 264.5
+                        // TFLOP/s, 80x136 227 -> 233, 40x68 221 -> 228, HRNet 192 -> 192 179 -> 189.  Moving the BARRIER itself behind the
+                        // first MFMA group as well (the group needs nothing the barrier guarantees) measured no further gain (260 vs 260):
+                        // the loop runs at the chip's power limit there, a saved cycle comes back as a lower clock.
+                        if (st + 1 < nsteps) read_w(st + 1, wf[cur ^ 1]);
+                        if (t != T / 2) issue_w(st + 3);
+                    }
                     if (t + 1 < T) load_x(pbuf, t + 1, pb);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -569,9 +576,6 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
             for (int t = 0; t < T; ++t) {
                 const int cur = (PAR + t) & 1;
                 const int st = st0 + t;
-                if (st + 1 < nsteps) read_w(st + 1, wf[cur ^ 1]);
-                if (t != T - 1) issue_w(st + 3);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int pb = 0; pb < PXB; ++pb) {
                     if (pb == 0 && t == T - 1) {
@@ -584,6 +588,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
                     }
                     mma(wf[cur], pb);
                     __builtin_amdgcn_sched_barrier(0);
+                    if (pb == 0) {       // behind the first MFMAs of the step, see chunk8
+                        if (st + 1 < nsteps) read_w(st + 1, wf[cur ^ 1]);
+                        if (t != T - 1) issue_w(st + 3);
+                    }
                     if (t + 1 < T) load_x(smem, t + 1, pb);
                     __builtin_amdgcn_sched_barrier(0);
                 }
