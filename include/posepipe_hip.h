@@ -414,7 +414,8 @@ int pp_linear_sum_assignment(const double* cost, int n_rows, int n_cols, int32_t
  * (wrappers/mmtrack.py:45), batched over frames.  net_a: image program (input [Hp][Wp][4]; outputs:
  * 5 RPN objectness maps [H][W][3], 5 RPN delta maps [H][W][12], FPN P2..P5 [H][W][256]); net_b: RoI-head
  * program (input [7][7][256] per RoI; outputs cls [1][1][2], reg [1][1][4]; max_batch >= 1000 per frame).
- * bufs_a = {input, cls0..4, reg0..4, p2..p5} (15 ids), bufs_b = {roi_in, cls, reg}.
+ * bufs_a = {input, cls0..4, reg0..4, p2..p5} (15 ids), bufs_b = {roi_in, cls, reg}.  cls_l == reg_l (all levels) selects the fused
+ * head layout: ONE map [H][W][16] per level, objectness in channels 0 - 2, deltas in 3 - 14 (rpn_cls and rpn_reg as one convolution).
  * lut: [3][256] fp32 = (v - mean[c]) * (1/std[c]) (mmcv imnormalize); channel c of the decoded BGR frame
  * feeds tensor channel c (the reference's double BGR<->RGB swap, wrappers/mmtrack.py:43 + to_rgb=True).
  * base_anchors: [5][3][4] fp32 (AnchorGenerator scales [8], ratios [.5,1,2], strides 4..64).

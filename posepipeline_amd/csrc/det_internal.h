@@ -4,8 +4,10 @@
 #include <cstdint>
 
 struct DetRpnArgs {
-    const float* cls[5];   // RPN objectness logits per level [frame][H][W][3]
-    const float* reg[5];   // RPN deltas per level [frame][H][W][12]
+    const float* cls[5];   // RPN objectness logits per level [frame][H][W][3] -- or, pitch 16: channels 0 - 2 of the fused head's map
+    const float* reg[5];   // RPN deltas per level [frame][H][W][12] -- or cls + 3 of the fused map (channels 3 - 14)
+    int pitch;             // 0: two maps (3 and 12 channels); 16: ONE [frame][H][W][16] map per level (round 4: rpn_cls and rpn_reg as
+                           // one 15-channel convolution: the 256-channel input is read once instead of twice)
     int h[5], w[5], stride[5];
     float base[5][3][4];   // AnchorGenerator base anchors (float32, computed by the host like mmdet)
     int nms_pre;           // 1000

@@ -100,8 +100,9 @@ __global__ __launch_bounds__(256) void det_preprocess_kernel(const uint8_t* __re
 
 // ---- rpn_select: one block per (level, frame) --------------------------------------------------------------
 struct RpnLevels {
-    const float* cls[5];      // [frame][H][W][3]
-    const float* reg[5];      // [frame][H][W][12]
+    const float* cls[5];      // [frame][H][W][3], or channels 0 - 2 of a 16-channel map (pitch 16)
+    const float* reg[5];      // [frame][H][W][12], or channels 3 - 14 of it
+    int pitch;
     int h[5], w[5], stride[5];
     float base[5][3][4];      // base anchors
 };
@@ -112,8 +113,11 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(RpnLevels L, int nms_p
     // outputs per frame: cand_box [5*nms_pre][4], cand_score [5*nms_pre], cand_cnt [5]
     const int lvl = blockIdx.x, f = blockIdx.y;
     const int N = L.h[lvl] * L.w[lvl] * 3;
-    const float* cls = L.cls[lvl] + (size_t)f * N;
-    const float* reg = L.reg[lvl] + (size_t)f * N * 4;
+    // anchor i = (pixel i / 3, anchor i % 3): logit at cls[i], deltas at reg[4 i ..] of the two-map layout; pixel * 16 + a and
+    // pixel * 16 + 3 + 4 a of the fused map
+    const bool fused = L.pitch == 16;
+    const float* cls = L.cls[lvl] + (size_t)f * (fused ? (size_t)(N / 3) * 16 : (size_t)N);
+    const float* reg = L.reg[lvl] + (size_t)f * (fused ? (size_t)(N / 3) * 16 : (size_t)N * 4);
     int lvl_off = 0;
     for (int l = 0; l < lvl; ++l) lvl_off += L.h[l] * L.w[l] * 3;
     float* sc = score_scratch + (size_t)f * scratch_stride + lvl_off;
@@ -125,7 +129,7 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(RpnLevels L, int nms_p
     __shared__ unsigned s_prefix;
     __shared__ int s_need;
 
-    for (int i = threadIdx.x; i < N; i += blockDim.x) sc[i] = sigmoid_f32(cls[i]);
+    for (int i = threadIdx.x; i < N; i += blockDim.x) sc[i] = sigmoid_f32(fused ? cls[(i / 3) * 16 + i % 3] : cls[i]);
     __syncthreads();
     const int k = min(nms_pre, N);
     int n_sel;
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(RpnLevels L, int nms_p
         const int x = pos % Wl, y = pos / Wl;
         const float sx = (float)x * stride, sy = (float)y * stride;
         float anchor[4] = {L.base[lvl][a][0] + sx, L.base[lvl][a][1] + sy, L.base[lvl][a][2] + sx, L.base[lvl][a][3] + sy};
-        const float* d = reg + (size_t)idx * 4;
+        const float* d = fused ? reg + (size_t)(idx / 3) * 16 + (idx % 3) * 4 : reg + (size_t)idx * 4;
         float dd[4] = {d[0], d[1], d[2], d[3]};
         float box[4];
         delta2bbox(anchor, dd, ones, box);
@@ -686,6 +690,7 @@ int det_enqueue_preprocess(hipStream_t s, const uint8_t* frames, int n_frames, i
 int det_enqueue_rpn(hipStream_t s, const DetRpnArgs& a, int n_frames) {
     RpnLevels L;
     for (int l = 0; l < 5; ++l) {
+        L.pitch = a.pitch;
         L.cls[l] = a.cls[l]; L.reg[l] = a.reg[l]; L.h[l] = a.h[l]; L.w[l] = a.w[l]; L.stride[l] = a.stride[l];
         memcpy(L.base[l], a.base[l], sizeof(L.base[l]));
     }

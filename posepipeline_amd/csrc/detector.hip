@@ -21,6 +21,7 @@ struct pp_detector {
     pp_net* netA = nullptr;   // image -> FPN levels + RPN maps
     pp_net* netB = nullptr;   // RoI features -> (cls, reg)
     int in_buf = 0, cls_buf[5], reg_buf[5], fpn_buf[4], roi_in = 0, roi_cls = 0, roi_reg = 0;
+    int rpn_pitch = 0;       // 16: cls_buf[l] == reg_buf[l] is the fused head's 16-channel map
     int H = 0, W = 0, nh = 0, nw = 0, Hp = 0, Wp = 0;
     float sfx = 1.f, sfy = 1.f;
     int max_frames = 0, nms_pre = 1000, max_rois = 1000, max_det = 100, max_n = 0;
@@ -144,9 +145,17 @@ int pp_detector_create(pp_net* netA, pp_net* netB, const int32_t* bufs_a, const 
         d->reg_buf[l] = bufs_a[6 + l];
         d->lvl_stride[l] = 4 << l;
         int ch, cw, cc, rh, rw, rc_;
+        if (d->cls_buf[l] == d->reg_buf[l]) {
+            // fused RPN head: ONE 16-channel map per level (objectness 0 - 2, deltas 3 - 14, channel 15 unused); all levels alike
+            PP_REQUIRE(pp_net_dims(netA, d->cls_buf[l], &ch, &cw, &cc) == PP_OK && cc == 16, "fused rpn map of level %d must have 16 channels", l);
+            PP_REQUIRE(l == 0 || d->rpn_pitch == 16, "pp_detector_create: fused and separate rpn maps mixed");
+            d->rpn_pitch = 16;
+        } else {
+        PP_REQUIRE(d->rpn_pitch == 0, "pp_detector_create: fused and separate rpn maps mixed");
         PP_REQUIRE(pp_net_dims(netA, d->cls_buf[l], &ch, &cw, &cc) == PP_OK && cc == 3, "rpn_cls level %d must have 3 channels", l);
         PP_REQUIRE(pp_net_dims(netA, d->reg_buf[l], &rh, &rw, &rc_) == PP_OK && rc_ == 12 && rh == ch && rw == cw,
                    "rpn_reg level %d shape mismatch", l);
+        }
         d->lvl_h[l] = ch; d->lvl_w[l] = cw;
         d->scratch_stride += ch * cw * 3;
     }
@@ -252,7 +261,8 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
         void *pc, *pr;
         pp_net_buffer(d->netA, d->cls_buf[l], &pc, nullptr);
         pp_net_buffer(d->netA, d->reg_buf[l], &pr, nullptr);
-        ra.cls[l] = (const float*)pc; ra.reg[l] = (const float*)pr;
+        ra.pitch = d->rpn_pitch;
+        ra.cls[l] = (const float*)pc; ra.reg[l] = d->rpn_pitch == 16 ? (const float*)pc + 3 : (const float*)pr;
         ra.h[l] = d->lvl_h[l]; ra.w[l] = d->lvl_w[l]; ra.stride[l] = d->lvl_stride[l];
         memcpy(ra.base[l], d->base[l], sizeof(ra.base[l]));
     }

@@ -150,11 +150,17 @@ def build_image_program(sd: dict, hp: int, wp: int, prefix="detector.") -> Progr
         h, w, _ = pb.dims(lat[i])
         outs.append(cbias(lat[i], f"neck.fpn_convs.{i}.conv", pad=1, out=pb.buf(h, w, 256, name=f"p{i + 2}")))
     outs.append(pb.maxpool(outs[3], 1, 2, 0, name="p6"))
+    # RPN head: rpn_cls (3 anchors) and rpn_reg (3 x 4 deltas) as ONE 1x1 convolution of 15 output channels into a 16-channel map
+    # per level (objectness 0 - 2, deltas 3 - 14): the 256-channel rpn_conv output is read once instead of twice (at 160x272 that read
+    # is 2.85 GB per 64 frames; the two heads were 1.5 ms of the step, HBM-bound).  Every output channel is its own fmaf chain over k,
+    # so the values are the two separate convolutions' bit for bit (tests/test_gpu_detector.py compares them with the oracle's maps).
+    w_rpn = np.concatenate([sd[p + "rpn_head.rpn_cls.weight"], sd[p + "rpn_head.rpn_reg.weight"]], axis=0)
+    b_rpn = np.concatenate([sd[p + "rpn_head.rpn_cls.bias"], sd[p + "rpn_head.rpn_reg.bias"]], axis=0)
+    assert w_rpn.shape[:2] == (15, 256)
     for l, f in enumerate(outs):
         h, w, _ = pb.dims(f)
         t = cbias(f, "rpn_head.rpn_conv", pad=1, relu=R)
-        cbias(t, "rpn_head.rpn_cls", out=pb.buf(h, w, 3, name=f"rpn_cls{l}"))
-        cbias(t, "rpn_head.rpn_reg", out=pb.buf(h, w, 12, name=f"rpn_reg{l}"))
+        pb.conv(t, w_rpn, b_rpn, name="rpn_head.rpn_cls+rpn_reg", out=pb.buf(h, w, 16, name=f"rpn{l}"))
     return pb.build()
 
 
@@ -197,7 +203,8 @@ class Detector:
         self.net_a = Net(ctx, self.prog_a, max_batch=max_frames, blob_dev=blob_fn("det_a", self.prog_a), numerics=numerics)
         self.net_b = Net(ctx, self.prog_b, max_batch=max_frames * self.MAX_ROIS, blob_dev=blob_fn("det_b", self.prog_b), numerics=numerics)
         na = self.prog_a.named
-        bufs_a = np.array([na["input"]] + [na[f"rpn_cls{l}"] for l in range(5)] + [na[f"rpn_reg{l}"] for l in range(5)] +
+        # (cls_l == reg_l: the fused RPN head's 16-channel map, see pp_detector_create)
+        bufs_a = np.array([na["input"]] + [na[f"rpn{l}"] for l in range(5)] + [na[f"rpn{l}"] for l in range(5)] +
                           [na[f"p{i}"] for i in range(2, 6)], np.int32)
         nb = self.prog_b.named
         bufs_b = np.array([nb["roi_in"], nb["cls"], nb["reg"]], np.int32)

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 def small_td(ctx):
     spec = hrnet.HRNetSpec(32, 17, 64, 64)
     sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(spec), seed=1)
-    net = Net(ctx, hrnet.build_hrnet_program(spec, sd), max_batch=8)
+    net = Net(ctx, hrnet.build_hrnet_program(spec, sd), max_batch=8, numerics="exact")      # (module scope: see test_gpu_detector.setup)
     return net, ops.TopDown(net, 17, flip_perm=hrnet.flip_perm(17), post="unbiased")
 
 
