@@ -27,6 +27,13 @@ python tools/pmc_traffic_update.py cascade_chunk64_persons1 $O/pmc_summary.txt "
 bash tools/pmc_sq.sh > $O/pmc_sq.log 2>&1; cp gpurun_out/pmc_sq/summary.txt $O/cascade_pmc_sq.txt
 bash tools/pmc_kernel.sh roi_align_sep_kernel roi python bench.py --profile-serial --steps 1 --warmup 1 > $O/roi_pmc.log 2>&1; cp gpurun_out/pmc_roi/summary.txt $O/roi_pmc.txt
 for w in "w48 128" "det 64" "w32 128"; do set -- $w; python tools/profile_net.py $1 $2 > $O/per_op_$1_b$2.txt 2>&1; POSEPIPE_CONV_EXACT=1 python tools/profile_net.py $1 $2 > $O/per_op_$1_b$2_exact.txt 2>&1; done
+# the HBM-bound kernels: duration + FETCH / WRITE counters, one shape per run
+DECODE_ONE=64 bash tools/hbm_kernel_profile.sh flip_merge_decode decode_n64 60162048 python tools/hbm_kernels_bench.py decode > /dev/null 2>&1; cp gpurun_out/hbm_decode_n64.txt $O/hbm_decode_n64.txt
+DECODE_ONE=256 bash tools/hbm_kernel_profile.sh flip_merge_decode decode_n256 240648192 python tools/hbm_kernels_bench.py decode > /dev/null 2>&1; cp gpurun_out/hbm_decode_n256.txt $O/hbm_decode_n256.txt
+NV12_ONE=1 bash tools/hbm_kernel_profile.sh nv12_to_bgr nv12_1080p 597196800 python tools/hbm_kernels_bench.py nv12 > /dev/null 2>&1; cp gpurun_out/hbm_nv12_1080p.txt $O/hbm_nv12_1080p.txt
+bash tools/hbm_kernel_profile.sh det_preprocess det_preprocess 1111228416 python bench.py --steps 3 --warmup 1 --light --cpu-frames 0 > /dev/null 2>&1; cp gpurun_out/hbm_det_preprocess.txt $O/hbm_det_preprocess.txt
+python bench.py --workload c5 --cpu-frames 0 > $O/bench_c5.json 2> $O/bench_c5.err
+python bench.py --workload cascade5 --cpu-frames 0 --steps 6 --warmup 2 > $O/bench_cascade5.json 2> $O/bench_cascade5.err
 python tools/split_check.py > $O/conv_split_accuracy.txt 2>&1
 python -m pytest tests/test_gpu_split.py -q -s -k reordering 2>&1 | grep "heat-maps\|joints\|passed\|failed" > $O/conv_split_control.txt
 # keep only the small files
