@@ -241,12 +241,13 @@ class Dist:
     def describe(self):
         """what actually ran: world size as the process group reports it, backend, and every rank's device"""
         me = {"rank": self.rank, "local_rank": self.local_rank, "pid": os.getpid()}
-        try:
-            import torch
-            if torch.cuda.is_available():
-                me["device"] = "cuda:%d %s" % (self.local_rank, torch.cuda.get_device_name(self.local_rank))
-        except Exception:
-            pass
+        if self.dist is not None:       # (N = 1 never imports torch: a cold `import torch` costs 1 - 2 minutes on a fresh box)
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    me["device"] = "cuda:%d %s" % (self.local_rank, torch.cuda.get_device_name(self.local_rank))
+            except Exception:
+                pass
         ranks = self.gather_obj(me)
         return {"world_size": self.dist.get_world_size() if self.dist is not None else 1,
                 "backend": ("rccl (torch.distributed 'nccl')" if self.backend == "nccl" else self.backend) if self.dist is not None else None,
@@ -560,6 +561,7 @@ def run_cascade_sharded(args, D, ctx, cas):
     stages = parallel.cascade_stages(cas, lambda first, n: rb[:n])
 
     class _Local:      # world_size 1: the torch.distributed calls parallel.py uses
+        numpy_only = True      # parallel._Gather keeps the slab on the host: no torch import in a one-rank run
         def get_rank(self): return 0
         def get_world_size(self): return 1
         def all_gather(self, outs, t): outs[0].copy_(t)

@@ -99,9 +99,14 @@ class _Gather:
     start() returns immediately (async_op), result() waits and returns [world][rows][cols] as numpy."""
 
     def __init__(self, dist, device, local: np.ndarray):
-        import torch
         self.world = dist.get_world_size()
         self.shape = local.shape
+        self.host = None
+        if self.world == 1 and getattr(dist, "numpy_only", False):      # a one-rank stand-in: nothing to exchange, no torch
+            self.host = np.array(local, copy=True)[None]
+            self.work = None
+            return
+        import torch
         # the slab keeps its dtype when torch can carry it (float32 / float64 / int64 / int32); anything else travels as float32
         if local.dtype not in (np.float32, np.float64, np.int64, np.int32):
             local = local.astype(np.float32)
@@ -116,6 +121,8 @@ class _Gather:
             self.work = dist.all_gather(outs, t)
 
     def result(self) -> np.ndarray:
+        if self.host is not None:
+            return self.host
         if self.work is not None and hasattr(self.work, "wait"):
             self.work.wait()
         return self.out.cpu().numpy().reshape((self.world,) + tuple(self.shape))

@@ -304,3 +304,27 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "plumbing"], capture_output=True, text=True, env=env, timeout=300)
     line = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][0])
     assert line["n_gpus"] == 1 and line["distributed"]["world_size"] == 1 and line["distributed"]["backend"] is None
+
+
+def test_single_rank_bench_never_imports_torch():
+    """N = 1 is what the driver times on a fresh box, where a cold `import torch` costs 1 - 2 minutes: neither the rank plumbing nor
+    the one-rank stand-in of the sharded mode (parallel._Gather with a `numpy_only` dist) may pull it in"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import runpy, sys; sys.argv = ['bench.py', '--workload', 'plumbing']; "
+            f"runpy.run_path({os.path.join(root, 'bench.py')!r}, run_name='__main__'); "
+            "assert 'torch' not in sys.modules, 'bench.py imported torch at N = 1'\n"
+            f"sys.path.insert(0, {root!r})\n"
+            "import numpy as np\n"
+            "from posepipeline_amd import parallel\n"
+            "class D:\n"
+            "    numpy_only = True\n"
+            "    def get_world_size(self): return 1\n"
+            "    def get_rank(self): return 0\n"
+            "g = parallel._Gather(D(), 'cpu', np.arange(6, dtype=np.float32).reshape(2, 3))\n"
+            "r = g.result(); assert r.shape == (1, 2, 3) and r[0, 1, 2] == 5\n"
+            "assert 'torch' not in sys.modules\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
