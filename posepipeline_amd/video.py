@@ -10,6 +10,11 @@ below exist because neither OpenCV nor ffmpeg is installed in the build / GPU im
 BGR sources yield frames in BGR order, like `cap.read()`.  NV12 sources (a decoder's native output: Y plane [H][W], then
 interleaved UV [H/2][W]; half the bytes) hand their raw planes to streaming.FrameStreamer, which uploads them as they are and
 converts on the device (csrc/nv12.hip, OpenCV's COLOR_YUV2BGR_NV12 arithmetic) -- there is no host conversion path.
+PARITY NOTE: an NV12 source is tolerance-parity, not bit-parity, with the reference's frames.  `cv2.VideoCapture.read()` converts
+the decoder's planes with FFmpeg / swscale (yuv420p -> bgr24), whose rounding differs from `cvtColor(COLOR_YUV2BGR_NV12)` by about
++-1 level per channel; the device kernel equals the restated cvtColor arithmetic bit for bit (oracle/nv12.py, itself unpinned: no
+cv2 here), so detector / pose INPUTS differ from the reference's by that much when the source is NV12.  Bit-parity of the inputs
+holds for BGR sources (what `cap.read()` returned).
 """
 from __future__ import annotations
 
