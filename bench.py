@@ -309,7 +309,10 @@ def run_cascade(args, D):
     else:
         pose_spec = hrnet.hrnet_w48_384x288()
         pose_sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(pose_spec), seed=1)
-    lift_sd = synth.synth_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3)
+    # lifting weights: metre-sized max-norm contractions (synth.smooth_lifting_state_dict) -- the lifting stage is 0.03 GFLOP per frame, its
+    # weight VALUES do not touch the timed region, and with them the readout's 3D difference is a statement in millimetres (seeded
+    # He-normal lifting weights amplify 2D differences ~5x and are not metre-sized: DESIGN.md 2a)
+    lift_sd = synth.smooth_lifting_state_dict(vp3d.videopose3d_param_shapes(vp3d.VideoPose3DSpec()), seed=3)
     B, P = args.chunk, args.persons
     # N > 1: every program's blob is rank 0's, delivered by one RCCL broadcast per program as a device tensor that
     # pp_net_create_mem consumes in place (the locally built state dicts only define the program structure)
@@ -674,7 +677,7 @@ def cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames, gt, n_frames, cascade
         readout[mode] = {"frames": len(ref), "frames_with_bit_identical_detections": eq, "oracle_detections": n_det,
                          "device_detections": n_dev, "oracle_detections_matched_within_0.05px": n_match,
                          "max_abs_diff_boxes_px": box_d, "max_abs_diff_scores": sc_d, "max_abs_diff_2d_px": d2, "max_abs_diff_3d": d3,
-                         "note": "seeded-random weights: the detector's 100-of-~1000 cut and NMS sit on near-ties, heat-maps are noise "
+                         "note": "seeded-random detector / pose weights (lifting weights: metre-sized contractions): the detector's 100-of-~1000 cut and NMS sit on near-ties, heat-maps are noise "
                                  "(ill-conditioned arg-max / DARK step); the tolerance claims are tests/test_gpu_parity_modes.py "
                                  "(well-conditioned weights, margin-aware detector check)"}
     readout["well_conditioned_end_to_end"] = parity_well_conditioned(cascades.get("default"), frames, gt, pick[:3])
