@@ -204,3 +204,25 @@ def test_two_ranks_1080p_default_numerics(ctx):
             assert sorted(g.files) == sorted(ref)
             for k, v in ref.items():
                 assert np.array_equal(g[k], v), (r, k)
+
+
+def test_bench_gpus2_launches_two_ranks_on_real_kernels():
+    """`python bench.py --gpus 2` (no torchrun: the form the driver may use) on the real cascade: two ranks -- sharing this box's one GPU,
+    collectives over gloo -- each time their own chunks; rank 0 prints ONE JSON line with n_gpus = 2, the process group's world size and
+    both ranks' step times.  (The RCCL runs differ only in the backend string and in one GPU per rank.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, POSEPIPE_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "POSEPIPE_CONV_EXACT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--chunk", "8",
+                          "--cpu-frames", "0"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["distributed"]["world_size"] == 2 and len(line["distributed"]["ranks"]) == 2
+    assert line["value"] > 0 and len(line["per_rank_ms_per_step"]) == 2 and line["scaling"] == "weak"
+    assert line["config"]["frames_per_step_per_gpu"] == 8 and "secondary" not in line      # side legs are N = 1 only
