@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 8   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
+#define PP_ABI_VERSION 9   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
                               3: PP_OP_VIT_ENCODER / PP_OP_DEPTH_TO_SPACE, bf16 building blocks, UDP top-down (post 2)
                               4: pp_memcpy_d2d, pp_net_create_mem (weights already on the device, e.g. an RCCL broadcast)
                               5: pp_buf.pad (zero halo of conv-only buffers), PP_OP_AVGPOOL, pp_crop_resize_bilinear,
@@ -41,7 +41,9 @@ extern "C" {
                               7: pp_net_create_ex / pp_net_numerics: the numerics of a program are fixed when it is created (a per-net
                                  property, no longer read from the process-wide switch at launch time); pp_op gained in2 / in3 /
                                  up2_log2 / up3_log2 (sizeof(pp_op) 104 -> 120)
-                              8: pp_upload_begin_nv12 / pp_nv12_to_bgr (NV12 frame source) */
+                              8: pp_upload_begin_nv12 / pp_nv12_to_bgr (NV12 frame source)
+                              9: PP_NET_NUMERICS_SPLIT_BF16 / _F16, pp_conv_split_kind, pp_net_split_kind: the split convolutions have a
+                                 second form -- two float16 terms per operand, three products (conv_split.hip, round 5) */
 
 typedef enum {
     PP_OK = 0,
@@ -193,11 +195,16 @@ int pp_net_create_mem(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bu
  * oracle/conv_ref.c), PP_NET_NUMERICS_SPLIT = eligible layers on the bf16 matrix cores (three-way split, see pp_conv_exact). */
 #define PP_NET_NUMERICS_DEFAULT 0
 #define PP_NET_NUMERICS_EXACT 1
-#define PP_NET_NUMERICS_SPLIT 2
+#define PP_NET_NUMERICS_SPLIT 2        /* the split form pp_conv_split_kind selects at this moment */
+#define PP_NET_NUMERICS_SPLIT_BF16 3   /* three bfloat16 terms per operand, six products (rounds 2 - 4) */
+#define PP_NET_NUMERICS_SPLIT_F16 4    /* two float16 terms per operand (per-channel / per-tensor power-of-two scales), three products */
 int pp_net_create_ex(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, int n_bufs,
                      const float* weights, size_t n_weights, int weights_mem, int max_batch, int numerics, pp_net** out);
 /* PP_NET_NUMERICS_EXACT or PP_NET_NUMERICS_SPLIT: what the net was created with (never DEFAULT) */
 int pp_net_numerics(pp_net* net);
+/* which split form a PP_NET_NUMERICS_SPLIT net runs (fixed at creation): PP_NET_NUMERICS_SPLIT_BF16 or PP_NET_NUMERICS_SPLIT_F16;
+ * PP_NET_NUMERICS_EXACT for an exact net */
+int pp_net_split_kind(pp_net* net);
 void pp_net_destroy(pp_net* net);
 /* device address of activation buffer `buf` (batch-major, then the pp_buf layout) */
 int pp_net_buffer(pp_net* net, int buf, void** dptr, size_t* bytes_per_sample);
@@ -240,6 +247,11 @@ int pp_conv_variant(int variant);
  * exact = 1 (or POSEPIPE_CONV_EXACT=1): every layer on the float32 MFMA kernels, bit-identical to oracle/conv_ref.c.
  * exact = -1: back to the environment's choice. */
 int pp_conv_exact(int exact);
+/* Process-wide DEFAULT split form: what PP_NET_NUMERICS_SPLIT (and DEFAULT, when it resolves to split) nets created LATER and the
+ * single-op entry point get.  f16 = 1: two float16 terms per operand and three v_mfma_f32_32x32x16_f16 products per term (half the
+ * matrix work of the six-product form; same float32 accumulation, error against a float64 convolution still that of the float32
+ * FMA chain, tests/test_gpu_split.py); 0: three bfloat16 terms, six products; -1: the environment's choice (POSEPIPE_SPLIT_F16). */
+int pp_conv_split_kind(int f16);
 
 /* single convolution on caller-provided device/host buffers (tests, VideoPose3D, FC layers).
  * x: [n][hin][win][cin]; bias: [cout_pad16]; y per op flags.

@@ -21,7 +21,9 @@ PP_OP_AVGPOOL = 9
 PP_RELU_NONE, PP_RELU_LAST, PP_RELU_FIRST = 0, 1, 2
 PP_ACT_LEAKY, PP_ACT_MISH, PP_ACT_ELU, PP_ACT_SWISH = 3, 4, 5, 6
 PP_NET_NUMERICS_DEFAULT, PP_NET_NUMERICS_EXACT, PP_NET_NUMERICS_SPLIT = 0, 1, 2
-NUMERICS = {None: 0, "default": 0, "exact": 1, "split": 2}
+PP_NET_NUMERICS_SPLIT_BF16, PP_NET_NUMERICS_SPLIT_F16 = 3, 4
+# "split": the form pp_conv_split_kind / POSEPIPE_SPLIT_F16 select when the net is created; the two forms by name
+NUMERICS = {None: 0, "default": 0, "exact": 1, "split": 2, "split_bf16": 3, "split_f16": 4}
 
 
 class PosePipeHipError(RuntimeError):
@@ -101,6 +103,8 @@ SIGNATURES = {
     "pp_net_create_mem": (_i, [_vp, C.POINTER(pp_op), _i, C.POINTER(pp_buf), _i, _vp, _sz, _i, _i, C.POINTER(_vp)]),
     "pp_net_create_ex": (_i, [_vp, C.POINTER(pp_op), _i, C.POINTER(pp_buf), _i, _vp, _sz, _i, _i, _i, C.POINTER(_vp)]),
     "pp_net_numerics": (_i, [_vp]),
+    "pp_net_split_kind": (_i, [_vp]),
+    "pp_conv_split_kind": (_i, [_i]),
     "pp_net_destroy": (None, [_vp]),
     "pp_net_buffer": (_i, [_vp, _i, C.POINTER(_vp), C.POINTER(_sz)]),
     "pp_net_run": (_i, [_vp, _i, _i, _i]),
@@ -182,12 +186,17 @@ def default_numerics(mode):
     (Net, Cascade, Detector, the YOLO / ReID encoders) instead; this context manager is for single-threaded tests."""
     lib = load_library()
     prev = _DEFAULT_NUMERICS[0]
-    check(lib.pp_conv_exact({None: -1, "default": -1, "exact": 1, "split": 0}[mode]), "pp_conv_exact")
+
+    def apply(m):
+        # "split_bf16" / "split_f16" also pin the split FORM (pp_conv_split_kind); the other modes leave it to the environment
+        check(lib.pp_conv_exact({None: -1, "default": -1, "exact": 1, "split": 0, "split_bf16": 0, "split_f16": 0}[m]), "pp_conv_exact")
+        check(lib.pp_conv_split_kind({"split_bf16": 0, "split_f16": 1}.get(m, -1)), "pp_conv_split_kind")
+    apply(mode)
     _DEFAULT_NUMERICS[0] = mode
     try:
         yield
     finally:
-        check(lib.pp_conv_exact({None: -1, "default": -1, "exact": 1, "split": 0}[prev]), "pp_conv_exact")
+        apply(prev)
         _DEFAULT_NUMERICS[0] = prev
 
 

@@ -221,6 +221,7 @@ struct pp_net {
     unsigned char* wsplit = nullptr;
     std::vector<long long> wsplit_off;   // per op: byte offset into wsplit, -1: the op runs on the fp32-MFMA kernels
     int numerics = PP_NET_NUMERICS_EXACT;   // fixed at creation (ABI 7)
+    int split_f16 = 0;                      // split nets: the fp16 form (ABI 9), fixed at creation as well
     float* arena = nullptr;
     size_t arena_floats = 0;
     int max_batch = 0;
@@ -409,6 +410,7 @@ static ConvArgs net_conv_args(pp_net* net, const pp_op& op, int batch) {
     const size_t idx = &op - net->ops.data();
     a.wsplit = (net->wsplit && idx < net->wsplit_off.size() && net->wsplit_off[idx] >= 0) ? net->wsplit + net->wsplit_off[idx] : nullptr;
     a.numerics = net->numerics;
+    a.split_f16 = net->split_f16;
     return a;
 }
 
@@ -470,11 +472,15 @@ int pp_net_create_mem(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bu
 }
 
 int pp_net_numerics(pp_net* net) { return net ? net->numerics : PP_ERR_ARG; }
+int pp_net_split_kind(pp_net* net) {
+    if (!net) return PP_ERR_ARG;
+    return net->numerics != PP_NET_NUMERICS_SPLIT ? PP_NET_NUMERICS_EXACT : net->split_f16 ? PP_NET_NUMERICS_SPLIT_F16 : PP_NET_NUMERICS_SPLIT_BF16;
+}
 
 int pp_net_create_ex(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, int n_bufs,
                      const float* weights, size_t n_weights, int weights_mem, int max_batch, int numerics, pp_net** out) {
     PP_REQUIRE(ctx && ops && bufs && weights && out, "pp_net_create: NULL argument");
-    PP_REQUIRE(numerics >= PP_NET_NUMERICS_DEFAULT && numerics <= PP_NET_NUMERICS_SPLIT, "pp_net_create_ex: bad numerics %d", numerics);
+    PP_REQUIRE(numerics >= PP_NET_NUMERICS_DEFAULT && numerics <= PP_NET_NUMERICS_SPLIT_F16, "pp_net_create_ex: bad numerics %d", numerics);
     PP_REQUIRE(weights_mem == PP_MEM_HOST || weights_mem == PP_MEM_DEVICE, "pp_net_create: bad weights_mem %d", weights_mem);
     PP_REQUIRE(n_ops > 0 && n_bufs > 0 && max_batch > 0, "pp_net_create: empty program");
     *out = nullptr;
@@ -486,6 +492,10 @@ int pp_net_create_ex(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* buf
     net->n_weights = n_weights;
     // the process-wide switch is read HERE, once: later pp_conv_exact calls (or other threads) do not change this net
     net->numerics = numerics != PP_NET_NUMERICS_DEFAULT ? numerics : (pp_conv_split_enabled() ? PP_NET_NUMERICS_SPLIT : PP_NET_NUMERICS_EXACT);
+    if (net->numerics >= PP_NET_NUMERICS_SPLIT) {       // the split form: named, or the process-wide default at this moment
+        net->split_f16 = net->numerics == PP_NET_NUMERICS_SPLIT ? pp_conv_split_f16_default() : net->numerics == PP_NET_NUMERICS_SPLIT_F16;
+        net->numerics = PP_NET_NUMERICS_SPLIT;
+    }
     size_t off = 0;
     for (int b = 0; b < n_bufs; ++b) {
         PP_REQUIRE(bufs[b].h > 0 && bufs[b].w > 0 && bufs[b].c > 0 && bufs[b].pad >= 0 && bufs[b].pad <= 8, "buffer %d has an empty dim / bad halo", b);

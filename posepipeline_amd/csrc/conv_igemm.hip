@@ -640,6 +640,22 @@ bool pp_conv_split_enabled() {
     return v == 4 || (v < 0 && !exact);
 }
 
+std::atomic<int> g_split_f16{-1};     // pp_conv_split_kind: -1 = POSEPIPE_SPLIT_F16
+bool pp_conv_split_f16_default() {
+    static const int env_f16 = env_int("POSEPIPE_SPLIT_F16", 0);
+    const int g = g_split_f16.load(std::memory_order_relaxed);
+    return (g >= 0 ? g : env_f16) != 0;
+}
+
+extern "C" int pp_conv_split_kind(int f16) {
+    if (f16 < -1 || f16 > 1) {
+        pp_set_error("pp_conv_split_kind: 1 (two float16 terms, three products), 0 (three bfloat16 terms, six products) or -1 (POSEPIPE_SPLIT_F16)");
+        return PP_ERR_ARG;
+    }
+    g_split_f16.store(f16, std::memory_order_relaxed);
+    return PP_OK;
+}
+
 extern "C" int pp_conv_exact(int exact) {
     if (exact < -1 || exact > 1) {
         pp_set_error("pp_conv_exact: 1 (bit-exact fp32 MFMA kernels), 0 (bf16-split kernels where eligible) or -1 (POSEPIPE_CONV_EXACT)");
@@ -706,6 +722,7 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
     if (a.numerics == PP_NET_NUMERICS_SPLIT && a.wsplit) return pp_launch_conv_split(a, stream);
     if (a.numerics == 0 && pp_conv_split_enabled() && pp_conv_split_eligible(a)) {
         if (a.wsplit) return pp_launch_conv_split(a, stream);
+        a.split_f16 = pp_conv_split_f16_default();
         void* tmp = nullptr;                 // single-op API: split the weights for this call
         PP_HIP_CHECK(hipMalloc(&tmp, pp_conv_split_bytes(a)));
         a.wsplit = tmp;

@@ -47,6 +47,7 @@
 #endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
@@ -82,6 +83,10 @@ struct SplitArgs {
     unsigned dv_tx[2], dv_ty[2], dv_pw[2];   // MODE_TILE: tiles_x, tiles_y, patch pitch
     unsigned dv_ncol[2], dv_run0[2], dv_run1[2];   // xcd_tile_column: gy, ntiles / 8, ntiles / 8 + 1
     unsigned dv_ktaps[2], dv_kw[2];       // tap-gather product: ktaps, KW
+    // fp16 form (H kernels): per-output-channel 1 / c of the weight normalisation (behind the fragments of the split copy), the
+    // power-of-two scale of the activations and its inverse
+    const float* wscale;
+    float xs, xinv;
 #ifdef PP_SPLIT_TIMELINE
     unsigned long long* dbg;              // diagnosis builds only (tools/build_variant.sh tl -DPP_SPLIT_TIMELINE): 16 x u64 per workgroup
 #endif
@@ -170,6 +175,34 @@ __device__ __forceinline__ void split4(const float4 v, uint2& p0, uint2& p1, uin
     p2 = make_uint2(__builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, b2));
 }
 
+// ---- fp16 form (round 5): two-term operand split, THREE products per term ------------------------------------------------------
+// The six-product form's ceiling is 2500 / 6 = 417 TFLOP/s fp32-equivalent, and two rounds of tuning put the kernels at 0.46 of it
+// with the long-K layers at the chip's power limit.  float16 carries 11 significand bits: two terms carry 22,
+//     x s = h0 + 2^-11 h1,   h0 = f16(x s),  h1 = f16((x s - h0) 2^11)       (s: power-of-two scale of the tensor, exact)
+//     w c = g0 + g1,         g0 = f16(w c),  g1 = f16(w c - g0),  g2 = f16(2^-11 g0)   (c: power of two PER OUTPUT CHANNEL)
+//     (x s)(w c) ~ h0 g0 + h0 g1 + h1 g2                                      (dropped: h1 g1 2^-11 ~ 2^-22 |x w|, random sign)
+// -- three v_mfma_f32_32x32x16_f16 (same rate as bf16) into ONE float32 accumulator set; the epilogue multiplies by 1 / (s c)
+// (exact) inside the bias add's fma.  Representation error: |x s - h0 - 2^-11 h1| <= 2^-22 |x s| wherever h0 is a normal float16
+// (|x s| >= 2^-14), and <= 2^-36 absolutely below (h1 is scaled by 2^11 so that it stays normal down to there); weights are
+// normalised per channel to max |w c| in [2^14, 2^15), so |w c - g0 - g1| <= 2^-22 |w c| down to 2^-18 of the channel's largest weight
+// and <= 2^-25 (2^-40 of the largest) below -- no weight tensor can leave the format's range.  Per product that is ~2^-23.7 rms with
+// random sign against the ~2^-24 EVERY step of a float32 FMA chain commits on the running sum: over K >= 144 terms the chain's own
+// rounding dominates (tests/test_gpu_split.py holds the same yardstick as for the six-product form: error against float64 <= the
+// float32 kernel's).  Range of activations: |x s| must stay below 65504; s comes from the producer's running maximum (x_amax)
+// where the program tracks it, else 1 -- and the split saturates (clamps to +-65504) rather than produce infinities.
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+__device__ __forceinline__ void split4h(const float4 v, const float s, uint2& p0, uint2& p1) {
+    const f32x2_t lim = {65504.f, 65504.f};
+    f32x2_t a = f32x2_t{v.x, v.y} * s, b = f32x2_t{v.z, v.w} * s;
+    a = __builtin_elementwise_min(__builtin_elementwise_max(a, -lim), lim);
+    b = __builtin_elementwise_min(__builtin_elementwise_max(b, -lim), lim);
+    const f16x2_t a0 = __builtin_convertvector(a, f16x2_t), b0 = __builtin_convertvector(b, f16x2_t);
+    const f32x2_t ra = (a - __builtin_convertvector(a0, f32x2_t)) * 2048.f, rb = (b - __builtin_convertvector(b0, f32x2_t)) * 2048.f;   // exact
+    const f16x2_t a1 = __builtin_convertvector(ra, f16x2_t), b1 = __builtin_convertvector(rb, f16x2_t);
+    p0 = make_uint2(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, b0));
+    p1 = make_uint2(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1));
+}
+
 // Activations of the DeepSortYOLOv4 / YOLOX programs, as conv_igemm_p3.hip: every transcendental is evaluated in double precision
 // and rounded to float once (what oracle/yolo.py restates); applied like PP_RELU_FIRST: y = res + act(conv + bias).
 __device__ __forceinline__ float split_activate(float x, int act) {
@@ -241,9 +274,12 @@ enum { MODE_TILE = 0, MODE_STREAM = 1, MODE_GEMM = 2 };
 // (33 - 40 KB: chunk c + 1 waits in registers, as before, and is written during the last tap of chunk c, after the barrier that
 // closed tap 7 has seen every fragment read of the old patch complete) + the 4-slot ring (12 / 24 KB) = <= 73 KB, two per CU.
 // Every wave copies ceil(COB * 3 / 4) fragments per tap (duplicates where 4 does not divide: the counts must be wave-uniform).
-template <int T, int NSLOT, int COB, int PXB = 2, int NW = 4, bool RING4 = false>
+// H (round 5): the fp16 form -- TWO activation planes (h0, h1) in the patch, three weight planes (g0, g1, g2) in the same fragment
+// order and ring, three products per term instead of six; the epilogue multiplies by 1 / (s c) per output channel.
+template <int T, int NSLOT, int COB, int PXB = 2, int NW = 4, bool RING4 = false, bool H = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(SplitArgs a) {
     constexpr int NT = 64 * NW;
+    constexpr int XP = H ? 2 : 3;                     // activation planes
     constexpr bool WLDS = NW == 8 || RING4;
     static_assert(!RING4 || (NW == 4 && T == 9), "RING4 is the 4-wave 3x3 form");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -258,7 +294,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     }
     const int cb0 = (int)col * COB;
     const int plane_bytes = 2 * a.NPp * 16;           // [half][pixel] x 16 B
-    const int buf_bytes = 3 * plane_bytes;
+    const int buf_bytes = XP * plane_bytes;
 
     // tile origin (32-bit throughout: one launch addresses < 4 GiB of input, so positions and pixels stay below 2^30)
     int n = 0, x0 = 0, y0 = 0;
@@ -360,12 +396,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         for (int j = 0; j < NSLOT; ++j) {
             if (j < j0 || j >= j1) continue;
             uint2 p0, p1, p2;
-            split4(xr[j], p0, p1, p2);
+            if constexpr (H) split4h(xr[j], a.xs, p0, p1);
+            else split4(xr[j], p0, p1, p2);
             if (j == NSLOT - 1 && !last_ok) continue;
             unsigned char* d = smem + buf * buf_bytes + woff0 + (NT / 4) * 16 * j;
             *reinterpret_cast<uint2*>(d) = p0;
             *reinterpret_cast<uint2*>(d + plane_bytes) = p1;
-            *reinterpret_cast<uint2*>(d + 2 * plane_bytes) = p2;
+            if constexpr (!H) *reinterpret_cast<uint2*>(d + 2 * plane_bytes) = p2;
         }
     };
     // ---- the first requests: weights of the first steps (DMA ring) / first step (registers), patch of chunk 0 -----------------
@@ -391,7 +428,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     // weights: fragment (step, channel block cb, plane) at ((step * ncb + cb) * 3 + plane) * 64 + lane, step = chunk * T + tap
     const uint4* wlane = a.w + (size_t)cb0 * 3 * 64 + lane;
     uint4 wf[2][COB][3];
-    uint4 xf[PXB][3];
+    uint4 xf[PXB][XP];
     const uint4* wp = wlane;                           // weights of the next step to fetch (one spare step at the end of the buffer)
     auto load_w = [&](uint4 (&dst)[COB][3]) {
 #pragma unroll
@@ -463,7 +500,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     auto load_x = [&](const unsigned char* pbuf, int t, int pb) {
         const int toff = T == 9 ? ((t / 3) * a.PWp + (t % 3)) * 16 : 0;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) xf[pb][pl] = *reinterpret_cast<const uint4*>(pbuf + pl * plane_bytes + aofs[pb] + toff);
+        for (int pl = 0; pl < XP; ++pl) xf[pb][pl] = *reinterpret_cast<const uint4*>(pbuf + pl * plane_bytes + aofs[pb] + toff);
     };
 
     // ---- prologue (4 waves; the 8-wave form has its own below) -------------------------------------------------------------
@@ -479,6 +516,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     // the six products with i + j <= 2 (smallest terms first) of one pixel block against every channel block; consecutive MFMAs
     // go to different accumulators (no back-to-back dependency on the matrix pipe)
     auto mma = [&](const uint4 (&wc)[COB][3], int pb) {
+        if constexpr (H) {       // g2 h1 + g1 h0 + g0 h0
+            constexpr int WI[3] = {2, 1, 0}, XI[3] = {1, 0, 0};
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int cb = 0; cb < COB; ++cb)
+                    acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wc[cb][WI[p]]),
+                                                                         __builtin_bit_cast(f16x8, xf[pb][XI[p]]), acc[cb][pb], 0, 0, 0);
+        } else {
         constexpr int WI[6] = {2, 1, 0, 1, 0, 0}, XI[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
         for (int p = 0; p < 6; ++p)
@@ -486,6 +532,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
             for (int cb = 0; cb < COB; ++cb)
                 acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wc[cb][WI[p]]),
                                                                       __builtin_bit_cast(bf16x8, xf[pb][XI[p]]), acc[cb][pb], 0, 0, 0);
+        }
     };
 
     if constexpr (WLDS) {
@@ -697,6 +744,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     bool cok[COB][4];
     int cos[COB][4];
     float4 b4[COB][4];
+    float4 sc4[H ? COB : 1][H ? 4 : 1];                // H: 1 / (s c) of the lane's channels
 #pragma unroll
     for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
@@ -705,6 +753,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
             cok[cb][g] = co < a.Cout;
             cos[cb][g] = cok[cb][g] ? co : 0;
             b4[cb][g] = *reinterpret_cast<const float4*>(a.bias + cos[cb][g]);
+            if constexpr (H) {
+                float4 sc = *reinterpret_cast<const float4*>(a.wscale + cos[cb][g]);
+                sc.x *= a.xinv; sc.y *= a.xinv; sc.z *= a.xinv; sc.w *= a.xinv;
+                sc4[cb][g] = sc;
+            }
         }
     size_t ypix[PXB], r1pix[PXB], r2pix[PXB];
 #pragma unroll
@@ -731,7 +784,14 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
             for (int g = 0; g < 4; ++g) {
                 const f32x16 cc = acc[cb][pb];
                 const float4 b = b4[cb][g];
-                float4 v = make_float4(cc[4 * g + 0] + b.x, cc[4 * g + 1] + b.y, cc[4 * g + 2] + b.z, cc[4 * g + 3] + b.w);
+                float4 v;
+                if constexpr (H) {       // (the product with a power of two is exact: the fma rounds once, like the add)
+                    const float4 sc = sc4[cb][g];
+                    v = make_float4(__builtin_fmaf(cc[4 * g + 0], sc.x, b.x), __builtin_fmaf(cc[4 * g + 1], sc.y, b.y),
+                                    __builtin_fmaf(cc[4 * g + 2], sc.z, b.z), __builtin_fmaf(cc[4 * g + 3], sc.w, b.w));
+                } else {
+                    v = make_float4(cc[4 * g + 0] + b.x, cc[4 * g + 1] + b.y, cc[4 * g + 2] + b.z, cc[4 * g + 3] + b.w);
+                }
                 if (a.relu == PP_RELU_FIRST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 else if (a.relu >= PP_ACT_LEAKY) { v.x = split_activate(v.x, a.relu); v.y = split_activate(v.y, a.relu); v.z = split_activate(v.z, a.relu); v.w = split_activate(v.w, a.relu); }
                 if (a.res1) { v.x += rv[pb][cb][g].x; v.y += rv[pb][cb][g].y; v.z += rv[pb][cb][g].z; v.w += rv[pb][cb][g].w; }
@@ -779,9 +839,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
 // Weights: [chunk][pair][16-channel block][plane][lane] x 16 B (split_weights48_kernel), read per wave one step ahead.
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-template <int NSLOT>
+template <int NSLOT, bool H = false>
 __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
     constexpr int NT = 256, NPAIR = 5, CB = 3, SB = 4;
+    constexpr int XP = H ? 2 : 3;                     // activation planes (H: the fp16 form, see conv_split_kernel)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -794,7 +855,7 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
     }
     const int cbase = (int)col * CB;                  // first 16-channel block of this workgroup (a.ncb blocks in all)
     const int plane_bytes = 2 * a.NPp * 16;
-    const int buf_bytes = 3 * plane_bytes;
+    const int buf_bytes = XP * plane_bytes;
     int n = 0, x0 = 0, y0 = 0;
     unsigned s0 = 0;
     if (a.mode == MODE_TILE) {
@@ -844,12 +905,13 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
             uint2 p0, p1, p2;
-            split4(xr[j], p0, p1, p2);
+            if constexpr (H) split4h(xr[j], a.xs, p0, p1);
+            else split4(xr[j], p0, p1, p2);
             if (j == NSLOT - 1 && !last_ok) continue;
             unsigned char* d = smem + buf * buf_bytes + woff0 + (NT / 4) * 16 * j;
             *reinterpret_cast<uint2*>(d) = p0;
             *reinterpret_cast<uint2*>(d + plane_bytes) = p1;
-            *reinterpret_cast<uint2*>(d + 2 * plane_bytes) = p2;
+            if constexpr (!H) *reinterpret_cast<uint2*>(d + 2 * plane_bytes) = p2;
         }
     };
     // weights: fragment (step, block cb, plane) at ((step * ncb + cb) * 3 + plane) * 64 + lane, step = chunk * 5 + pair
@@ -919,12 +981,21 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
         for (int sb = 0; sb < SB; ++sb) acc[cb][sb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint4 xf[2][3];          // the B fragments of sub-block sb live in set sb & 1; the next sub-block's are read during this one's MFMAs
+    uint4 xf[2][XP];         // the B fragments of sub-block sb live in set sb & 1; the next sub-block's are read during this one's MFMAs
     auto load_x = [&](const unsigned char* pbuf, int q, int sb) {
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) xf[sb & 1][pl] = *reinterpret_cast<const uint4*>(pbuf + pl * plane_bytes + aofs[sb] + tofs[q]);
+        for (int pl = 0; pl < XP; ++pl) xf[sb & 1][pl] = *reinterpret_cast<const uint4*>(pbuf + pl * plane_bytes + aofs[sb] + tofs[q]);
     };
     auto mma = [&](const uint4 (&wc)[CB][3], int sb) {
+        if constexpr (H) {       // g2 h1 + g1 h0 + g0 h0
+            constexpr int WI[3] = {2, 1, 0}, XI[3] = {1, 0, 0};
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+                    acc[cb][sb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, wc[cb][WI[p]]),
+                                                                         __builtin_bit_cast(f16x8, xf[sb & 1][XI[p]]), acc[cb][sb], 0, 0, 0);
+        } else {
         constexpr int WI[6] = {2, 1, 0, 1, 0, 0}, XI[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
         for (int p = 0; p < 6; ++p)
@@ -932,6 +1003,7 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
             for (int cb = 0; cb < CB; ++cb)
                 acc[cb][sb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wc[cb][WI[p]]),
                                                                       __builtin_bit_cast(bf16x8, xf[sb & 1][XI[p]]), acc[cb][sb], 0, 0, 0);
+        }
     };
     // ---- prologue ---------------------------------------------------------------------------------------------------------------
     store_patch(0);              // (patch 0 and the first weights were requested above)
@@ -975,12 +1047,18 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
     bool cok[CB];
     int cos[CB];
     float4 b4[CB];
+    float4 sc4[H ? CB : 1];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
         const int co = (cbase + cb) * 16 + 4 * (lane >> 4);
         cok[cb] = co < a.Cout;
         cos[cb] = cok[cb] ? co : 0;
         b4[cb] = *reinterpret_cast<const float4*>(a.bias + cos[cb]);
+        if constexpr (H) {
+            float4 sc = *reinterpret_cast<const float4*>(a.wscale + cos[cb]);
+            sc.x *= a.xinv; sc.y *= a.xinv; sc.z *= a.xinv; sc.w *= a.xinv;
+            sc4[cb] = sc;
+        }
     }
     size_t ypix[SB], r1pix[SB], r2pix[SB];
     bool ook[SB];
@@ -1006,7 +1084,10 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
         for (int cb = 0; cb < CB; ++cb) {
             const f32x4 cc = acc[cb][sb];
             const float4 b = b4[cb];
-            float4 v = make_float4(cc[0] + b.x, cc[1] + b.y, cc[2] + b.z, cc[3] + b.w);
+            float4 v;
+            if constexpr (H) v = make_float4(__builtin_fmaf(cc[0], sc4[cb].x, b.x), __builtin_fmaf(cc[1], sc4[cb].y, b.y),
+                                             __builtin_fmaf(cc[2], sc4[cb].z, b.z), __builtin_fmaf(cc[3], sc4[cb].w, b.w));
+            else v = make_float4(cc[0] + b.x, cc[1] + b.y, cc[2] + b.z, cc[3] + b.w);
             if (a.relu == PP_RELU_FIRST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             else if (a.relu >= PP_ACT_LEAKY) { v.x = split_activate(v.x, a.relu); v.y = split_activate(v.y, a.relu); v.z = split_activate(v.z, a.relu); v.w = split_activate(v.w, a.relu); }
             if (a.res1) { v.x += rv[sb][cb].x; v.y += rv[sb][cb].y; v.z += rv[sb][cb].z; v.w += rv[sb][cb].w; }
@@ -1038,9 +1119,42 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
     PP_TL_FLUSH();
 }
 
+// fp16 form: the three weight planes of one value under its channel's normalisation c = 2^e (g0 = f16(w c), g1 = f16(w c - g0),
+// g2 = f16(2^-11 g0)); cmax = max |w| of the output channel (0: an all-zero channel, c = 1)
+__device__ __forceinline__ float channel_scale(float cmax) {
+    if (!(cmax > 0.f) || !(cmax < 3.0e38f)) return 1.f;
+    int e;
+    (void)frexpf(cmax, &e);                    // cmax = m 2^e, m in [0.5, 1)  ->  cmax 2^(15 - e) in [2^14, 2^15)
+    return ldexpf(1.f, 15 - e);
+}
+__device__ __forceinline__ void split_weight_h(float v, float c, unsigned short& q0, unsigned short& q1, unsigned short& q2) {
+    const float vs = v * c;                    // exact (power of two; |vs| < 2^15)
+    const _Float16 g0 = (_Float16)vs;
+    const float r = vs - (float)g0;            // exact
+    const _Float16 g1 = (_Float16)r;
+    const _Float16 g2 = (_Float16)((float)g0 * (1.f / 2048.f));
+    q0 = __builtin_bit_cast(unsigned short, g0);
+    q1 = __builtin_bit_cast(unsigned short, g1);
+    q2 = __builtin_bit_cast(unsigned short, g2);
+}
+// max |w| per output channel of a packed conv weight ([K / 32][CoutPad][32]); one wave per channel; also writes 1 / c
+__global__ __launch_bounds__(64) void weight_channel_max_kernel(const float* w, int kchunks, int CoutPad, int nout, float* cmax, float* inv_scale) {
+    const int cout = blockIdx.x, lane = threadIdx.x;
+    float m = 0.f;
+    if (cout < CoutPad)
+        for (int c = lane >> 5; c < kchunks; c += 2) m = fmaxf(m, fabsf(w[((size_t)c * CoutPad + cout) * 32 + (lane & 31)]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0 && cout < nout) {
+        cmax[cout] = m;
+        inv_scale[cout] = 1.f / channel_scale(m);
+    }
+}
+
 // split weights of the 48-channel form: [chunk][pair][16-channel block][plane][lane] x 16 B; lane = (k group g = lane >> 4: tap
 // 2 * pair + (g >> 1), channels 8 (g & 1) .. + 7 of the chunk; channel block row lane & 15); tap 9 (the odd half of pair 4) is zero
-__global__ __launch_bounds__(256) void split_weights48_kernel(const float* w, uint4* out, int Cin, int CoutPad, int ncb16, size_t total) {
+template <bool H>
+__global__ __launch_bounds__(256) void split_weights48_kernel(const float* w, uint4* out, int Cin, int CoutPad, int ncb16, size_t total, const float* cmax) {
     const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;       // (chunk, pair, cb, lane)
     if (i >= total) return;
     const int lane = (int)(i & 63);
@@ -1059,6 +1173,10 @@ __global__ __launch_bounds__(256) void split_weights48_kernel(const float* w, ui
         const int k = t * Cin + cin;
         float v = 0.f;
         if (t < 9 && cout < CoutPad) v = w[((size_t)(k >> 5) * CoutPad + cout) * 32 + 8 * (k & 3) + ((k & 31) >> 2)];
+        if constexpr (H) {
+            split_weight_h(v, channel_scale(cmax[cout]), h[0][j], h[1][j], h[2][j]);
+            continue;
+        }
         const __bf16 q0 = (__bf16)v;
         const float r1 = v - (float)q0;
         const __bf16 q1 = (__bf16)r1;
@@ -1089,15 +1207,16 @@ __global__ __launch_bounds__(256) void split_weights48_kernel(const float* w, ui
 // order and shared by the waves along M), two LDS stages of 16 input channels, one barrier per stage (3072 matrix-pipe cycles).
 // WM x WN = 8 waves: one workgroup per CU; 4 waves (256 x 128 tile): two workgroups per CU, for layers with few 16-channel stages,
 // where one workgroup's start-up and epilogue hide under the other's K loop.
-template <int WM, int WN>
+template <int WM, int WN, bool H = false>
 __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split_gemm_kernel(SplitArgs a) {
+    constexpr int XP = H ? 2 : 3;                    // activation planes (H: the fp16 form, see conv_split_kernel)
     constexpr int NT = 64 * WM * WN, NWAVE = WM * WN;
     constexpr int BM = 128 * WM, BN = 64 * WN;
     constexpr int XS = BM * 4 / NT;                  // float4 patch slots per thread and stage
     constexpr int WU = BN * 6;                       // 16-byte units of split weights per stage: BN / 32 blocks x 3 planes x 64 lanes
     constexpr int NPp = BM + 4;
     constexpr int XPLANE = 2 * NPp * 16;
-    constexpr int XBYTES = 3 * XPLANE, STAGE = XBYTES + WU * 16;
+    constexpr int XBYTES = XP * XPLANE, STAGE = XBYTES + WU * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1145,11 +1264,12 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
 #pragma unroll
         for (int j = 0; j < XS; ++j) {
             uint2 p0, p1, p2;
-            split4(xr[j], p0, p1, p2);
+            if constexpr (H) split4h(xr[j], a.xs, p0, p1);
+            else split4(xr[j], p0, p1, p2);
             unsigned char* d = base + woff0 + (NT / 4) * 16 * j;
             *reinterpret_cast<uint2*>(d) = p0;
             *reinterpret_cast<uint2*>(d + XPLANE) = p1;
-            *reinterpret_cast<uint2*>(d + 2 * XPLANE) = p2;
+            if constexpr (!H) *reinterpret_cast<uint2*>(d + 2 * XPLANE) = p2;
         }
     };
     // split weights of a stage: copied verbatim global -> LDS by the DMA path (global_load_lds_dwordx4: no staging registers, no
@@ -1199,18 +1319,18 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
 
     for (int c = 0; c < a.nchunks; ++c) {
         const unsigned char* sb = smem + (c & 1) * STAGE;
-        uint4 wf[2][3], xf[2][3];
+        uint4 wf[2][3], xf[2][XP];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) wf[cb][pl] = *reinterpret_cast<const uint4*>(sb + wofs + (cb * 3 + pl) * 1024);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) xf[0][pl] = *reinterpret_cast<const uint4*>(sb + xofs + pl * XPLANE);
+        for (int pl = 0; pl < XP; ++pl) xf[0][pl] = *reinterpret_cast<const uint4*>(sb + xofs + pl * XPLANE);
 #pragma unroll
         for (int pb = 0; pb < 4; ++pb) {
             if (pb < 3) {
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) xf[(pb + 1) & 1][pl] = *reinterpret_cast<const uint4*>(sb + xofs + pl * XPLANE + (pb + 1) * 512);
+                for (int pl = 0; pl < XP; ++pl) xf[(pb + 1) & 1][pl] = *reinterpret_cast<const uint4*>(sb + xofs + pl * XPLANE + (pb + 1) * 512);
             }
             __builtin_amdgcn_sched_barrier(0);
             // the next stage's pixels (loaded during the previous stage) are split and written to the other buffer in the shadow
@@ -1221,6 +1341,15 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
                 issue_w(c + 1, (c + 1) & 1);
                 if (c + 2 < a.nchunks) load_x(c + 2);
             }
+            if constexpr (H) {       // g2 h1 + g1 h0 + g0 h0
+                constexpr int WI[3] = {2, 1, 0}, XI[3] = {1, 0, 0};
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[cb][WI[p]]),
+                                                                             __builtin_bit_cast(f16x8, xf[pb & 1][XI[p]]), acc[cb][pb], 0, 0, 0);
+            } else {
             constexpr int WI[6] = {2, 1, 0, 1, 0, 0}, XI[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
             for (int p = 0; p < 6; ++p)
@@ -1228,6 +1357,7 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
                 for (int cb = 0; cb < 2; ++cb)
                     acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[cb][WI[p]]),
                                                                           __builtin_bit_cast(bf16x8, xf[pb & 1][XI[p]]), acc[cb][pb], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (c + 2 < a.nchunks)
@@ -1274,7 +1404,14 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
                     const int co = (cb0 + cb) * 32 + 8 * g + 4 * (lane >> 5);
                     const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
                     const f32x16 cc = acc[cb][pb];
-                    float4 v = make_float4(cc[4 * g + 0] + b4.x, cc[4 * g + 1] + b4.y, cc[4 * g + 2] + b4.z, cc[4 * g + 3] + b4.w);
+                    float4 v;
+                    if constexpr (H) {
+                        const float4 sc = *reinterpret_cast<const float4*>(a.wscale + co);
+                        v = make_float4(__builtin_fmaf(cc[4 * g + 0], sc.x * a.xinv, b4.x), __builtin_fmaf(cc[4 * g + 1], sc.y * a.xinv, b4.y),
+                                        __builtin_fmaf(cc[4 * g + 2], sc.z * a.xinv, b4.z), __builtin_fmaf(cc[4 * g + 3], sc.w * a.xinv, b4.w));
+                    } else {
+                        v = make_float4(cc[4 * g + 0] + b4.x, cc[4 * g + 1] + b4.y, cc[4 * g + 2] + b4.z, cc[4 * g + 3] + b4.w);
+                    }
                     if (a.relu == PP_RELU_FIRST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                     else if (a.relu >= PP_ACT_LEAKY) { v.x = split_activate(v.x, a.relu); v.y = split_activate(v.y, a.relu); v.z = split_activate(v.z, a.relu); v.w = split_activate(v.w, a.relu); }
                     *reinterpret_cast<float4*>(stg + (pb * 32 + (lane & 31)) * 128 + (((2 * g + (lane >> 5)) ^ (lane & 7)) << 4)) = v;
@@ -1336,7 +1473,14 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
                 if (co >= a.Cout) continue;
                 const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
                 const f32x16 cc = acc[cb][pb];
-                float4 v = make_float4(cc[4 * g + 0] + b4.x, cc[4 * g + 1] + b4.y, cc[4 * g + 2] + b4.z, cc[4 * g + 3] + b4.w);
+                float4 v;
+                if constexpr (H) {
+                    const float4 sc = *reinterpret_cast<const float4*>(a.wscale + co);
+                    v = make_float4(__builtin_fmaf(cc[4 * g + 0], sc.x * a.xinv, b4.x), __builtin_fmaf(cc[4 * g + 1], sc.y * a.xinv, b4.y),
+                                    __builtin_fmaf(cc[4 * g + 2], sc.z * a.xinv, b4.z), __builtin_fmaf(cc[4 * g + 3], sc.w * a.xinv, b4.w));
+                } else {
+                    v = make_float4(cc[4 * g + 0] + b4.x, cc[4 * g + 1] + b4.y, cc[4 * g + 2] + b4.z, cc[4 * g + 3] + b4.w);
+                }
                 if (a.relu == PP_RELU_FIRST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 else if (a.relu >= PP_ACT_LEAKY) { v.x = split_activate(v.x, a.relu); v.y = split_activate(v.y, a.relu); v.z = split_activate(v.z, a.relu); v.w = split_activate(v.w, a.relu); }
                 if (a.res1) {
@@ -1355,8 +1499,9 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
 }
 
 // ---- weight split: float32 blob rows ([K / 32][CoutPad][32], pack_conv order) -> fragment order, three bf16 planes ---------
+template <bool H>
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* w, uint4* out, int Cin, int taps, int CoutPad, int ncb,
-                                                            size_t total) {
+                                                            size_t total, const float* cmax) {
     const size_t i = blockIdx.x * (size_t)256 + threadIdx.x;       // (chunk, tap, cb, lane)
     if (i >= total) return;
     const int lane = (int)(i & 63);
@@ -1373,6 +1518,10 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* w, uint
         const int k = t * Cin + cin;
         float v = 0.f;
         if (cout < CoutPad) v = w[((size_t)(k >> 5) * CoutPad + cout) * 32 + 8 * (k & 3) + ((k & 31) >> 2)];
+        if constexpr (H) {
+            split_weight_h(v, channel_scale(cmax[cout]), h[0][j], h[1][j], h[2][j]);
+            continue;
+        }
         // round-to-nearest-even split (see split4): planes 1 and 2 are signed residuals
         const __bf16 q0 = (__bf16)v;
         const float r1 = v - (float)q0;                                      // exact
@@ -1514,21 +1663,39 @@ static bool split_c48(const ConvArgs& a) {
 }
 static int split_ncb16(const ConvArgs& a) { return (a.Cout + 47) / 48 * 3; }      // 16-channel blocks, whole columns of 3
 
-size_t pp_conv_split_bytes(const ConvArgs& a) {
+// bytes of the fragments (both forms: three planes) ...
+static size_t split_frag_bytes(const ConvArgs& a) {
     int taps = 1, cin = a.Cin, mode = 0;
     split_shape(a, &taps, &cin, &mode);
     if (split_c48(a)) return ((size_t)(cin / 16) * 5 + 1) * split_ncb16(a) * 3 * 64 * sizeof(uint4);
     return ((size_t)(cin / 16) * taps + 1) * split_ncb(a) * 3 * 64 * sizeof(uint4);      // + one spare step: the kernel fetches one step ahead
+}
+// ... and, fp16 form, of what follows them: 1 / c per output channel, then max |w| per output channel
+static int split_nout(const ConvArgs& a) { return split_c48(a) ? split_ncb16(a) * 16 : split_ncb(a) * 32; }
+size_t pp_conv_split_bytes(const ConvArgs& a) {
+    return split_frag_bytes(a) + (a.split_f16 ? (size_t)2 * split_nout(a) * sizeof(float) : 0);
 }
 
 int pp_conv_split_weights(const ConvArgs& a, void* out, hipStream_t stream) {
     int taps = 1, cin = a.Cin, mode = 0;
     split_shape(a, &taps, &cin, &mode);
     const int ncb = split_ncb(a);
+    float* inv_scale = nullptr;
+    float* cmax = nullptr;
+    if (a.split_f16) {
+        const int nout = split_nout(a);
+        inv_scale = reinterpret_cast<float*>(static_cast<unsigned char*>(out) + split_frag_bytes(a));
+        cmax = inv_scale + nout;
+        hipLaunchKernelGGL(weight_channel_max_kernel, dim3((unsigned)nout), dim3(64), 0, stream, a.w, a.Kpad / 32, a.CoutPad, nout, cmax, inv_scale);
+    }
     if (split_c48(a)) {
         const size_t total48 = (size_t)(cin / 16) * 5 * split_ncb16(a) * 64;
-        hipLaunchKernelGGL(split_weights48_kernel, dim3((unsigned)((total48 + 255) / 256)), dim3(256), 0, stream, a.w, (uint4*)out, cin,
-                           a.CoutPad, split_ncb16(a), total48);
+        if (a.split_f16)
+            hipLaunchKernelGGL(split_weights48_kernel<true>, dim3((unsigned)((total48 + 255) / 256)), dim3(256), 0, stream, a.w, (uint4*)out, cin,
+                               a.CoutPad, split_ncb16(a), total48, cmax);
+        else
+        hipLaunchKernelGGL(split_weights48_kernel<false>, dim3((unsigned)((total48 + 255) / 256)), dim3(256), 0, stream, a.w, (uint4*)out, cin,
+                           a.CoutPad, split_ncb16(a), total48, cmax);
         hipError_t e48 = hipGetLastError();
         if (e48 != hipSuccess) {
             pp_set_error("split_weights48 launch failed: %s", hipGetErrorString(e48));
@@ -1537,8 +1704,12 @@ int pp_conv_split_weights(const ConvArgs& a, void* out, hipStream_t stream) {
         return PP_OK;
     }
     const size_t total = (size_t)(cin / 16) * taps * ncb * 64;
-    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a.w, (uint4*)out, cin,
-                       taps, a.CoutPad, ncb, total);
+    if (a.split_f16)
+        hipLaunchKernelGGL(split_weights_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a.w, (uint4*)out, cin,
+                           taps, a.CoutPad, ncb, total, cmax);
+    else
+    hipLaunchKernelGGL(split_weights_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a.w, (uint4*)out, cin,
+                       taps, a.CoutPad, ncb, total, cmax);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         pp_set_error("split_weights launch failed: %s", hipGetErrorString(e));
@@ -1627,6 +1798,11 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     }
     s.x_bytes = a.x_bytes;
     s.xcd_remap = a.xcd_remap;
+    const bool f16 = a.split_f16 != 0;
+    const int xp = f16 ? 2 : 3;              // activation planes in LDS
+    s.wscale = f16 ? reinterpret_cast<const float*>(static_cast<const unsigned char*>(a.wsplit) + split_frag_bytes(a)) : nullptr;
+    s.xs = 1.f;
+    s.xinv = 1.f;
     PP_TL_BEGIN();
     // inputs beyond the Infinity Cache (256 MB): the columns of a tile back to back; smaller ones: column by column
     static const int colmaj_mb = env_int("POSEPIPE_SPLIT_COLMAJOR_MB", 256);
@@ -1649,12 +1825,14 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         s.epi_lds = epi_env ? atoi(epi_env) : 1;
         const int nwave = 4;
         fill_divisors(s);
-        const size_t lds = std::max<size_t>((size_t)2 * (3 * 2 * (BM + 4) * 16 + BN * 6 * 16), s.epi_lds ? (size_t)nwave * (16384 + 2048) : 0);
+        const size_t lds = std::max<size_t>((size_t)2 * (xp * 2 * (BM + 4) * 16 + BN * 6 * 16), s.epi_lds ? (size_t)nwave * (16384 + 2048) : 0);
         static std::once_flag once;
         std::call_once(once, [] {
-            (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         });
-        hipLaunchKernelGGL((conv_split_gemm_kernel<2, 2>), grid, dim3(256), lds, stream, s);
+        if (f16) hipLaunchKernelGGL((conv_split_gemm_kernel<2, 2, true>), grid, dim3(256), lds, stream, s);
+        else hipLaunchKernelGGL((conv_split_gemm_kernel<2, 2, false>), grid, dim3(256), lds, stream, s);
         PP_TL_END("g256x128", grid.x * grid.y);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
@@ -1720,14 +1898,16 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         if (s.xcd_remap) grid = dim3((unsigned)((s.gx + 7) / 8 * 8 * s.gy), 1);
         else grid = dim3(gx, (unsigned)s.gy);
         fill_divisors(s);
-        const size_t lds48 = (size_t)2 * 3 * 2 * s.NPp * 16;
+        const size_t lds48 = (size_t)2 * xp * 2 * s.NPp * 16;
 #define PP_SPLIT48_LAUNCH(NS_)                                                                                          \
     do {                                                                                                                \
         static std::once_flag once;                                                                                     \
         std::call_once(once, [] {                                                                                       \
-            (void)hipFuncSetAttribute((const void*)conv_split48_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_split48_kernel<NS_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_split48_kernel<NS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
         });                                                                                                             \
-        hipLaunchKernelGGL((conv_split48_kernel<NS_>), grid, dim3(256), lds48, stream, s);                              \
+        if (f16) hipLaunchKernelGGL((conv_split48_kernel<NS_, true>), grid, dim3(256), lds48, stream, s);               \
+        else hipLaunchKernelGGL((conv_split48_kernel<NS_, false>), grid, dim3(256), lds48, stream, s);                  \
     } while (0)
         if (nslot <= 5) PP_SPLIT48_LAUNCH(5);
         else if (nslot == 6) PP_SPLIT48_LAUNCH(6);
@@ -1743,20 +1923,25 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     }
     // 4 waves, 3x3: weights through the LDS ring with a single-buffered patch (RING4), two workgroups per CU
     static const int ring4_env = env_int("POSEPIPE_SPLIT_RING4", 1);
-    const bool ring4 = ring4_env && nw == 4 && mode != MODE_GEMM && (size_t)3 * 2 * s.NPp * 16 + (size_t)4 * cob * 3072 <= 80 * 1024;
-    const size_t lds = (size_t)(ring4 ? 1 : 2) * 3 * 2 * s.NPp * 16 + ((nw == 8 || ring4) ? (size_t)4 * cob * 3072 : 0);
+    const bool ring4 = ring4_env && nw == 4 && mode != MODE_GEMM && (size_t)xp * 2 * s.NPp * 16 + (size_t)4 * cob * 3072 <= 80 * 1024;
+    const size_t lds = (size_t)(ring4 ? 1 : 2) * xp * 2 * s.NPp * 16 + ((nw == 8 || ring4) ? (size_t)4 * cob * 3072 : 0);
     fill_divisors(s);
-#define PP_SPLIT_LAUNCH(T_, NS_, NW_, R4_)                                                                              \
+#define PP_SPLIT_LAUNCH_H(T_, NS_, NW_, R4_, H_)                                                                        \
     do {                                                                                                                \
         static std::once_flag once;                                                                                     \
         std::call_once(once, [] {     /* > 64 KB of dynamic LDS has to be allowed per kernel */                         \
-            (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 2, 2, NW_, R4_>, hipFuncAttributeMaxDynamicSharedMemorySize, (NW_ == 8 ? 160 : 100) * 1024); \
-            (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 1, 2, NW_, R4_>, hipFuncAttributeMaxDynamicSharedMemorySize, (NW_ == 8 ? 160 : 100) * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 2, 2, NW_, R4_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, (NW_ == 8 ? 160 : 100) * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 1, 2, NW_, R4_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, (NW_ == 8 ? 160 : 100) * 1024); \
         });                                                                                                             \
         if (cob == 2)                                                                                                   \
-            hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 2, 2, NW_, R4_>), grid, dim3(64 * NW_), lds, stream, s);     \
+            hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 2, 2, NW_, R4_, H_>), grid, dim3(64 * NW_), lds, stream, s); \
         else                                                                                                            \
-            hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 1, 2, NW_, R4_>), grid, dim3(64 * NW_), lds, stream, s);     \
+            hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 1, 2, NW_, R4_, H_>), grid, dim3(64 * NW_), lds, stream, s); \
+    } while (0)
+#define PP_SPLIT_LAUNCH(T_, NS_, NW_, R4_)                                                                              \
+    do {                                                                                                                \
+        if (f16) PP_SPLIT_LAUNCH_H(T_, NS_, NW_, R4_, true);                                                            \
+        else PP_SPLIT_LAUNCH_H(T_, NS_, NW_, R4_, false);                                                               \
     } while (0)
     if (mode == MODE_GEMM)
         PP_SPLIT_LAUNCH(1, 4, 4, false);

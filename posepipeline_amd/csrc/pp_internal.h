@@ -88,6 +88,9 @@ struct ConvArgs {
     // 0: single-op API -- the process-wide setting (pp_conv_exact) decides; 1 / 2: an op of a net created exact / split (ABI 7: a
     // net's numerics never change after creation; with 2 the split kernel runs exactly where the net built split weights)
     int numerics;
+    // split kernels: 0 = three bf16 planes, six products; 1 = the fp16 form (two activation planes, three products; round 5).  Fixed
+    // with the split weights (pp_conv_split_bytes / _weights / pp_launch_conv_split must see the same value)
+    int split_f16;
 };
 // fp32 convolution on the bf16 matrix cores (three-way split, six products; conv_split.hip)
 bool pp_conv_split_eligible(const ConvArgs& a);
@@ -95,6 +98,7 @@ size_t pp_conv_split_bytes(const ConvArgs& a);
 int pp_conv_split_weights(const ConvArgs& a, void* out, hipStream_t stream);
 int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream);   // `a` as prepared by pp_launch_conv, a.wsplit set
 bool pp_conv_split_enabled();       // false: POSEPIPE_CONV_EXACT=1 or an explicit exact variant
+bool pp_conv_split_f16_default();   // the process-wide default split form (pp_conv_split_kind / POSEPIPE_SPLIT_F16)
 // builds (and caches per device) the tap tables the pipelined kernel may use for this geometry; call outside graph capture
 int pp_conv_prepare(const ConvArgs& a);
 int pp_conv_out_dim(int in, int k, int stride, int pad, int dil);

@@ -353,7 +353,8 @@ class Net:
         """blob_dev: optional (device pointer, n_floats) of a weight blob that is already resident on ctx's device -- the
         tensor an RCCL broadcast delivered; prog.blob (host) is not read then.
         numerics: None / "default" (the process-wide pp_conv_exact / POSEPIPE_CONV_EXACT setting at this moment), "exact"
-        (float32 MFMA kernels, the oracle's bits) or "split" (bf16 matrix cores where eligible).  Fixed for the net's life."""
+        (float32 MFMA kernels, the oracle's bits) or "split" (bf16 / fp16 matrix cores where eligible; "split_bf16" / "split_f16" name
+        the form, "split" takes the process default, pp_conv_split_kind / POSEPIPE_SPLIT_F16).  Fixed for the net's life."""
         self.ctx = ctx
         self.prog = prog
         self.max_batch = int(max_batch)
@@ -373,6 +374,8 @@ class Net:
                                          self.max_batch, L.NUMERICS[numerics], C.byref(h)), "pp_net_create_ex")
         self.handle = h
         self.numerics = "split" if lib.pp_net_numerics(h) == L.PP_NET_NUMERICS_SPLIT else "exact"
+        # which split form the net runs ("split_bf16": three bf16 terms / six products, "split_f16": two fp16 terms / three products)
+        self.split_kind = {L.PP_NET_NUMERICS_SPLIT_BF16: "split_bf16", L.PP_NET_NUMERICS_SPLIT_F16: "split_f16"}.get(lib.pp_net_split_kind(h), "exact")
 
     def close(self):
         if getattr(self, "handle", None):
