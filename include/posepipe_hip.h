@@ -43,7 +43,8 @@ extern "C" {
                                  up2_log2 / up3_log2 (sizeof(pp_op) 104 -> 120)
                               8: pp_upload_begin_nv12 / pp_nv12_to_bgr (NV12 frame source)
                               9: PP_NET_NUMERICS_SPLIT_BF16 / _F16, pp_conv_split_kind, pp_net_split_kind: the split convolutions have a
-                                 second form -- two float16 terms per operand, three products (conv_split.hip, round 5) */
+                                 second form -- two float16 terms per operand, three products (conv_split.hip, round 5);
+                                 pp_detector_constants */
 
 typedef enum {
     PP_OK = 0,
@@ -444,6 +445,10 @@ int pp_rescale_size(int src_h, int src_w, int max_long, int max_short, int divis
                     int32_t* hp, int32_t* wp);
 int pp_resize_pad_normalize(pp_ctx* ctx, const uint8_t* frames, int n, int src_h, int src_w, int frames_mem, int nh,
                             int nw, int hp, int wp, const float* lut, float pad_val, float* out_device);
+/* The detector's test-time constants, for pinning against the vendored configs (faster_rcnn_r50_fpn.py:101-109, mot_challenge.py:33-47):
+ * out[15] = {rpn nms_pre, rpn NMS IoU, rpn max_per_img, rcnn score_thr, rcnn NMS IoU, rcnn max_per_img, img_scale long, img_scale
+ * short, Pad size_divisor, RoIAlign output_size, SingleRoIExtractor finest_scale, bbox_head target_stds[4]}.  Returns 15. */
+int pp_detector_constants(double* out, int cap);
 int pp_detector_create(pp_net* net_a, pp_net* net_b, const int32_t* bufs_a, const int32_t* bufs_b, int src_h,
                        int src_w, const float* lut, const float* base_anchors, pp_detector** out);
 void pp_detector_destroy(pp_detector* d);

@@ -3,6 +3,7 @@
 #include <memory>
 
 #include "pp_internal.h"
+#include "pp_amax.h"
 
 static thread_local std::string g_last_error;
 
@@ -222,6 +223,13 @@ struct pp_net {
     std::vector<long long> wsplit_off;   // per op: byte offset into wsplit, -1: the op runs on the fp32-MFMA kernels
     int numerics = PP_NET_NUMERICS_EXACT;   // fixed at creation (ABI 7)
     int split_f16 = 0;                      // split nets: the fp16 form (ABI 9), fixed at creation as well
+    // fp16 form (pp_amax.h): per-sample running maxima of the tensors its convolutions read, [slot][max_batch] bit patterns.  A slot
+    // belongs to ONE tensor of the program (a buffer between two overwrites); it is raised by the fused epilogues of the tensor's
+    // producers (op_y_slot) or, where a producer has none, by a stand-alone pass after the last of them (op_post_slot); tensors that
+    // come from outside the program get a pass in front of the reading op (op_pre_slot).  Slots are numbered in op order, so the
+    // slots a run of ops [first, last) has to zero are one contiguous range (slot_owner = the first op that raises the slot).
+    unsigned* amax = nullptr;
+    std::vector<int> op_x_slot, op_y_slot, op_pre_slot, op_post_slot, slot_owner;
     float* arena = nullptr;
     size_t arena_floats = 0;
     int max_batch = 0;
@@ -242,7 +250,79 @@ struct pp_net {
     std::vector<pp_deconv_bf16*> deconvs; // per op: the object of a PP_OP_DECONV_BF16, else null
 
     float* buf_ptr(int b) const { return arena + buf_off[b]; }
+    unsigned* amax_slot(int slot) const { return slot >= 0 ? amax + (size_t)slot * max_batch : nullptr; }
 };
+
+static ConvArgs net_conv_args(pp_net* net, const pp_op& op, int batch);
+
+// which tensors the fp16-form convolutions read, who produces them and who therefore tracks their maxima (see pp_net::amax)
+static void net_plan_amax(pp_net* net) {
+    const int n = (int)net->ops.size(), nb = (int)net->bufs.size();
+    net->op_x_slot.assign(n, -1);
+    net->op_y_slot.assign(n, -1);
+    net->op_pre_slot.assign(n, -1);
+    net->op_post_slot.assign(n, -1);
+    net->slot_owner.clear();
+    if (net->numerics != PP_NET_NUMERICS_SPLIT || !net->split_f16) return;
+    auto is_h = [&](int i) { return net->ops[i].type == PP_OP_CONV && net->wsplit_off[i] >= 0; };
+    // producers with a fused maximum: convolutions (pp_conv_tracks_amax) and PP_OP_UPSAMPLE_ADD
+    auto tracks = [&](int i) {
+        const pp_op& op = net->ops[i];
+        if (op.type == PP_OP_UPSAMPLE_ADD) return true;
+        return op.type == PP_OP_CONV && pp_conv_tracks_amax(net_conv_args(net, op, 1), is_h(i));
+    };
+    struct Tensor { int slot; std::vector<int> producers; bool wanted; };
+    std::vector<Tensor> tensors;
+    std::vector<int> cur(nb, -1);                 // tensor currently held by buffer b (-1: written outside the program)
+    std::vector<char> read_since(nb, 1);
+    std::vector<std::pair<int, int>> readers;     // (H conv, tensor)
+    for (int i = 0; i < n; ++i) {
+        const pp_op& op = net->ops[i];
+        if (is_h(i)) {
+            if (cur[op.in] < 0) {
+                net->op_pre_slot[i] = net->op_x_slot[i] = (int)net->slot_owner.size();
+                net->slot_owner.push_back(i);
+            } else {
+                tensors[cur[op.in]].wanted = true;
+                readers.push_back({i, cur[op.in]});
+            }
+        }
+        for (int b : {op.in, op.res1, op.res2, op.in2, op.in3})
+            if (b >= 0) read_since[b] = 1;
+        // a write after a read (or the first write) starts a new tensor; writes without a read in between fill the same one (the
+        // channel slices of a concatenation)
+        if (cur[op.out] < 0 || read_since[op.out]) {
+            cur[op.out] = (int)tensors.size();
+            tensors.push_back({(int)net->slot_owner.size(), {}, false});
+            net->slot_owner.push_back(i);         // (a slot per tensor, wanted or not: the numbering must follow the op order)
+        }
+        tensors[cur[op.out]].producers.push_back(i);
+        read_since[op.out] = 0;
+    }
+    for (const Tensor& t : tensors) {
+        if (!t.wanted) continue;
+        bool fused = true;
+        for (int p : t.producers) fused = fused && tracks(p);
+        if (fused)
+            for (int p : t.producers) net->op_y_slot[p] = t.slot;
+        else
+            net->op_post_slot[t.producers.back()] = t.slot;
+    }
+    for (const auto& r : readers) net->op_x_slot[r.first] = tensors[r.second].slot;
+}
+
+// zero the maxima that ops [first, last) raise (on `s`, ahead of them)
+static int net_reset_amax(pp_net* net, int first, int last, hipStream_t s) {
+    if (!net->amax) return PP_OK;
+    int s0 = -1, s1 = -1;
+    for (int k = 0; k < (int)net->slot_owner.size(); ++k)
+        if (net->slot_owner[k] >= first && net->slot_owner[k] < last) {
+            if (s0 < 0) s0 = k;
+            s1 = k + 1;
+        }
+    if (s0 >= 0) PP_HIP_CHECK(hipMemsetAsync(net->amax_slot(s0), 0, (size_t)(s1 - s0) * net->max_batch * sizeof(unsigned), s));
+    return PP_OK;
+}
 
 static void net_plan_lanes(pp_net* net, int n_lanes) {
     const int n = (int)net->ops.size(), nb = (int)net->bufs.size();
@@ -411,10 +491,28 @@ static ConvArgs net_conv_args(pp_net* net, const pp_op& op, int batch) {
     a.wsplit = (net->wsplit && idx < net->wsplit_off.size() && net->wsplit_off[idx] >= 0) ? net->wsplit + net->wsplit_off[idx] : nullptr;
     a.numerics = net->numerics;
     a.split_f16 = net->split_f16;
+    if (idx < net->op_x_slot.size()) {
+        a.x_amax = net->amax_slot(net->op_x_slot[idx]);
+        a.y_amax = net->amax_slot(net->op_y_slot[idx]);
+    }
     return a;
 }
 
+static int net_launch_op_body(pp_net* net, const pp_op& op, int batch, hipStream_t s);
+
 static int net_launch_op(pp_net* net, const pp_op& op, int batch, hipStream_t s) {
+    const size_t idx = &op - net->ops.data();
+    if (net->amax && net->op_pre_slot[idx] >= 0) {
+        int rc = pp_launch_amax(net->buf_ptr(op.in), batch, net->buf_elems[op.in], net->amax_slot(net->op_pre_slot[idx]), s);
+        if (rc != PP_OK) return rc;
+    }
+    int rc = net_launch_op_body(net, op, batch, s);
+    if (rc == PP_OK && net->amax && net->op_post_slot[idx] >= 0)
+        rc = pp_launch_amax(net->buf_ptr(op.out), batch, net->buf_elems[op.out], net->amax_slot(net->op_post_slot[idx]), s);
+    return rc;
+}
+
+static int net_launch_op_body(pp_net* net, const pp_op& op, int batch, hipStream_t s) {
     const pp_buf& bi = net->bufs[op.in];
     const pp_buf& bo = net->bufs[op.out];
     if (op.type == PP_OP_CONV) {
@@ -443,7 +541,8 @@ static int net_launch_op(pp_net* net, const pp_op& op, int batch, hipStream_t s)
         return pp_launch_upsample_add(net->buf_ptr(op.in), op.res1 >= 0 ? net->buf_ptr(op.res1) : nullptr,
                                       op.res2 >= 0 ? net->buf_ptr(op.res2) : nullptr, net->buf_ptr(op.out), batch, bo.h, bo.w,
                                       bo.c, op.up_log2, op.relu == PP_RELU_LAST, s, op.in2 >= 0 ? net->buf_ptr(op.in2) : nullptr,
-                                      op.up2_log2, op.in3 >= 0 ? net->buf_ptr(op.in3) : nullptr, op.up3_log2);
+                                      op.up2_log2, op.in3 >= 0 ? net->buf_ptr(op.in3) : nullptr, op.up3_log2,
+                                      net->amax && net->op_y_slot[&op - net->ops.data()] >= 0 ? net->amax_slot(net->op_y_slot[&op - net->ops.data()]) : nullptr);
     } else if (op.type == PP_OP_VIT_ENCODER) {
         pp_vit_encoder* enc = net->vits[&op - net->ops.data()];
         return pp_vit_encoder_run(enc, net->buf_ptr(op.in), net->buf_ptr(op.out), batch, s);
@@ -548,6 +647,12 @@ int pp_net_create_ex(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* buf
             net->wsplit_off[i] = (long long)bytes;
             bytes += (pp_conv_split_bytes(a) + 255) / 256 * 256;
         }
+        net_plan_amax(net.get());
+        if (!net->slot_owner.empty()) {
+            const size_t ab = net->slot_owner.size() * (size_t)max_batch * sizeof(unsigned);
+            PP_HIP_CHECK(hipMalloc((void**)&net->amax, ab));
+            PP_HIP_CHECK(hipMemsetAsync(net->amax, 0, ab, ctx->stream));
+        }
         if (bytes) {
             PP_HIP_CHECK(hipMalloc((void**)&net->wsplit, bytes));
             for (int i = 0; i < n_ops; ++i) {
@@ -611,6 +716,7 @@ void pp_net_destroy(pp_net* net) {
     for (auto* d : net->deconvs) pp_deconv_bf16_destroy(d);
     if (net->weights) (void)hipFree(net->weights);
     if (net->wsplit) (void)hipFree(net->wsplit);
+    if (net->amax) (void)hipFree(net->amax);
     if (net->arena) (void)hipFree(net->arena);
     delete net;
 }
@@ -633,6 +739,10 @@ int pp_net_run(pp_net* net, int batch, int first_op, int last_op) {
         return PP_OK;
     }
     hipStream_t main = net->ctx->stream;
+    {
+        int rc = net_reset_amax(net, first_op, last_op, main);
+        if (rc != PP_OK) return rc;
+    }
     if (net->lanes.empty() || !net->use_lanes || last_op - first_op < 8) {
         for (int i = first_op; i < last_op; ++i) {
             int rc = net_launch_op(net, net->ops[i], batch, main);
@@ -693,7 +803,7 @@ int pp_net_capture(pp_net* net, int batch) {
     PP_HIP_CHECK(hipStreamSynchronize(s));
     hipGraph_t graph = nullptr;
     PP_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    int rc = PP_OK;
+    int rc = net_reset_amax(net, 0, (int)net->ops.size(), s);
     for (size_t i = 0; i < net->ops.size() && rc == PP_OK; ++i) rc = net_launch_op(net, net->ops[i], batch, s);
     hipError_t e = hipStreamEndCapture(s, &graph);
     if (rc != PP_OK) {
@@ -731,7 +841,7 @@ int pp_net_profile(pp_net* net, int batch, float* ms_per_op) {
     const size_t n = net->ops.size();
     std::vector<hipEvent_t> ev(n + 1);
     for (auto& e : ev) PP_HIP_CHECK(hipEventCreate(&e));
-    int rc = PP_OK;
+    int rc = net_reset_amax(net, 0, (int)n, s);
     PP_HIP_CHECK(hipEventRecord(ev[0], s));
     for (size_t i = 0; i < n && rc == PP_OK; ++i) {
         rc = net_launch_op(net, net->ops[i], batch, s);

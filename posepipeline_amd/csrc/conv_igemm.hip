@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "pp_internal.h"
+#include "pp_amax.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -302,6 +303,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
             cos[ct] = cok[ct] ? co : 0;
             b4[ct] = *reinterpret_cast<const float4*>(a.bias + cos[ct]);
         }
+        float ymax[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) ymax[pt] = 0.f;
 #pragma unroll
         for (int p0 = 0; p0 < PT; p0 += PB) {
             bool mok[PB];
@@ -351,8 +355,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 for (int pb = 0; pb < PB; ++pb) {
                     float4 v = o[ct][pb];
                     if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (mok[pb] && cok[ct]) *reinterpret_cast<float4*>(a.y + moff[pb] + cos[ct]) = v;
+                    if (mok[pb] && cok[ct]) {
+                        *reinterpret_cast<float4*>(a.y + moff[pb] + cos[ct]) = v;
+                        ymax[p0 + pb] = fmaxf(ymax[p0 + pb], pp_abs4max(v));
+                    }
                 }
+        }
+        if (a.y_amax) {              // a fp16-form convolution reads this tensor: max |y| per sample of what was stored (pp_amax.h)
+            __shared__ float amax_red[16];
+            int yimg[PT];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+                yimg[pt] = (int)udiv((unsigned)min(m0 + wave * (16 * PT) + pt * 16 + lcol, a.M - 1), a.div_hw_m, a.div_hw_s1, a.div_hw_s2);
+            const unsigned wlast = (unsigned)min(m0 + 64 * PT - 1, a.M - 1);
+            pp_amax_commit_wg<4, PT>(a.y_amax, yimg, ymax, (int)udiv((unsigned)min(m0, (int)wlast), a.div_hw_m, a.div_hw_s1, a.div_hw_s2),
+                                     (int)udiv(wlast, a.div_hw_m, a.div_hw_s1, a.div_hw_s2), amax_red);
         }
         return;
     }
@@ -665,6 +682,15 @@ extern "C" int pp_conv_exact(int exact) {
     return PP_OK;
 }
 
+// (the float32 kernels' condition is the one their "common case" epilogue tests)
+bool pp_conv_tracks_amax(const ConvArgs& a, bool split) {
+    if (split) return true;
+    const int Ho2 = a.Hout << a.up_log2, Wo2 = a.Wout << a.up_log2;
+    const bool res1_plain = a.res1_shift == 0 && a.res1_off_w == 0 && a.res1_H == Ho2 && a.res1_W == Wo2;
+    return a.up_log2 == 0 && (a.Cout & 3) == 0 && !a.out_nchw && (!a.res1 || res1_plain) && a.relu <= PP_RELU_FIRST &&
+           (a.y_stride == 0 || a.y_stride == a.Cout);
+}
+
 int pp_conv_prepare(const ConvArgs& a) {
     if (a.Cin % 4 != 0 || a.K <= 0) return PP_OK;
     return tap_table_for(a, true) ? PP_OK : PP_ERR_HIP;
@@ -710,6 +736,8 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
             p.y = a.y + (size_t)n0 * y_img;
             if (a.res1) p.res1 = a.res1 + (size_t)n0 * r1_img;
             if (a.res2) p.res2 = a.res2 + (size_t)n0 * r2_img;
+            if (a.x_amax) p.x_amax = a.x_amax + n0;
+            if (a.y_amax) p.y_amax = a.y_amax + n0;
             const int rc = pp_launch_conv(p, stream);
             if (rc != PP_OK) return rc;
         }
@@ -724,13 +752,24 @@ int pp_launch_conv(const ConvArgs& a_in, hipStream_t stream) {
         if (a.wsplit) return pp_launch_conv_split(a, stream);
         a.split_f16 = pp_conv_split_f16_default();
         void* tmp = nullptr;                 // single-op API: split the weights for this call
-        PP_HIP_CHECK(hipMalloc(&tmp, pp_conv_split_bytes(a)));
+        const size_t wbytes = (pp_conv_split_bytes(a) + 255) / 256 * 256;
+        PP_HIP_CHECK(hipMalloc(&tmp, wbytes + (a.split_f16 ? (size_t)a.N * sizeof(unsigned) : 0)));
         a.wsplit = tmp;
         int rc = pp_conv_split_weights(a, tmp, stream);
+        if (rc == PP_OK && a.split_f16) {    // ... and take the per-sample maxima of the input (a net tracks them where the tensor is produced)
+            unsigned* am = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(tmp) + wbytes);
+            if (hipMemsetAsync(am, 0, (size_t)a.N * sizeof(unsigned), stream) != hipSuccess) rc = PP_ERR_HIP;
+            if (rc == PP_OK) rc = pp_launch_amax(a.x, a.N, img_bytes / sizeof(float), am, stream);
+            a.x_amax = am;
+        }
         if (rc == PP_OK) rc = pp_launch_conv_split(a, stream);
         (void)hipStreamSynchronize(stream);
         (void)hipFree(tmp);
         return rc;
+    }
+    if (a.y_amax && !pp_conv_tracks_amax(a, false)) {
+        pp_set_error("conv: this layer's epilogue does not track the output maximum (ConvArgs::y_amax; see pp_conv_tracks_amax)");
+        return PP_ERR_STATE;
     }
     static const int force_ct = env_int("POSEPIPE_CONV_CT", 0), force_pt = env_int("POSEPIPE_CONV_PT", 0),
                      min_blocks = env_int("POSEPIPE_CONV_MIN_BLOCKS", 512);

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include "pp_internal.h"
+#include "pp_amax.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
@@ -325,6 +326,9 @@ __device__ __forceinline__ void conv_p3_body(const ConvArgs& a) {
             cos[ct] = cok[ct] ? co : 0;
             b4[ct] = *reinterpret_cast<const float4*>(a.bias + cos[ct]);
         }
+        float ymax[PT];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) ymax[pt] = 0.f;
 #pragma unroll
         for (int p0 = 0; p0 < PT; p0 += PB) {
             bool mok[PB];
@@ -385,8 +389,21 @@ __device__ __forceinline__ void conv_p3_body(const ConvArgs& a) {
                 for (int pb = 0; pb < PB; ++pb) {
                     float4 v = o[ct][pb];
                     if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                    if (mok[pb] && cok[ct]) *reinterpret_cast<float4*>(a.y + moff[pb] + cos[ct]) = v;
+                    if (mok[pb] && cok[ct]) {
+                        *reinterpret_cast<float4*>(a.y + moff[pb] + cos[ct]) = v;
+                        ymax[p0 + pb] = fmaxf(ymax[p0 + pb], pp_abs4max(v));
+                    }
                 }
+        }
+        if (a.y_amax) {              // a fp16-form convolution reads this tensor: max |y| per sample of what was stored (pp_amax.h)
+            __shared__ float amax_red[16];
+            int yimg[PT];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt)
+                yimg[pt] = (int)udiv((unsigned)min(m0 + wave * (16 * PT) + pt * 16 + lcol, a.M - 1), a.div_hw_m, a.div_hw_s1, a.div_hw_s2);
+            const unsigned wlast = (unsigned)min(m0 + 64 * PT - 1, a.M - 1);
+            pp_amax_commit_wg<4, PT>(a.y_amax, yimg, ymax, (int)udiv((unsigned)min(m0, (int)wlast), a.div_hw_m, a.div_hw_s1, a.div_hw_s2),
+                                     (int)udiv(wlast, a.div_hw_m, a.div_hw_s1, a.div_hw_s2), amax_red);
         }
         return;
     }

@@ -39,6 +39,7 @@
 #include <cstdio>
 
 #include "pp_internal.h"
+#include "pp_amax.h"
 
 // timing experiments only (tools/build_variant.sh; WRONG results): 1 no weight loads, 2 no patch staging, 4 no barrier,
 // 8 no fragment reads from LDS, 16 no MFMAs in the K loop of conv_split_kernel, 32 no epilogue (one store per lane)
@@ -83,10 +84,12 @@ struct SplitArgs {
     unsigned dv_tx[2], dv_ty[2], dv_pw[2];   // MODE_TILE: tiles_x, tiles_y, patch pitch
     unsigned dv_ncol[2], dv_run0[2], dv_run1[2];   // xcd_tile_column: gy, ntiles / 8, ntiles / 8 + 1
     unsigned dv_ktaps[2], dv_kw[2];       // tap-gather product: ktaps, KW
-    // fp16 form (H kernels): per-output-channel 1 / c of the weight normalisation (behind the fragments of the split copy), the
-    // power-of-two scale of the activations and its inverse
+    // fp16 form (H kernels): per-output-channel 1 / c of the weight normalisation (behind the fragments of the split copy) and the
+    // running maximum of |x| PER SAMPLE (bit pattern of a non-negative float, pp_amax.h) that the activation scale follows
     const float* wscale;
-    float xs, xinv;
+    const unsigned* x_amax;
+    // any form: where to fold max |y| per sample of what this launch stores (null: the output feeds no fp16-form convolution)
+    unsigned* y_amax;
 #ifdef PP_SPLIT_TIMELINE
     unsigned long long* dbg;              // diagnosis builds only (tools/build_variant.sh tl -DPP_SPLIT_TIMELINE): 16 x u64 per workgroup
 #endif
@@ -188,14 +191,13 @@ __device__ __forceinline__ void split4(const float4 v, uint2& p0, uint2& p1, uin
 // and <= 2^-25 (2^-40 of the largest) below -- no weight tensor can leave the format's range.  Per product that is ~2^-23.7 rms with
 // random sign against the ~2^-24 EVERY step of a float32 FMA chain commits on the running sum: over K >= 144 terms the chain's own
 // rounding dominates (tests/test_gpu_split.py holds the same yardstick as for the six-product form: error against float64 <= the
-// float32 kernel's).  Range of activations: |x s| must stay below 65504; s comes from the producer's running maximum (x_amax)
-// where the program tracks it, else 1 -- and the split saturates (clamps to +-65504) rather than produce infinities.
+// float32 kernel's).  Range of activations: s = 2^k is chosen PER SAMPLE from the running maximum of the tensor (pp_amax.h: the kernel
+// that stores a tensor folds max |v| into amax[sample]; max |x| s lies in [2^14, 2^15)), so nothing can leave the format upwards,
+// values down to 2^-29 of the sample's maximum keep their 22 bits and smaller ones are off by <= 2^-51 of it -- whatever the
+// magnitude of the data (1e-30 .. 1e30 alike).  Non-finite inputs stay non-finite (inf s = inf in float16, NaN stays NaN).
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 __device__ __forceinline__ void split4h(const float4 v, const float s, uint2& p0, uint2& p1) {
-    const f32x2_t lim = {65504.f, 65504.f};
-    f32x2_t a = f32x2_t{v.x, v.y} * s, b = f32x2_t{v.z, v.w} * s;
-    a = __builtin_elementwise_min(__builtin_elementwise_max(a, -lim), lim);
-    b = __builtin_elementwise_min(__builtin_elementwise_max(b, -lim), lim);
+    const f32x2_t a = f32x2_t{v.x, v.y} * s, b = f32x2_t{v.z, v.w} * s;
     const f16x2_t a0 = __builtin_convertvector(a, f16x2_t), b0 = __builtin_convertvector(b, f16x2_t);
     const f32x2_t ra = (a - __builtin_convertvector(a0, f32x2_t)) * 2048.f, rb = (b - __builtin_convertvector(b0, f32x2_t)) * 2048.f;   // exact
     const f16x2_t a1 = __builtin_convertvector(ra, f16x2_t), b1 = __builtin_convertvector(rb, f16x2_t);
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     // index arithmetic (fragment addresses, output coordinates), whose cost then hides behind their latency
     unsigned goff[NSLOT];
     unsigned vmask[T == 1 ? NSLOT : 1];               // GEMM with taps: bit t = tap t of this slot's pixel lies inside the image
+    int simg[H ? NSLOT : 1];                          // fp16 form: the sample slot j belongs to (its activation scale)
     // LDS byte offset (plane 0) of slot j: woff0 + (NT / 4) * 16 j (NT / 4 pixels further, same quad)
     const int woff0 = ((((tid & 3) >> 1) * a.NPp + (tid >> 2)) * 16 + (tid & 1) * 8);
     if (a.mode == MODE_STREAM) {
@@ -330,6 +333,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
 #pragma unroll
             for (int j = 0; j < NSLOT; ++j) vmask[j] = 0;
         }
+        if constexpr (H) {       // halo positions carry zeros: whichever neighbouring sample they are counted to
+#pragma unroll
+            for (int j = 0; j < NSLOT; ++j) {
+                const int pj = pos0 + (NT / 4) * j;
+                simg[j] = (int)pp_udiv((unsigned)min(max(pj, 0), (int)a.S - 1), a.dv_per);
+            }
+        }
     } else {
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
@@ -337,6 +347,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         const int p = u >> 2, quad = u & 3;
         const bool in_patch = p < a.NP;
         unsigned off = 0xffffffffu;
+        if constexpr (H) simg[j] = n;
         if (a.mode == MODE_TILE) {
             const int pr = (int)pp_udiv((unsigned)p, a.dv_pw), pc = p - pr * a.PWp;
             const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
@@ -348,6 +359,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
             if (in_patch && m < (unsigned)a.S) {
                 const int img = (int)pp_udiv(m, a.dv_per), rem = (int)(m - (unsigned)img * (unsigned)(a.H * a.W));
                 const int ho = (int)pp_udiv((unsigned)rem, a.dv_row), wo = rem - ho * a.W;
+                if constexpr (H) simg[j] = img;
                 if (T == 1 && a.ktaps > 1) {
                     // origin of the pixel's window (may lie before the image: the offset wraps, a valid tap's sum is exact again)
                     const int iy0 = ho * a.stride - a.pad, ix0 = wo * a.stride - a.pad;
@@ -391,12 +403,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     // split + write slots [j0, j1) of the staged chunk; branch-free (it sits between MFMAs) except for the last slot, the only
     // one that can be partly outside the patch (NSLOT = ceil(NP / (NT / 4)))
     const bool last_ok = (tid >> 2) + (NT / 4) * (NSLOT - 1) < a.NP;
+    float sx[H ? NSLOT : 1];                          // fp16 form: activation scale of slot j's sample (set behind the first requests)
     auto store_patch = [&](int buf, int j0, int j1) {
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
             if (j < j0 || j >= j1) continue;
             uint2 p0, p1, p2;
-            if constexpr (H) split4h(xr[j], a.xs, p0, p1);
+            if constexpr (H) split4h(xr[j], sx[j], p0, p1);
             else split4(xr[j], p0, p1, p2);
             if (j == NSLOT - 1 && !last_ok) continue;
             unsigned char* d = smem + buf * buf_bytes + woff0 + (NT / 4) * 16 * j;
@@ -446,6 +459,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         load_patch(0);
         load_w(wf[0]);
     }
+    // fp16 form: the maxima of the slots' samples are REQUESTED here, with the first loads, and turned into scales behind the index
+    // arithmetic below (consuming them here would put a full wait in front of it)
+    unsigned xam[H ? NSLOT : 1];
+    if constexpr (H) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) xam[j] = a.x_amax[simg[j]];
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- operand addresses and output pixels (behind the first loads) ------------------------------------------------------------
@@ -489,6 +509,11 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         }
     }
 
+    unsigned oam[H ? PXB : 1];                         // fp16 form: maximum of the output pixel's sample (the epilogue's 1 / s)
+    if constexpr (H) {
+#pragma unroll
+        for (int pb = 0; pb < PXB; ++pb) oam[pb] = a.x_amax[on[pb]];
+    }
     f32x16 acc[COB][PXB];
 #pragma unroll
     for (int cb = 0; cb < COB; ++cb)
@@ -496,6 +521,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         for (int pb = 0; pb < PXB; ++pb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
+    if constexpr (H) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) sx[j] = pp_act_scale(xam[j]);
+    }
 
     auto load_x = [&](const unsigned char* pbuf, int t, int pb) {
         const int toff = T == 9 ? ((t / 3) * a.PWp + (t % 3)) * 16 : 0;
@@ -753,15 +782,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
             cok[cb][g] = co < a.Cout;
             cos[cb][g] = cok[cb][g] ? co : 0;
             b4[cb][g] = *reinterpret_cast<const float4*>(a.bias + cos[cb][g]);
-            if constexpr (H) {
-                float4 sc = *reinterpret_cast<const float4*>(a.wscale + cos[cb][g]);
-                sc.x *= a.xinv; sc.y *= a.xinv; sc.z *= a.xinv; sc.w *= a.xinv;
-                sc4[cb][g] = sc;
-            }
+            if constexpr (H) sc4[cb][g] = *reinterpret_cast<const float4*>(a.wscale + cos[cb][g]);
         }
     size_t ypix[PXB], r1pix[PXB], r2pix[PXB];
+    float xinv[H ? PXB : 1];                           // H: 1 / s of the pixel's sample
 #pragma unroll
     for (int pb = 0; pb < PXB; ++pb) {
+        if constexpr (H) xinv[pb] = pp_act_unscale(oam[pb]);
         const int n_ = ook[pb] ? on[pb] : 0, y_ = ook[pb] ? oy[pb] : 0, x_ = ook[pb] ? ox[pb] : 0;
         ypix[pb] = ((size_t)n_ * (a.H + a.y_pad) + y_) * (a.W + a.y_pad) + x_;
         r1pix[pb] = ((size_t)n_ * (a.r1_H + a.r1_pad) + (y_ >> a.r1_shift)) * (a.r1_W + a.r1_pad) + (x_ >> a.r1_shift);
@@ -785,8 +812,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
                 const f32x16 cc = acc[cb][pb];
                 const float4 b = b4[cb][g];
                 float4 v;
-                if constexpr (H) {       // (the product with a power of two is exact: the fma rounds once, like the add)
-                    const float4 sc = sc4[cb][g];
+                if constexpr (H) {       // (the products with powers of two are exact: the fma rounds once, like the add)
+                    const float xi = xinv[pb];
+                    const float4 sc = make_float4(sc4[cb][g].x * xi, sc4[cb][g].y * xi, sc4[cb][g].z * xi, sc4[cb][g].w * xi);
                     v = make_float4(__builtin_fmaf(cc[4 * g + 0], sc.x, b.x), __builtin_fmaf(cc[4 * g + 1], sc.y, b.y),
                                     __builtin_fmaf(cc[4 * g + 2], sc.z, b.z), __builtin_fmaf(cc[4 * g + 3], sc.w, b.w));
                 } else {
@@ -809,16 +837,31 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
                     rv[pb][cb][g].x += r.x; rv[pb][cb][g].y += r.y; rv[pb][cb][g].z += r.z; rv[pb][cb][g].w += r.w;
                 }
     }
+    float ymax[PXB];
 #pragma unroll
-    for (int pb = 0; pb < PXB; ++pb)
+    for (int pb = 0; pb < PXB; ++pb) {
+        ymax[pb] = 0.f;
 #pragma unroll
         for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 v = rv[pb][cb][g];
                 if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-                if (ook[pb] && cok[cb][g]) *reinterpret_cast<float4*>(a.y + ypix[pb] * a.Cout + cos[cb][g]) = v;
+                if (ook[pb] && cok[cb][g]) {
+                    *reinterpret_cast<float4*>(a.y + ypix[pb] * a.Cout + cos[cb][g]) = v;
+                    ymax[pb] = fmaxf(ymax[pb], pp_abs4max(v));
+                }
             }
+    }
+    if (a.y_amax) {          // the consumer is a fp16-form convolution: max |y| per sample of what was stored (pp_amax.h)
+        int wg_first = n, wg_last = n;                 // samples of the workgroup's pixels
+        if (a.mode != MODE_TILE) {
+            const unsigned last = (unsigned)min((long long)s0 + 32 * PXB * NW - 1, a.S - 1);
+            wg_first = (int)pp_udiv(min(s0, last), a.dv_per);
+            wg_last = (int)pp_udiv(last, a.dv_per);
+        }
+        pp_amax_commit_wg<NW, PXB>(a.y_amax, on, ymax, wg_first, wg_last, reinterpret_cast<float*>(smem));
+    }
     PP_TL_MARK(3);
 #ifdef PP_SPLIT_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -870,6 +913,7 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
     }
     // ---- patch loader (as conv_split_kernel: the first loads are requested before the rest of the index arithmetic) -------------
     unsigned goff[NSLOT];
+    int simg[H ? NSLOT : 1];                          // fp16 form: the sample slot j belongs to (its activation scale)
     const int woff0 = ((((tid & 3) >> 1) * a.NPp + (tid >> 2)) * 16 + (tid & 1) * 8);
     if (a.mode == MODE_STREAM) {
         const int pos0 = (int)s0 - a.PWp - 1 + (tid >> 2);
@@ -877,6 +921,13 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
         const unsigned base = (unsigned)pos0 * cin4 + (unsigned)(tid & 3) * 16u;
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) goff[j] = pos0 + (NT / 4) * j < 0 ? 0xffffffffu : base + (unsigned)((NT / 4) * j) * cin4;
+        if constexpr (H) {
+#pragma unroll
+            for (int j = 0; j < NSLOT; ++j) {
+                const int pj = pos0 + (NT / 4) * j;
+                simg[j] = (int)pp_udiv((unsigned)min(max(pj, 0), (int)a.S - 1), a.dv_per);
+            }
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
@@ -884,6 +935,7 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
             const int p = u >> 2, quad = u & 3;
             const bool in_patch = p < a.NP;
             unsigned off = 0xffffffffu;
+            if constexpr (H) simg[j] = n;
             const int pr = (int)pp_udiv((unsigned)p, a.dv_pw), pc = p - pr * a.PWp;
             const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
             if (in_patch && pc < a.TW + 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
@@ -901,11 +953,12 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
         }
     };
     const bool last_ok = (tid >> 2) + (NT / 4) * (NSLOT - 1) < a.NP;
+    float sx[H ? NSLOT : 1];                          // fp16 form: activation scale of slot j's sample
     auto store_patch = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
             uint2 p0, p1, p2;
-            if constexpr (H) split4h(xr[j], a.xs, p0, p1);
+            if constexpr (H) split4h(xr[j], sx[j], p0, p1);
             else split4(xr[j], p0, p1, p2);
             if (j == NSLOT - 1 && !last_ok) continue;
             unsigned char* d = smem + buf * buf_bytes + woff0 + (NT / 4) * 16 * j;
@@ -929,6 +982,11 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
     PP_TL_MARK(4);
     load_patch(0);
     load_w(wf[0]);
+    unsigned xam[H ? NSLOT : 1];                      // (requested with the first loads, consumed behind the index arithmetic)
+    if constexpr (H) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) xam[j] = a.x_amax[simg[j]];
+    }
     __builtin_amdgcn_sched_barrier(0);
     // ---- operand addresses and output pixels: sub-block sb = 2 * (32-pixel block of the wave) + half ------------------------------
     // (the output coordinates are recomputed in the epilogue: 16 registers less across the K loop)
@@ -962,11 +1020,13 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
         }
     };
     int aofs[SB];            // LDS byte offset of this lane's pixel (tap (0,0), plane 0, its k half)
+    unsigned oam[H ? SB : 1];                          // fp16 form: maximum of the output pixel's sample (the epilogue's 1 / s)
 #pragma unroll
     for (int sb = 0; sb < SB; ++sb) {
         int t0, t1, t2;
         bool t3;
         sub_block(sb, aofs[sb], t0, t1, t2, t3);
+        if constexpr (H) oam[sb] = a.x_amax[t0];
     }
     // tap offset of this lane per pair: lanes 0 - 31 read tap 2 * pair, lanes 32 - 63 tap 2 * pair + 1 (pair 4: tap 8 twice, the
     // second against zero weights)
@@ -1006,6 +1066,10 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
         }
     };
     // ---- prologue ---------------------------------------------------------------------------------------------------------------
+    if constexpr (H) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) sx[j] = pp_act_scale(xam[j]);
+    }
     store_patch(0);              // (patch 0 and the first weights were requested above)
     PP_TL_MARK(5);
     if (a.nchunks > 1) load_patch(1);
@@ -1054,18 +1118,18 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
         cok[cb] = co < a.Cout;
         cos[cb] = cok[cb] ? co : 0;
         b4[cb] = *reinterpret_cast<const float4*>(a.bias + cos[cb]);
-        if constexpr (H) {
-            float4 sc = *reinterpret_cast<const float4*>(a.wscale + cos[cb]);
-            sc.x *= a.xinv; sc.y *= a.xinv; sc.z *= a.xinv; sc.w *= a.xinv;
-            sc4[cb] = sc;
-        }
+        if constexpr (H) sc4[cb] = *reinterpret_cast<const float4*>(a.wscale + cos[cb]);
     }
     size_t ypix[SB], r1pix[SB], r2pix[SB];
     bool ook[SB];
+    int onn[SB];
+    float xinv[H ? SB : 1];                            // H: 1 / s of the pixel's sample
 #pragma unroll
     for (int sb = 0; sb < SB; ++sb) {
         int aof_, on_, oy_, ox_;
         sub_block(sb, aof_, on_, oy_, ox_, ook[sb]);
+        onn[sb] = on_;
+        if constexpr (H) xinv[sb] = pp_act_unscale(oam[sb]);
         const int n_ = ook[sb] ? on_ : 0, y_ = ook[sb] ? oy_ : 0, x_ = ook[sb] ? ox_ : 0;
         ypix[sb] = ((size_t)n_ * (a.H + a.y_pad) + y_) * (a.W + a.y_pad) + x_;
         r1pix[sb] = ((size_t)n_ * (a.r1_H + a.r1_pad) + (y_ >> a.r1_shift)) * (a.r1_W + a.r1_pad) + (x_ >> a.r1_shift);
@@ -1085,8 +1149,8 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
             const f32x4 cc = acc[cb][sb];
             const float4 b = b4[cb];
             float4 v;
-            if constexpr (H) v = make_float4(__builtin_fmaf(cc[0], sc4[cb].x, b.x), __builtin_fmaf(cc[1], sc4[cb].y, b.y),
-                                             __builtin_fmaf(cc[2], sc4[cb].z, b.z), __builtin_fmaf(cc[3], sc4[cb].w, b.w));
+            if constexpr (H) v = make_float4(__builtin_fmaf(cc[0], sc4[cb].x * xinv[sb], b.x), __builtin_fmaf(cc[1], sc4[cb].y * xinv[sb], b.y),
+                                             __builtin_fmaf(cc[2], sc4[cb].z * xinv[sb], b.z), __builtin_fmaf(cc[3], sc4[cb].w * xinv[sb], b.w));
             else v = make_float4(cc[0] + b.x, cc[1] + b.y, cc[2] + b.z, cc[3] + b.w);
             if (a.relu == PP_RELU_FIRST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
             else if (a.relu >= PP_ACT_LEAKY) { v.x = split_activate(v.x, a.relu); v.y = split_activate(v.y, a.relu); v.z = split_activate(v.z, a.relu); v.w = split_activate(v.w, a.relu); }
@@ -1103,14 +1167,29 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
                 rv[sb][cb].x += r.x; rv[sb][cb].y += r.y; rv[sb][cb].z += r.z; rv[sb][cb].w += r.w;
             }
     }
+    float ymax[SB];
 #pragma unroll
-    for (int sb = 0; sb < SB; ++sb)
+    for (int sb = 0; sb < SB; ++sb) {
+        ymax[sb] = 0.f;
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             float4 v = rv[sb][cb];
             if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            if (ook[sb] && cok[cb]) *reinterpret_cast<float4*>(a.y + ypix[sb] * a.Cout + cos[cb]) = v;
+            if (ook[sb] && cok[cb]) {
+                *reinterpret_cast<float4*>(a.y + ypix[sb] * a.Cout + cos[cb]) = v;
+                ymax[sb] = fmaxf(ymax[sb], pp_abs4max(v));
+            }
         }
+    }
+    if (a.y_amax) {          // max |y| per sample of what was stored (pp_amax.h)
+        int wg_first = n, wg_last = n;
+        if (a.mode != MODE_TILE) {
+            const unsigned last = (unsigned)min((long long)s0 + 255, a.S - 1);
+            wg_first = (int)pp_udiv(min(s0, last), a.dv_per);
+            wg_last = (int)pp_udiv(last, a.dv_per);
+        }
+        pp_amax_commit_wg<4, SB>(a.y_amax, onn, ymax, wg_first, wg_last, reinterpret_cast<float*>(smem));
+    }
     PP_TL_MARK(3);
 #ifdef PP_SPLIT_TIMELINE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1236,13 +1315,16 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
 
     // ---- loaders -------------------------------------------------------------------------------------------------------------
     unsigned goff[XS];
+    int simg[H ? XS : 1];                            // fp16 form: the sample slot j belongs to (its activation scale)
 #pragma unroll
     for (int j = 0; j < XS; ++j) {
         const int u = tid + NT * j;
         const long long m = m0 + (u >> 2);
         unsigned off = 0xffffffffu;
+        if constexpr (H) simg[j] = 0;
         if (m < a.S) {
             const int img = (int)pp_udiv((unsigned)m, a.dv_per), rem = (int)((unsigned)m - (unsigned)img * (unsigned)(a.H * a.W));
+            if constexpr (H) simg[j] = img;
             const int ho = (int)pp_udiv((unsigned)rem, a.dv_row), wo = rem - ho * a.W;
             off = (unsigned)(((img * a.xp_h + ho * a.stride) * a.xp_w + wo * a.stride) * a.Cin) * 4u + (unsigned)(u & 3) * 16u;
         }
@@ -1259,12 +1341,13 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
             xr[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
         }
     };
+    float sx[H ? XS : 1];                            // fp16 form: activation scale of slot j's sample
     auto store_x = [&](int buf) {
         unsigned char* base = smem + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < XS; ++j) {
             uint2 p0, p1, p2;
-            if constexpr (H) split4h(xr[j], a.xs, p0, p1);
+            if constexpr (H) split4h(xr[j], sx[j], p0, p1);
             else split4(xr[j], p0, p1, p2);
             unsigned char* d = base + woff0 + (NT / 4) * 16 * j;
             *reinterpret_cast<uint2*>(d) = p0;
@@ -1309,6 +1392,15 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
     PP_TL_MARK(4);
     issue_w(0, 0);
     load_x(0);
+    // sample of the wave's first / last pixel (clamped to the tensor): equal = the wave's 128 pixels lie in one sample
+    const unsigned mfirst = (unsigned)min(m0 + wm * 128, a.S - 1), mlast = (unsigned)min(m0 + wm * 128 + 127, a.S - 1);
+    const int img_first = __builtin_amdgcn_readfirstlane((int)pp_udiv(mfirst, a.dv_per)), img_last = __builtin_amdgcn_readfirstlane((int)pp_udiv(mlast, a.dv_per));
+    unsigned oam_first = 0;                          // fp16 form: maximum of that sample (the epilogue's 1 / s), requested here
+    if constexpr (H) {
+        oam_first = a.x_amax[img_first];
+#pragma unroll
+        for (int j = 0; j < XS; ++j) sx[j] = pp_act_scale(a.x_amax[simg[j]]);
+    }
     store_x(0);
     PP_TL_MARK(5);
     if (a.nchunks > 1) load_x(1);
@@ -1390,11 +1482,24 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
                 t.x = (unsigned)(((size_t)img * (a.H + a.y_pad) + oy) * (a.W + a.y_pad) + ox);
                 t.y = (unsigned)(((size_t)img * (a.r1_H + a.r1_pad) + (oy >> a.r1_shift)) * (a.r1_W + a.r1_pad) + (ox >> a.r1_shift));
                 t.z = (unsigned)(((size_t)img * (a.H + a.r2_pad) + oy) * (a.W + a.r2_pad) + ox);
-                t.w = 1u;
+                t.w = (unsigned)img + 1u;            // 0: no such pixel
             }
             tab[p] = t;
         }
         const int rdrow = lane >> 3, rdpos = lane & 7, rdchunk = rdpos ^ rdrow;
+        float xinv[H ? 4 : 1];                       // H: 1 / s of the sample of pixel pb * 32 + (lane & 31)
+        if constexpr (H) {
+#pragma unroll
+            for (int pb = 0; pb < 4; ++pb) xinv[pb] = pp_act_unscale(oam_first);
+            if (img_first != img_last) {
+#pragma unroll
+                for (int pb = 0; pb < 4; ++pb) {
+                    const unsigned mp = (unsigned)min(m0 + wm * 128 + pb * 32 + (lane & 31), a.S - 1);
+                    xinv[pb] = pp_act_unscale(a.x_amax[pp_udiv(mp, a.dv_per)]);
+                }
+            }
+        }
+        float ymax = 0.f, ymax1 = 0.f;               // max |y| of the lane's pixels in img_first / (two samples in the wave) in img_last
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
 #pragma unroll
@@ -1407,8 +1512,9 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
                     float4 v;
                     if constexpr (H) {
                         const float4 sc = *reinterpret_cast<const float4*>(a.wscale + co);
-                        v = make_float4(__builtin_fmaf(cc[4 * g + 0], sc.x * a.xinv, b4.x), __builtin_fmaf(cc[4 * g + 1], sc.y * a.xinv, b4.y),
-                                        __builtin_fmaf(cc[4 * g + 2], sc.z * a.xinv, b4.z), __builtin_fmaf(cc[4 * g + 3], sc.w * a.xinv, b4.w));
+                        const float xi = xinv[pb];
+                        v = make_float4(__builtin_fmaf(cc[4 * g + 0], sc.x * xi, b4.x), __builtin_fmaf(cc[4 * g + 1], sc.y * xi, b4.y),
+                                        __builtin_fmaf(cc[4 * g + 2], sc.z * xi, b4.z), __builtin_fmaf(cc[4 * g + 3], sc.w * xi, b4.w));
                     } else {
                         v = make_float4(cc[4 * g + 0] + b4.x, cc[4 * g + 1] + b4.y, cc[4 * g + 2] + b4.z, cc[4 * g + 3] + b4.w);
                     }
@@ -1443,8 +1549,28 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
                 float4 v = vv[it];
                 if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 const uint2 t = *reinterpret_cast<const uint2*>(tabw + (it * 8 + rdrow) * 4);     // .x: output pixel; then (.w via the next read)
-                if (tabw[(it * 8 + rdrow) * 4 + 3]) *reinterpret_cast<float4*>(a.y + (size_t)t.x * a.Cout + co) = v;
+                const unsigned tw = tabw[(it * 8 + rdrow) * 4 + 3];
+                if (tw) *reinterpret_cast<float4*>(a.y + (size_t)t.x * a.Cout + co) = v;
+                if (a.y_amax) {
+                    const float m = tw ? pp_abs4max(v) : 0.f;
+                    if (img_last - img_first <= 1) {
+                        if ((int)tw - 1 == img_first) ymax = fmaxf(ymax, m);
+                        else ymax1 = fmaxf(ymax1, m);
+                    } else {             // several samples in the wave's pixels (the RoI head: one per pixel): per pixel, its 8 lanes reduced
+                        float m8 = fmaxf(m, __shfl_xor(m, 1));
+                        m8 = fmaxf(m8, __shfl_xor(m8, 2));
+                        m8 = fmaxf(m8, __shfl_xor(m8, 4));
+                        if (rdpos == 0 && m8 > 0.f) atomicMax(a.y_amax + (tw - 1u), __float_as_uint(m8));
+                    }
+                }
             }
+        }
+        if (a.y_amax) {      // (a wave with more than two samples has issued its atomics above and passes zeros)
+            const unsigned wlast = (unsigned)min(m0 + BM - 1, a.S - 1);
+            const int im[2] = {img_first, img_last};
+            const float ym[2] = {ymax, ymax1};
+            pp_amax_commit_wg<NWAVE, 2>(a.y_amax, im, ym, (int)pp_udiv((unsigned)min(m0, (long long)wlast), a.dv_per), (int)pp_udiv(wlast, a.dv_per),
+                                        reinterpret_cast<float*>(smem));
         }
         PP_TL_MARK(3);
 #ifdef PP_SPLIT_TIMELINE
@@ -1456,11 +1582,17 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
     }
 
     // ---- epilogue (as conv_split_kernel) -----------------------------------------------------------------------------------------
+    int rimg[4];
+    float rmax[4];
 #pragma unroll
     for (int pb = 0; pb < 4; ++pb) {
-        const long long m = m0 + wm * 128 + pb * 32 + (lane & 31);
-        if (m >= a.S) continue;
+        const long long mt = m0 + wm * 128 + pb * 32 + (lane & 31);
+        const bool pok = mt < a.S;
+        const long long m = pok ? mt : a.S - 1;
         const int img = (int)pp_udiv((unsigned)m, a.dv_per), rem = (int)((unsigned)m - (unsigned)img * (unsigned)(a.H * a.W));
+        float xi = 1.f, ymax = 0.f;
+        if constexpr (H) xi = pp_act_unscale(a.x_amax[img]);
+        rimg[pb] = img;
         const int oy = (int)pp_udiv((unsigned)rem, a.dv_row), ox = rem - oy * a.W;
         const size_t ypix = ((size_t)img * (a.H + a.y_pad) + oy) * (a.W + a.y_pad) + ox;
         const size_t r1pix = ((size_t)img * (a.r1_H + a.r1_pad) + (oy >> a.r1_shift)) * (a.r1_W + a.r1_pad) + (ox >> a.r1_shift);
@@ -1470,14 +1602,14 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int co = (cb0 + cb) * 32 + 8 * g + 4 * (lane >> 5);
-                if (co >= a.Cout) continue;
+                if (co >= a.Cout || !pok) continue;
                 const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co);
                 const f32x16 cc = acc[cb][pb];
                 float4 v;
                 if constexpr (H) {
                     const float4 sc = *reinterpret_cast<const float4*>(a.wscale + co);
-                    v = make_float4(__builtin_fmaf(cc[4 * g + 0], sc.x * a.xinv, b4.x), __builtin_fmaf(cc[4 * g + 1], sc.y * a.xinv, b4.y),
-                                    __builtin_fmaf(cc[4 * g + 2], sc.z * a.xinv, b4.z), __builtin_fmaf(cc[4 * g + 3], sc.w * a.xinv, b4.w));
+                    v = make_float4(__builtin_fmaf(cc[4 * g + 0], sc.x * xi, b4.x), __builtin_fmaf(cc[4 * g + 1], sc.y * xi, b4.y),
+                                    __builtin_fmaf(cc[4 * g + 2], sc.z * xi, b4.z), __builtin_fmaf(cc[4 * g + 3], sc.w * xi, b4.w));
                 } else {
                     v = make_float4(cc[4 * g + 0] + b4.x, cc[4 * g + 1] + b4.y, cc[4 * g + 2] + b4.z, cc[4 * g + 3] + b4.w);
                 }
@@ -1493,8 +1625,15 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
                 }
                 if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 *reinterpret_cast<float4*>(a.y + ypix * a.Cout + co) = v;
+                ymax = fmaxf(ymax, pp_abs4max(v));
             }
         }
+        rmax[pb] = ymax;
+    }
+    if (a.y_amax) {
+        const unsigned wlast = (unsigned)min(m0 + BM - 1, a.S - 1);
+        pp_amax_commit_wg<NWAVE, 4>(a.y_amax, rimg, rmax, (int)pp_udiv((unsigned)min(m0, (long long)wlast), a.dv_per), (int)pp_udiv(wlast, a.dv_per),
+                                    reinterpret_cast<float*>(smem));
     }
 }
 
@@ -1664,9 +1803,9 @@ static bool split_c48(const ConvArgs& a) {
 static int split_ncb16(const ConvArgs& a) { return (a.Cout + 47) / 48 * 3; }      // 16-channel blocks, whole columns of 3
 
 // bytes of the fragments (both forms: three planes) ...
-static size_t split_frag_bytes(const ConvArgs& a) {
+static size_t split_frag_bytes(const ConvArgs& a, bool committed = false) {
     int taps = 1, cin = a.Cin, mode = 0;
-    split_shape(a, &taps, &cin, &mode);
+    split_shape(a, &taps, &cin, &mode, committed);      // (committed: at launch the form is the one the split copy was built for)
     if (split_c48(a)) return ((size_t)(cin / 16) * 5 + 1) * split_ncb16(a) * 3 * 64 * sizeof(uint4);
     return ((size_t)(cin / 16) * taps + 1) * split_ncb(a) * 3 * 64 * sizeof(uint4);      // + one spare step: the kernel fetches one step ahead
 }
@@ -1713,6 +1852,36 @@ int pp_conv_split_weights(const ConvArgs& a, void* out, hipStream_t stream) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         pp_set_error("split_weights launch failed: %s", hipGetErrorString(e));
+        return PP_ERR_HIP;
+    }
+    return PP_OK;
+}
+
+// ---- stand-alone running maximum (pp_amax.h): tensors whose producer has no fused epilogue (program inputs, pools, ...) -----------
+__global__ __launch_bounds__(256) void amax_kernel(const float4* x, size_t quads, unsigned per, unsigned* amax) {
+    const unsigned n = blockIdx.x / per, part = blockIdx.x - n * per;      // 1-D grid: the RoI head has 64 000 samples
+    const float4* xs = x + (size_t)n * quads;
+    float m = 0.f;
+    for (size_t i = (size_t)part * 256 + threadIdx.x; i < quads; i += (size_t)per * 256) m = fmaxf(m, pp_abs4max(xs[i]));
+    __shared__ float red[16];
+    const int im[1] = {(int)n};
+    const float mm[1] = {m};
+    pp_amax_commit_wg<4, 1>(amax, im, mm, (int)n, (int)n, red);
+}
+
+int pp_launch_amax(const float* x, int n, size_t elems, unsigned* amax, hipStream_t stream) {
+    if (n <= 0 || elems == 0) return PP_OK;
+    if (elems % 4 != 0) {
+        pp_set_error("amax: %zu floats per sample (a multiple of 4 is required)", elems);
+        return PP_ERR_ARG;
+    }
+    const size_t quads = elems / 4;
+    // ~16 KB per workgroup pass; enough workgroups to fill the chip even for a single large sample
+    const unsigned per = (unsigned)std::min<size_t>(std::max<size_t>((quads + 1023) / 1024, 1), std::max<size_t>(2048 / (size_t)n, 1));
+    hipLaunchKernelGGL(amax_kernel, dim3(per * (unsigned)n), dim3(256), 0, stream, (const float4*)x, quads, per, amax);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        pp_set_error("amax launch failed: %s", hipGetErrorString(e));
         return PP_ERR_HIP;
     }
     return PP_OK;
@@ -1800,9 +1969,13 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     s.xcd_remap = a.xcd_remap;
     const bool f16 = a.split_f16 != 0;
     const int xp = f16 ? 2 : 3;              // activation planes in LDS
-    s.wscale = f16 ? reinterpret_cast<const float*>(static_cast<const unsigned char*>(a.wsplit) + split_frag_bytes(a)) : nullptr;
-    s.xs = 1.f;
-    s.xinv = 1.f;
+    s.wscale = f16 ? reinterpret_cast<const float*>(static_cast<const unsigned char*>(a.wsplit) + split_frag_bytes(a, true)) : nullptr;
+    s.x_amax = a.x_amax;
+    s.y_amax = a.y_amax;
+    if (f16 && !a.x_amax) {
+        pp_set_error("conv_split: the fp16 form needs the per-sample maximum of its input (ConvArgs::x_amax)");
+        return PP_ERR_STATE;
+    }
     PP_TL_BEGIN();
     // inputs beyond the Infinity Cache (256 MB): the columns of a tile back to back; smaller ones: column by column
     static const int colmaj_mb = env_int("POSEPIPE_SPLIT_COLMAJOR_MB", 256);

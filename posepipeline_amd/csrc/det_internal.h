@@ -3,6 +3,17 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+// Test-time constants of the configuration the reference selects (wrappers/mmtrack.py:16-19 ->
+// 3rdparty/mmtracking/mot/deepsort/deepsort_faster-rcnn_fpn_4e_mot17-private-half.py on _base_/models/faster_rcnn_r50_fpn.py:101-109
+// and _base_/datasets/mot_challenge.py:33-47).  pp_detector_constants exports them; tests/test_arch_configs.py compares that with
+// the values evaluated from those files (tests/golden/arch_configs.json).
+constexpr int PP_DET_RPN_NMS_PRE = 1000, PP_DET_RPN_MAX_PER_IMG = 1000, PP_DET_RCNN_MAX_PER_IMG = 100;
+constexpr float PP_DET_RPN_NMS_IOU = 0.7f, PP_DET_RCNN_SCORE_THR = 0.05f, PP_DET_RCNN_NMS_IOU = 0.5f;
+constexpr int PP_DET_IMG_SCALE_LONG = 1088, PP_DET_IMG_SCALE_SHORT = 1088, PP_DET_SIZE_DIVISOR = 32;
+constexpr int PP_DET_ROI_SIZE = 7;                 // RoIAlign output_size = bbox_head.roi_feat_size (the kernels are written for 7 x 7 bins)
+constexpr float PP_DET_FINEST_SCALE = 56.f;        // SingleRoIExtractor.map_roi_levels (mmdet's default; not in the config file)
+#define PP_DET_RCNN_STDS {0.1f, 0.1f, 0.2f, 0.2f}  /* bbox_head.bbox_coder.target_stds (means 0) */
+
 struct DetRpnArgs {
     const float* cls[5];   // RPN objectness logits per level [frame][H][W][3] -- or, pitch 16: channels 0 - 2 of the fused head's map
     const float* reg[5];   // RPN deltas per level [frame][H][W][12] -- or cls + 3 of the fused map (channels 3 - 14)

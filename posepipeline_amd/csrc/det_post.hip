@@ -367,7 +367,7 @@ __device__ __forceinline__ float4 bilinear4(const float* feat, int H, int W, int
 
 __device__ __forceinline__ int roi_level(float x1, float y1, float x2, float y2) {
     const float scale = sqrtf((x2 - x1) * (y2 - y1));
-    const int lvl = (int)floor(log2((double)(scale / 56.f + 1e-6f)));
+    const int lvl = (int)floor(log2((double)(scale / PP_DET_FINEST_SCALE + 1e-6f)));
     return min(max(lvl, 0), 3);
 }
 
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void roi_align_kernel_scalar(FpnLevels L, int 
     const float rx1 = roi[0], ry1 = roi[1], rx2 = roi[2], ry2 = roi[3];
     // SingleRoIExtractor.map_roi_levels (finest_scale 56)
     const float scale = sqrtf((rx2 - rx1) * (ry2 - ry1));
-    int lvl = (int)floor(log2((double)(scale / 56.f + 1e-6f)));
+    int lvl = (int)floor(log2((double)(scale / PP_DET_FINEST_SCALE + 1e-6f)));
     lvl = min(max(lvl, 0), 3);
     const float ss = 1.0f / (float)L.stride[lvl];
     const int H = L.h[lvl], W = L.w[lvl];
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(1024) void final_decode_kernel(const float* __restr
     const int f = blockIdx.x;
     __shared__ int s_w[17];
     const int n = n_rois[f];
-    const float stds[4] = {0.1f, 0.1f, 0.2f, 0.2f};
+    const float stds[4] = PP_DET_RCNN_STDS;
     int written = 0;
     for (int base = 0; base < n; base += blockDim.x) {
         const int r = base + threadIdx.x;

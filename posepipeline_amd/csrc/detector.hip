@@ -24,8 +24,8 @@ struct pp_detector {
     int rpn_pitch = 0;       // 16: cls_buf[l] == reg_buf[l] is the fused head's 16-channel map
     int H = 0, W = 0, nh = 0, nw = 0, Hp = 0, Wp = 0;
     float sfx = 1.f, sfy = 1.f;
-    int max_frames = 0, nms_pre = 1000, max_rois = 1000, max_det = 100, max_n = 0;
-    float rpn_iou = 0.7f, score_thr = 0.05f, det_iou = 0.5f;
+    int max_frames = 0, nms_pre = PP_DET_RPN_NMS_PRE, max_rois = PP_DET_RPN_MAX_PER_IMG, max_det = PP_DET_RCNN_MAX_PER_IMG, max_n = 0;
+    float rpn_iou = PP_DET_RPN_NMS_IOU, score_thr = PP_DET_RCNN_SCORE_THR, det_iou = PP_DET_RCNN_NMS_IOU;
     int lvl_h[5], lvl_w[5], lvl_stride[5];
     float base[5][3][4];
     int scratch_stride = 0;
@@ -70,11 +70,21 @@ extern "C" {
 int pp_detector_input_size(int src_h, int src_w, int32_t* nh, int32_t* nw, int32_t* hp, int32_t* wp) {
     PP_REQUIRE(src_h > 0 && src_w > 0 && nh && nw && hp && wp, "pp_detector_input_size: bad argument");
     int a, b;
-    rescale_size(src_w, src_h, 1088, 1088, &a, &b);
+    rescale_size(src_w, src_h, PP_DET_IMG_SCALE_LONG, PP_DET_IMG_SCALE_SHORT, &a, &b);
     *nw = a; *nh = b;
-    *wp = (a + 31) / 32 * 32;
-    *hp = (b + 31) / 32 * 32;
+    *wp = (a + PP_DET_SIZE_DIVISOR - 1) / PP_DET_SIZE_DIVISOR * PP_DET_SIZE_DIVISOR;
+    *hp = (b + PP_DET_SIZE_DIVISOR - 1) / PP_DET_SIZE_DIVISOR * PP_DET_SIZE_DIVISOR;
     return PP_OK;
+}
+
+int pp_detector_constants(double* out, int cap) {
+    const float stds[4] = PP_DET_RCNN_STDS;
+    const double v[15] = {PP_DET_RPN_NMS_PRE, PP_DET_RPN_NMS_IOU, PP_DET_RPN_MAX_PER_IMG, PP_DET_RCNN_SCORE_THR, PP_DET_RCNN_NMS_IOU,
+                          PP_DET_RCNN_MAX_PER_IMG, PP_DET_IMG_SCALE_LONG, PP_DET_IMG_SCALE_SHORT, PP_DET_SIZE_DIVISOR, PP_DET_ROI_SIZE,
+                          PP_DET_FINEST_SCALE, stds[0], stds[1], stds[2], stds[3]};
+    PP_REQUIRE(out && cap >= 15, "pp_detector_constants: out must hold 15 doubles");
+    for (int i = 0; i < 15; ++i) out[i] = v[i];
+    return 15;
 }
 
 int pp_rescale_size(int src_h, int src_w, int max_long, int max_short, int divisor, int32_t* nh, int32_t* nw, int32_t* hp,
@@ -130,9 +140,9 @@ int pp_detector_create(pp_net* netA, pp_net* netB, const int32_t* bufs_a, const 
     PP_REQUIRE(pp_net_ctx(netB) == d->ctx, "pp_detector_create: both programs must live on the same context");
     d->netA = netA; d->netB = netB;
     d->H = src_h; d->W = src_w;
-    rescale_size(src_w, src_h, 1088, 1088, &d->nw, &d->nh);
-    d->Wp = (d->nw + 31) / 32 * 32;
-    d->Hp = (d->nh + 31) / 32 * 32;
+    rescale_size(src_w, src_h, PP_DET_IMG_SCALE_LONG, PP_DET_IMG_SCALE_SHORT, &d->nw, &d->nh);
+    d->Wp = (d->nw + PP_DET_SIZE_DIVISOR - 1) / PP_DET_SIZE_DIVISOR * PP_DET_SIZE_DIVISOR;
+    d->Hp = (d->nh + PP_DET_SIZE_DIVISOR - 1) / PP_DET_SIZE_DIVISOR * PP_DET_SIZE_DIVISOR;
     d->sfx = (float)((double)d->nw / src_w);
     d->sfy = (float)((double)d->nh / src_h);
     d->in_buf = bufs_a[0];
@@ -165,7 +175,7 @@ int pp_detector_create(pp_net* netA, pp_net* netB, const int32_t* bufs_a, const 
                    "FPN level %d shape mismatch", l);
     }
     d->roi_in = bufs_b[0]; d->roi_cls = bufs_b[1]; d->roi_reg = bufs_b[2];
-    PP_REQUIRE(pp_net_dims(netB, d->roi_in, &h, &w, &c) == PP_OK && h == 7 && w == 7 && c == 256, "RoI head input must be 7x7x256");
+    PP_REQUIRE(pp_net_dims(netB, d->roi_in, &h, &w, &c) == PP_OK && h == PP_DET_ROI_SIZE && w == PP_DET_ROI_SIZE && c == 256, "RoI head input must be 7x7x256");
     PP_REQUIRE(pp_net_dims(netB, d->roi_cls, &h, &w, &c) == PP_OK && h * w == 1 && c == 2, "RoI head cls output must be 1x1x2");
     PP_REQUIRE(pp_net_dims(netB, d->roi_reg, &h, &w, &c) == PP_OK && h * w == 1 && c == 4, "RoI head reg output must be 1x1x4");
     d->max_frames = std::min(pp_net_max_batch(netA), pp_net_max_batch(netB) / d->max_rois);

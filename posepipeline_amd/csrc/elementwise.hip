@@ -9,43 +9,67 @@
 #include <algorithm>
 
 #include "pp_internal.h"
+#include "pp_amax.h"
 
 namespace {
 
+// UA_R float4 per thread (consecutive 4 KB chunks of the block): with the maximum tracked for a fp16-form reader (pp_amax.h) a block
+// then issues ONE atomic per sample for 32 KB of output -- same-address atomics serialise at ~0.6 us each at the memory side
+constexpr int UA_R = 8;
 __global__ __launch_bounds__(256) void upsample_add_kernel(const float4* __restrict__ t, const float4* __restrict__ r1,
                                                            const float4* __restrict__ r2, float4* __restrict__ y, size_t total,
                                                            int H, int W, int c4, int up, int relu, const float4* __restrict__ t2,
-                                                           int up2, const float4* __restrict__ t3, int up3) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int cc = (int)(i % c4);
-    size_t p = i / c4;
-    const int x = (int)(p % W);
-    p /= W;
-    const int yy = (int)(p % H);
-    const size_t n = p / H;
-    const int hs = H >> up, ws = W >> up;
-    float4 v = t[((n * hs + (yy >> up)) * ws + (x >> up)) * c4 + cc];
-    if (r1) {
-        const float4 a = r1[i];
-        v.x = __fadd_rn(v.x, a.x); v.y = __fadd_rn(v.y, a.y); v.z = __fadd_rn(v.z, a.z); v.w = __fadd_rn(v.w, a.w);
+                                                           int up2, const float4* __restrict__ t3, int up3, unsigned* y_amax) {
+    const size_t per = (size_t)H * W * c4;            // float4 per sample
+    const size_t b0 = (size_t)blockIdx.x * (256 * UA_R);
+    const int img_first = (int)(b0 / per);
+    float ym[2] = {0.f, 0.f};                         // max |y| of this thread's elements in sample img_first / img_first + 1
+#pragma unroll
+    for (int r = 0; r < UA_R; ++r) {
+        const size_t i = b0 + (size_t)r * 256 + threadIdx.x;
+        if (i >= total) break;
+        const int cc = (int)(i % c4);
+        size_t p = i / c4;
+        const int x = (int)(p % W);
+        p /= W;
+        const int yy = (int)(p % H);
+        const size_t n = p / H;
+        const int hs = H >> up, ws = W >> up;
+        float4 v = t[((n * hs + (yy >> up)) * ws + (x >> up)) * c4 + cc];
+        if (r1) {
+            const float4 a = r1[i];
+            v.x = __fadd_rn(v.x, a.x); v.y = __fadd_rn(v.y, a.y); v.z = __fadd_rn(v.z, a.z); v.w = __fadd_rn(v.w, a.w);
+        }
+        if (t2) {          // further coarse terms, in mmpose's `y += ...` order
+            const float4 a = t2[((n * (H >> up2) + (yy >> up2)) * (W >> up2) + (x >> up2)) * c4 + cc];
+            v.x = __fadd_rn(v.x, a.x); v.y = __fadd_rn(v.y, a.y); v.z = __fadd_rn(v.z, a.z); v.w = __fadd_rn(v.w, a.w);
+        }
+        if (t3) {
+            const float4 a = t3[((n * (H >> up3) + (yy >> up3)) * (W >> up3) + (x >> up3)) * c4 + cc];
+            v.x = __fadd_rn(v.x, a.x); v.y = __fadd_rn(v.y, a.y); v.z = __fadd_rn(v.z, a.z); v.w = __fadd_rn(v.w, a.w);
+        }
+        if (r2) {
+            const float4 a = r2[i];
+            v.x = __fadd_rn(v.x, a.x); v.y = __fadd_rn(v.y, a.y); v.z = __fadd_rn(v.z, a.z); v.w = __fadd_rn(v.w, a.w);
+        }
+        if (relu) {
+            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        y[i] = v;
+        if (y_amax) {
+            const float m = pp_abs4max(v);
+            const int d = (int)n - img_first;
+            if (d == 0) ym[0] = fmaxf(ym[0], m);
+            else if (d == 1) ym[1] = fmaxf(ym[1], m);
+            else if (m > 0.f) atomicMax(y_amax + n, __float_as_uint(m));      // samples smaller than a quarter of a block: rare, direct
+        }
     }
-    if (t2) {          // further coarse terms, in mmpose's `y += ...` order
-        const float4 a = t2[((n * (H >> up2) + (yy >> up2)) * (W >> up2) + (x >> up2)) * c4 + cc];
-        v.x = __fadd_rn(v.x, a.x); v.y = __fadd_rn(v.y, a.y); v.z = __fadd_rn(v.z, a.z); v.w = __fadd_rn(v.w, a.w);
+    if (y_amax) {
+        __shared__ float red[16];
+        const size_t last = (b0 + 256 * UA_R - 1 < total ? b0 + 256 * UA_R - 1 : total - 1) / per;
+        const int im[2] = {img_first, img_first + 1};
+        pp_amax_commit_wg<4, 2>(y_amax, im, ym, img_first, (int)last > img_first ? img_first + 1 : img_first, red);
     }
-    if (t3) {
-        const float4 a = t3[((n * (H >> up3) + (yy >> up3)) * (W >> up3) + (x >> up3)) * c4 + cc];
-        v.x = __fadd_rn(v.x, a.x); v.y = __fadd_rn(v.y, a.y); v.z = __fadd_rn(v.z, a.z); v.w = __fadd_rn(v.w, a.w);
-    }
-    if (r2) {
-        const float4 a = r2[i];
-        v.x = __fadd_rn(v.x, a.x); v.y = __fadd_rn(v.y, a.y); v.z = __fadd_rn(v.z, a.z); v.w = __fadd_rn(v.w, a.w);
-    }
-    if (relu) {
-        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-    }
-    y[i] = v;
 }
 
 // PP_OP_AVGPOOL: nn.AvgPool2d((kh, kw), stride) without padding (the GlobalAveragePooling neck of mmtrack's ReID model,
@@ -138,15 +162,16 @@ extern "C" int pp_crop_resize_bilinear(pp_ctx* ctx, const float* src_nhwc4, int 
 }
 
 int pp_launch_upsample_add(const float* t, const float* res1, const float* res2, float* y, int n, int H, int W, int c,
-                           int up_log2, int relu, hipStream_t stream, const float* t2, int up2, const float* t3, int up3) {
+                           int up_log2, int relu, hipStream_t stream, const float* t2, int up2, const float* t3, int up3,
+                           unsigned* y_amax) {
     PP_REQUIRE(n > 0 && H > 0 && W > 0 && c > 0 && (c & 3) == 0, "upsample_add: c = %d must be a multiple of 4", c);
     PP_REQUIRE(up_log2 >= 0 && up_log2 <= 5 && (H >> up_log2 << up_log2) == H && (W >> up_log2 << up_log2) == W,
                "upsample_add: %dx%d is not a multiple of 2^%d", H, W, up_log2);
     const size_t total = (size_t)n * H * W * (c / 4);
-    hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)((total + 256 * UA_R - 1) / (256 * UA_R))), dim3(256), 0, stream,
                        reinterpret_cast<const float4*>(t), reinterpret_cast<const float4*>(res1),
                        reinterpret_cast<const float4*>(res2), reinterpret_cast<float4*>(y), total, H, W, c / 4, up_log2, relu,
-                       reinterpret_cast<const float4*>(t2), up2, reinterpret_cast<const float4*>(t3), up3);
+                       reinterpret_cast<const float4*>(t2), up2, reinterpret_cast<const float4*>(t3), up3, y_amax);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }

@@ -91,12 +91,19 @@ struct ConvArgs {
     // split kernels: 0 = three bf16 planes, six products; 1 = the fp16 form (two activation planes, three products; round 5).  Fixed
     // with the split weights (pp_conv_split_bytes / _weights / pp_launch_conv_split must see the same value)
     int split_f16;
+    // fp16 form: per-sample running maximum of |x| (pp_amax.h; required by the fp16 kernels) and, any conv kernel, where to fold max |y|
+    // per sample of what this launch stores (null: nobody needs it).  Device pointers to N slots each.
+    const unsigned* x_amax;
+    unsigned* y_amax;
 };
 // fp32 convolution on the bf16 matrix cores (three-way split, six products; conv_split.hip)
 bool pp_conv_split_eligible(const ConvArgs& a);
 size_t pp_conv_split_bytes(const ConvArgs& a);
 int pp_conv_split_weights(const ConvArgs& a, void* out, hipStream_t stream);
 int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream);   // `a` as prepared by pp_launch_conv, a.wsplit set
+// true: the kernel this layer runs on folds max |y| per sample into ConvArgs::y_amax in its epilogue (pp_amax.h) -- the split
+// kernels always, the float32 kernels in their plain NHWC epilogue; false: the caller takes the maximum in a pass of its own
+bool pp_conv_tracks_amax(const ConvArgs& a, bool split);
 bool pp_conv_split_enabled();       // false: POSEPIPE_CONV_EXACT=1 or an explicit exact variant
 bool pp_conv_split_f16_default();   // the process-wide default split form (pp_conv_split_kind / POSEPIPE_SPLIT_F16)
 // builds (and caches per device) the tap tables the pipelined kernel may use for this geometry; call outside graph capture
@@ -155,7 +162,7 @@ int pp_launch_depth_to_space(const float* x, float* y, int n, int h, int w, int 
 // t2 / t3 may be null)
 int pp_launch_upsample_add(const float* t, const float* res1, const float* res2, float* y, int n, int H, int W, int c,
                            int up_log2, int relu, hipStream_t stream, const float* t2 = nullptr, int up2 = 0,
-                           const float* t3 = nullptr, int up3 = 0);
+                           const float* t3 = nullptr, int up3 = 0, unsigned* y_amax = nullptr);   // y_amax: pp_amax.h
 // encoder behind PP_OP_VIT_ENCODER; `params` is a DEVICE pointer into the program's fp32 weight blob
 struct pp_vit_encoder;
 size_t pp_vit_param_floats(int tokens, int dim, int depth, int hidden);

@@ -25,6 +25,8 @@ from ..program import Net, Program, ProgramBuilder, fold_bn
 BN_EPS = 1e-3
 STRIDES = (8, 16, 32)
 WIDEN, DEEPEN = 1.25, 1.33
+PAD_VALUE = 114.0            # Pad(size_divisor=32, pad_val=dict(img=(114.0, 114.0, 114.0))), bytetrack_*.py test pipeline
+SIZE_DIVISOR = 32
 ARCH = ((64, 128, 3, True, False), (128, 256, 9, True, False), (256, 512, 9, True, False), (512, 1024, 3, False, True))
 
 
@@ -184,7 +186,7 @@ class YoloXDetector:
                  score_thr: float = 0.01, iou_thr: float = 0.7, numerics=None):
         self.ctx, self.src = ctx, (src_h, src_w)
         dims = [C.c_int32() for _ in range(4)]
-        L.check(ctx.lib.pp_rescale_size(src_h, src_w, max(scale), min(scale), 32, *[C.byref(d) for d in dims]), "pp_rescale_size")
+        L.check(ctx.lib.pp_rescale_size(src_h, src_w, max(scale), min(scale), SIZE_DIVISOR, *[C.byref(d) for d in dims]), "pp_rescale_size")
         self.nh, self.nw, self.hp, self.wp = (int(d.value) for d in dims)
         self.scale_factor = np.array([self.nw / src_w, self.nh / src_h, self.nw / src_w, self.nh / src_h], np.float32)
         self.score_thr, self.iou_thr = score_thr, iou_thr
@@ -215,7 +217,7 @@ class YoloXDetector:
         assert 0 < n <= self.max_frames
         din, _, _ = self.net.buffer("input")
         L.check(self.ctx.lib.pp_resize_pad_normalize(self.ctx.handle, src, n, self.src[0], self.src[1], mem, self.nh, self.nw,
-                                                     self.hp, self.wp, L.ptr(self.lut), 114.0, L.ptr(int(din))),
+                                                     self.hp, self.wp, L.ptr(self.lut), PAD_VALUE, L.ptr(int(din))),
                 "pp_resize_pad_normalize")
         self.ctx.timer_start()
         self.net.run(n)

@@ -59,6 +59,14 @@ BATCH = 32
 _cache: dict = {}
 
 
+def topdown_settings(method):
+    """What `_model` hands ops.TopDown for `method` -- the test_cfg of the method's config (flip_test, post_process,
+    shift_heatmap, modulate_kernel: hrnet_w48_coco_384x288_dark.py:81-85).  No device needed (tests/test_arch_configs.py)."""
+    _, _, k, pairs, post, blur = _METHODS[method]
+    return dict(num_joints=k, flip_perm=hrnet.flip_perm(k, pairs), shift_heatmap=post != "udp", post=post, blur_kernel=blur,
+                chan_map=(0, 1, 2))
+
+
 def _model(method, device=0):
     """(Context, Net, TopDown) for `method`, built once per process (the reference rebuilds per key, :57)."""
     if (method, device) not in _cache:
@@ -76,8 +84,7 @@ def _model(method, device=0):
             sd = weights.get_state_dict(ckpt, hrnet.hrnet_param_shapes(spec), seed=1)
             prog = hrnet.build_hrnet_program(spec, sd)
         net = Net(ctx, prog, max_batch=2 * BATCH)
-        td = ops.TopDown(net, num_joints=k, flip_perm=hrnet.flip_perm(k, pairs), shift_heatmap=post != "udp", post=post,
-                         blur_kernel=blur, chan_map=(0, 1, 2))
+        td = ops.TopDown(net, **topdown_settings(method))
         _cache[(method, device)] = (ctx, net, td, k)
     return _cache[(method, device)]
 

@@ -47,6 +47,10 @@ def main():
         "relu": lambda s: np.maximum(rng.standard_normal(s), 0) * 3,                               # same-sign data
         "tiny": lambda s: rng.standard_normal(s) * 1e-6,
         "large": lambda s: rng.standard_normal(s) * 3e3,
+        "1e-30": lambda s: rng.standard_normal(s) * 1e-30,
+        "1e+7": lambda s: rng.standard_normal(s) * 1e7,                                            # above the float16 range
+        # every sample of the batch at its own magnitude (1e-6 .. 1e4): the activation scale is per sample
+        "persample": lambda s: rng.standard_normal(s) * (10.0 ** np.linspace(-6, 4, s[0])).reshape(-1, 1, 1, 1),
     }
     print("case | dist | exact max rms | bf16x3 max rms | f16x2 max rms | f16/exact rms ratio")
     worst = 0.0
@@ -66,7 +70,8 @@ def main():
                 with L.default_numerics(mode):
                     out[mode] = hip_conv_op(ctx, x, wt, b, stride=stride, pad=(pad, pad), relu=0)
             # per-channel scale (the channels' ranges differ by orders of magnitude)
-            scale = np.abs(ref).reshape(-1, cout).max(0) + 1e-300
+            # (and per sample: "persample" spreads the batch over ten orders)
+            scale = np.abs(ref).reshape(n, -1, cout).max(1).reshape(n, 1, 1, cout) + 1e-300
             st = []
             for mode in ("exact", "split_bf16", "split_f16"):
                 d = (out[mode] - ref) / scale
@@ -74,7 +79,7 @@ def main():
             ratio = st[5] / max(st[1], 1e-30)
             worst = max(worst, ratio)
             same = np.array_equal(out["split_f16"], out["exact"])
-            print(f"{n}x{h}x{w} {cin}->{cout} k{k}s{stride} | {dname:6s} | {st[0]:.2e} {st[1]:.2e} | {st[2]:.2e} {st[3]:.2e} | {st[4]:.2e} {st[5]:.2e} | {ratio:.2f}"
+            print(f"{n}x{h}x{w} {cin}->{cout} k{k}s{stride} | {dname:9s} | {st[0]:.2e} {st[1]:.2e} | {st[2]:.2e} {st[3]:.2e} | {st[4]:.2e} {st[5]:.2e} | {ratio:.2f}"
                   f"{' (f16 == exact: kernel did not run?)' if same else ''}{' NaN' if not np.isfinite(out['split_f16']).all() else ''}", flush=True)
     print(f"worst f16 / exact rms ratio: {worst:.2f}")
 
