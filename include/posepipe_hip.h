@@ -72,6 +72,11 @@ int pp_ctx_synchronize(pp_ctx* ctx);
 /* HIP-event timer on the ctx stream (bench.py's roofline leg): start/stop bracket launches. */
 int pp_timer_start(pp_ctx* ctx);
 int pp_timer_stop(pp_ctx* ctx, float* elapsed_ms); /* synchronises on the stop event */
+/* A/B knobs of tests and profiles that select between two kernels giving IDENTICAL bits (never numerics): "decode_generic"
+ * (1: the generic flip-merge / decode kernel instead of the fast one), "split_gemm_epilogue" (1: the product kernel's epilogue
+ * transposed through LDS, 0: from registers).  value -1: back to the environment's choice (POSEPIPE_DECODE_GENERIC /
+ * POSEPIPE_SPLIT_GEMM_EPI, read once per process).  Process-wide, thread-safe. */
+int pp_debug_knob(const char* name, int value);
 /* raw device memory helpers so that a host language without a HIP binding can keep data resident */
 int pp_malloc(pp_ctx* ctx, size_t bytes, void** dptr);
 int pp_free(pp_ctx* ctx, void* dptr);
@@ -198,7 +203,7 @@ int pp_net_create_mem(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bu
 #define PP_NET_NUMERICS_EXACT 1
 #define PP_NET_NUMERICS_SPLIT 2        /* the split form pp_conv_split_kind selects at this moment */
 #define PP_NET_NUMERICS_SPLIT_BF16 3   /* three bfloat16 terms per operand, six products (rounds 2 - 4) */
-#define PP_NET_NUMERICS_SPLIT_F16 4    /* two float16 terms per operand (per-channel / per-tensor power-of-two scales), three products */
+#define PP_NET_NUMERICS_SPLIT_F16 4    /* two float16 terms per operand (per-channel / per-sample power-of-two scales), three products */
 int pp_net_create_ex(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* bufs, int n_bufs,
                      const float* weights, size_t n_weights, int weights_mem, int max_batch, int numerics, pp_net** out);
 /* PP_NET_NUMERICS_EXACT or PP_NET_NUMERICS_SPLIT: what the net was created with (never DEFAULT) */
@@ -249,9 +254,14 @@ int pp_conv_variant(int variant);
  * exact = -1: back to the environment's choice. */
 int pp_conv_exact(int exact);
 /* Process-wide DEFAULT split form: what PP_NET_NUMERICS_SPLIT (and DEFAULT, when it resolves to split) nets created LATER and the
- * single-op entry point get.  f16 = 1: two float16 terms per operand and three v_mfma_f32_32x32x16_f16 products per term (half the
- * matrix work of the six-product form; same float32 accumulation, error against a float64 convolution still that of the float32
- * FMA chain, tests/test_gpu_split.py); 0: three bfloat16 terms, six products; -1: the environment's choice (POSEPIPE_SPLIT_F16). */
+ * single-op entry point get.  f16 = 1 (the default since round 5): two float16 terms per operand and three
+ * v_mfma_f32_32x32x16_f16 products per term (half the matrix work of the six-product form; same float32 accumulation).  Weights are
+ * normalised per output channel, activations PER SAMPLE by a power of two taken from the running maximum of the tensor -- tracked by
+ * the kernel that produces it, or by one extra pass for tensors that come from outside the program -- so the representation keeps 22
+ * significand bits at ANY magnitude of the data (nothing saturates, nothing underflows) and a sample's result does not depend on
+ * what else is in the batch.  Error against a float64 convolution: that of the float32 FMA chain or lower (tests/test_gpu_split.py,
+ * inputs from 1e-30 to 1e7).  0: three bfloat16 terms, six products (rounds 2 - 4); -1: the environment's choice
+ * (POSEPIPE_SPLIT_F16, default 1). */
 int pp_conv_split_kind(int f16);
 
 /* single convolution on caller-provided device/host buffers (tests, VideoPose3D, FC layers).

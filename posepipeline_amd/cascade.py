@@ -44,7 +44,7 @@ class Cascade:
     def __init__(self, ctx: L.Context, det_sd, pose_sd: dict, lift_sd: dict, src_h: int, src_w: int,
                  chunk: int = 8, max_persons: int = 1, pose_spec=None, post="unbiased", blur_kernel=17,
                  tracking: str = "MMTrack_deepsort", keep_tracks=None, flip_pairs=None, blob_fn=None, reid_sd=None,
-                 overlap_detector: bool | None = None, numerics=None):
+                 overlap_detector: bool | None = None, numerics=None, id_numerics=None):
         """blob_fn(name, program) -> (device pointer, n_floats) or None, name in "det_a", "det_b", "pose", "lift" (called in
         that order): a weight blob that is already resident on the device -- parallel.broadcast_blob_device delivers rank
         0's over RCCL; the *_sd arguments then only define the program structure (ops, buffers, blob offsets).
@@ -56,7 +56,13 @@ class Cascade:
         (the worker thread spends its time inside a synchronous GPU call, and HIP's waits spin), POSEPIPE_OVERLAP_DETECTOR=0/1
         overrides."""
         # numerics: "exact" / "split" / None (= the process default at this moment) for EVERY program this cascade creates, passed
-        # down explicitly -- two threads building cascades in different modes do not interfere (unlike _lib.default_numerics)
+        # down explicitly -- two threads building cascades in different modes do not interfere (unlike _lib.default_numerics).
+        # id_numerics (round 5): numerics of the programs whose outputs feed INTEGER decisions -- the detector (top-k, NMS, score
+        # thresholds -> which boxes exist, in which order) and the appearance encoder (gated assignment) -- where it should differ from
+        # the rest.  numerics="split", id_numerics="exact" is the "integer-exact" configuration: track ids, bbox indices and `present`
+        # are the oracle's BY CONSTRUCTION (the float32-MFMA detector is bit-identical to it, the tracker is host float64), while the
+        # pose / lifting programs, whose outputs are held to 1e-3 px / mm, run on the fast kernels.
+        id_numerics = numerics if id_numerics is None else id_numerics
         self.ctx = ctx
         self.det_ctx = ctx
         self._pending = None          # (chunk key, Future of _det_job) started by step(prefetch=...)
@@ -71,8 +77,8 @@ class Cascade:
         self.reid = None
         if tracking == "DeepSortYOLOv4":
             from .models import mars, yolov4
-            self.detector = yolov4.YoloV4Detector(ctx, det_sd[0], src_h, src_w, max_frames=chunk, numerics=numerics)
-            self.encoder = mars.MarsEncoder(ctx, det_sd[1], src_h, src_w, max_patches=max(64, chunk * max_persons), numerics=numerics)
+            self.detector = yolov4.YoloV4Detector(ctx, det_sd[0], src_h, src_w, max_frames=chunk, numerics=id_numerics)
+            self.encoder = mars.MarsEncoder(ctx, det_sd[1], src_h, src_w, max_patches=max(64, chunk * max_persons), numerics=id_numerics)
         else:
             assert tracking == "MMTrack_deepsort", tracking
             if overlap_detector is None:
@@ -80,10 +86,10 @@ class Cascade:
                 ranks = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
                 overlap_detector = (env != "0") if env is not None else (os.cpu_count() or 1) >= 4 * ranks
             self.det_ctx = L.Context(ctx.device) if (overlap_detector and reid_sd is None) else ctx
-            self.detector = fr.Detector(self.det_ctx, det_sd, src_h, src_w, max_frames=chunk, blob_fn=blob_fn, numerics=numerics)
+            self.detector = fr.Detector(self.det_ctx, det_sd, src_h, src_w, max_frames=chunk, blob_fn=blob_fn, numerics=id_numerics)
             if reid_sd is not None:
                 from .models import reid_r50
-                self.reid = reid_r50.ReidEncoder(ctx, reid_sd, self.detector, max_crops=max(64, chunk * max_persons), blob_fn=blob_fn, numerics=numerics)
+                self.reid = reid_r50.ReidEncoder(ctx, reid_sd, self.detector, max_crops=max(64, chunk * max_persons), blob_fn=blob_fn, numerics=id_numerics)
         self.pose_spec = pose_spec or hrnet.hrnet_w48_384x288()
         if isinstance(self.pose_spec, vitpose.VitPoseSpec):     # BASELINE.json configs[4]: ViTPose 2D stage (UDP, bf16 MFMA)
             pose_prog = vitpose.build_vitpose_program(self.pose_spec, pose_sd)

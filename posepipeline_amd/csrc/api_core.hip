@@ -5,6 +5,9 @@
 #include "pp_internal.h"
 #include "pp_amax.h"
 
+#include <atomic>
+extern std::atomic<int> g_decode_generic, g_split_gemm_epi;      // dark_decode.hip, conv_split.hip
+
 static thread_local std::string g_last_error;
 
 void pp_set_error(const char* fmt, ...) {
@@ -33,6 +36,17 @@ int pp_ctx::ensure_scratch(size_t bytes) {
 extern "C" {
 
 int pp_abi_version(void) { return PP_ABI_VERSION; }
+
+int pp_debug_knob(const char* name, int value) {
+    PP_REQUIRE(name && value >= -1 && value <= 1, "pp_debug_knob: name and a value in {-1, 0, 1}");
+    if (!strcmp(name, "decode_generic")) g_decode_generic.store(value, std::memory_order_relaxed);
+    else if (!strcmp(name, "split_gemm_epilogue")) g_split_gemm_epi.store(value, std::memory_order_relaxed);
+    else {
+        pp_set_error("pp_debug_knob: unknown knob '%s' (decode_generic, split_gemm_epilogue)", name);
+        return PP_ERR_ARG;
+    }
+    return PP_OK;
+}
 
 const char* pp_last_error(void) { return g_last_error.c_str(); }
 

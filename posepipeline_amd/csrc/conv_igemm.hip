@@ -659,7 +659,7 @@ bool pp_conv_split_enabled() {
 
 std::atomic<int> g_split_f16{-1};     // pp_conv_split_kind: -1 = POSEPIPE_SPLIT_F16
 bool pp_conv_split_f16_default() {
-    static const int env_f16 = env_int("POSEPIPE_SPLIT_F16", 0);
+    static const int env_f16 = env_int("POSEPIPE_SPLIT_F16", 1);     // round 5: the fp16 form is the default split form
     const int g = g_split_f16.load(std::memory_order_relaxed);
     return (g >= 0 ? g : env_f16) != 0;
 }

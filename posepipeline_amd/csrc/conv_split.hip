@@ -31,6 +31,7 @@
 //     the float32 loads of chunk c + 1 are in flight during chunk c and split / written half-way through it.
 // Traffic per 16-channel chunk and block: patch 340 x 64 B + weights 9 x 6 KB (L1 / L2 resident) = 11 B / matrix-pipe cycle.
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <type_traits>
@@ -50,6 +51,8 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+std::atomic<int> g_split_gemm_epi{-1};       // pp_debug_knob("split_gemm_epilogue"): -1 = POSEPIPE_SPLIT_GEMM_EPI
 
 namespace {
 
@@ -1991,11 +1994,12 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         s.xcd_remap = gemm_remap && s.gy > 1;
         if (s.xcd_remap) grid = dim3((unsigned)((s.gx + 7) / 8 * 8 * s.gy), 1);
         else s.xcd_remap = 0;
-        // POSEPIPE_SPLIT_GEMM_EPI: 1 = epilogue transposed through LDS (18 KiB per wave), 0 = from registers.  The one knob still read per
-        // launch: it selects between two store orders of the SAME values (bit-identical, tests/test_gpu_split.py A/Bs them in one
-        // process), needs no creation-time state and cannot make a created net ineligible
-        const char* epi_env = getenv("POSEPIPE_SPLIT_GEMM_EPI");
-        s.epi_lds = epi_env ? atoi(epi_env) : 1;
+        // 1 = epilogue transposed through LDS (18 KiB per wave), 0 = from registers: two store orders of the SAME values (bit-identical,
+        // tests/test_gpu_split.py A/Bs them in one process through pp_debug_knob("split_gemm_epilogue", ..)); POSEPIPE_SPLIT_GEMM_EPI is
+        // read ONCE per process -- no environment scan per launch
+        static const int epi_env = [] { const char* e = getenv("POSEPIPE_SPLIT_GEMM_EPI"); return e ? atoi(e) : 1; }();
+        const int epi_knob = g_split_gemm_epi.load(std::memory_order_relaxed);
+        s.epi_lds = epi_knob >= 0 ? epi_knob : epi_env;
         const int nwave = 4;
         fill_divisors(s);
         const size_t lds = std::max<size_t>((size_t)2 * (xp * 2 * (BM + 4) * 16 + BN * 6 * 16), s.epi_lds ? (size_t)nwave * (16384 + 2048) : 0);

@@ -15,7 +15,11 @@
 // The heatmap lives in LDS for the whole decode (96x72 fp32 = 27.6 KB, two planes for the
 // separable blur); argmax / max are wave-shuffle reductions.  HBM traffic = the two heatmap
 // reads (2 * K*H*W*4 bytes per person) + 12 bytes per joint.
+#include <atomic>
+#include <mutex>
 #include "pp_internal.h"
+
+std::atomic<int> g_decode_generic{-1};      // pp_debug_knob("decode_generic"): -1 = POSEPIPE_DECODE_GENERIC
 
 namespace {
 
@@ -545,11 +549,18 @@ int pp_enqueue_decode(hipStream_t s, const DecodeParams& p, const float* hm, con
     a.hm = hm; a.hm_flip = hm_flip; a.flip_perm = flip_perm; a.center_scale = center_scale;
     a.kpts = kpts; a.merged = merged;
     // the fast form (see flip_merge_decode_fast_kernel): even maps with w % 4 == 0 up to 128 x 128, blur kernels 11 / 17 (or no blur)
-    const char* gen_env = getenv("POSEPIPE_DECODE_GENERIC");      // A/B and test knob (both kernels give identical bits: tests/test_gpu_decode_fast.py)
-    const bool fast_off = gen_env && atoi(gen_env) != 0;
+    // A/B and test knob (both kernels give identical bits: tests/test_gpu_decode_fast.py): pp_debug_knob("decode_generic", 1), else
+    // POSEPIPE_DECODE_GENERIC read ONCE -- no environment scan per launch
+    static const int gen_env = [] { const char* e = getenv("POSEPIPE_DECODE_GENERIC"); return e ? atoi(e) : 0; }();
+    const int gen_knob = g_decode_generic.load(std::memory_order_relaxed);
+    const bool fast_off = (gen_knob >= 0 ? gen_knob : gen_env) != 0;
     const bool blur = p.post >= 1;
+    // UDP (post 2) fills its frame by REFLECTION (BORDER_REFLECT_101): column / row j of the frame mirrors index j, which must be a
+    // map cell -- an 8-pixel map with the 17-tap kernel (radius 8) would read index 8, a frame cell other threads are writing
+    // (ADVICE r4); such maps take the generic kernel, whose mirror() folds the index back
+    const bool reflect_ok = p.post != 2 || (p.h > p.blur_kernel / 2 && p.w > p.blur_kernel / 2);
     const bool fast_ok = !fast_off && p.h % 2 == 0 && p.w % 4 == 0 && p.h <= 128 && p.w <= 128 && p.h >= 8 && p.w >= 8 &&
-                         (!blur || p.blur_kernel == 11 || p.blur_kernel == 17);
+                         (!blur || p.blur_kernel == 11 || p.blur_kernel == 17) && reflect_ok;
     if (fast_ok) {
         FastGeom g{};
         const int w8 = (p.w + 7) / 8 * 8, h8 = (p.h + 7) / 8 * 8;
@@ -565,13 +576,12 @@ int pp_enqueue_decode(hipStream_t s, const DecodeParams& p, const float* hm, con
         g.inv_nseg = 1.0f / (float)g.nseg;
         g.inv_nsegy = 1.0f / (float)g.nsegy;
         const size_t lds_fast = ((size_t)(p.h / 2) * g.wpa * 2 + (blur ? (size_t)(w8 / 2) * g.hpb * 2 + 64 : 0)) * sizeof(float);
-        static bool fast_attr = false;
-        if (!fast_attr) {
-            PP_HIP_CHECK(hipFuncSetAttribute((const void*)flip_merge_decode_fast_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-            PP_HIP_CHECK(hipFuncSetAttribute((const void*)flip_merge_decode_fast_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-            PP_HIP_CHECK(hipFuncSetAttribute((const void*)flip_merge_decode_fast_kernel<17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-            fast_attr = true;
-        }
+        static std::once_flag fast_attr;      // (as the conv_split launch macros: once per process, thread-safe)
+        std::call_once(fast_attr, [] {
+            (void)hipFuncSetAttribute((const void*)flip_merge_decode_fast_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+            (void)hipFuncSetAttribute((const void*)flip_merge_decode_fast_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+            (void)hipFuncSetAttribute((const void*)flip_merge_decode_fast_kernel<17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        });
         if (!blur) hipLaunchKernelGGL(flip_merge_decode_fast_kernel<0>, dim3(p.n * p.k), dim3(512), lds_fast, s, a, g);
         else if (p.blur_kernel == 11) hipLaunchKernelGGL(flip_merge_decode_fast_kernel<11>, dim3(p.n * p.k), dim3(512), lds_fast, s, a, g);
         else hipLaunchKernelGGL(flip_merge_decode_fast_kernel<17>, dim3(p.n * p.k), dim3(512), lds_fast, s, a, g);

@@ -4,11 +4,12 @@ replaces on the hot path: the SAME bits -- key points, scores, merged maps -- fo
 tile of the map matters for the blurred maximum), peaked maps, maps with peaks on the border and all-negative maps; and against
 the oracle (oracle/decode.py: mmpose's flip_back / shift / average, _gaussian_blur, _taylor, post_dark_udp, transform_preds --
 pose_pipeline/utils/inference.py:27-114 is the in-tree statement of the same steps) with the suite's usual bars.
-POSEPIPE_DECODE_GENERIC=1 selects the generic kernel (read per call)."""
+pp_debug_knob("decode_generic", 1) selects the generic kernel (process-wide; POSEPIPE_DECODE_GENERIC is read once per process)."""
 import numpy as np
 import pytest
 
 from oracle import decode as odec
+from posepipeline_amd import _lib as L
 from posepipeline_amd import ops
 from posepipeline_amd.models import hrnet
 
@@ -34,7 +35,9 @@ def _maps(rng, n, k, h, w, kind):
 
 
 CASES = [(96, 72, "unbiased", 17), (64, 48, "unbiased", 11), (64, 48, "udp", 11), (96, 72, "udp", 17), (96, 72, "default", 17),
-         (64, 48, None, 11), (24, 16, "unbiased", 17), (12, 8, "udp", 11), (128, 128, "unbiased", 17), (10, 12, "unbiased", 11)]
+         (64, 48, None, 11), (24, 16, "unbiased", 17), (12, 8, "udp", 11), (128, 128, "unbiased", 17), (10, 12, "unbiased", 11),
+         # 8-pixel maps with the 17-tap kernel under UDP's reflected frame: the launcher hands them to the generic kernel
+         (8, 8, "udp", 17), (8, 12, "udp", 17), (8, 8, "unbiased", 17)]
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -48,9 +51,11 @@ def test_fast_decode_equals_generic_kernel(ctx, monkeypatch, case, kind):
     perm = hrnet.flip_perm(17)
     for flip, shift in ((True, True), (True, False), (False, False)):
         args = dict(flip_perm=perm if flip else None, shift_heatmap=shift, post=post, blur_kernel=ks, want_merged=True)
-        monkeypatch.setenv("POSEPIPE_DECODE_GENERIC", "1")
-        kp_ref, mg_ref = ops.flip_merge_decode(ctx, hm, hf if flip else None, cs, **args)
-        monkeypatch.setenv("POSEPIPE_DECODE_GENERIC", "0")
+        try:
+            L.check(ctx.lib.pp_debug_knob(b"decode_generic", 1), "pp_debug_knob")
+            kp_ref, mg_ref = ops.flip_merge_decode(ctx, hm, hf if flip else None, cs, **args)
+        finally:
+            L.check(ctx.lib.pp_debug_knob(b"decode_generic", -1), "pp_debug_knob")
         kp, mg = ops.flip_merge_decode(ctx, hm, hf if flip else None, cs, **args)
         assert np.array_equal(mg, mg_ref)
         assert np.array_equal(kp, kp_ref, equal_nan=True), (case, kind, flip, shift, np.abs(kp - kp_ref).max())

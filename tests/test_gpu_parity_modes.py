@@ -372,3 +372,107 @@ def test_track_ids_on_detector_boxes(ctx, numerics):
             assert np.abs(box[:4] - r[1:5]).max() <= BOX_TOL[numerics] and abs(box[4] - r[5]) <= 1e-4
         total += len(rows)
     print(f"[{numerics}] {total} tracked detector boxes over {n} frames, ids identical")
+
+
+# ---- (iv) the integer contract at full size, NO replay -------------------------------------------------------
+def _clip_1080p_four_persons(n, rng):
+    """1080p clip: static block background, four textured rectangles on crossing trajectories"""
+    h, w = 1080, 1920
+    bg = np.repeat(np.repeat(rng.integers(20, 60, (h // 40, w // 40, 3)).astype(np.uint8), 40, axis=0), 40, axis=1)
+    people = [dict(x=200.0, y=150.0, w=170, h=520, vx=9.0), dict(x=1500.0, y=260.0, w=150, h=470, vx=-11.0),
+              dict(x=900.0, y=90.0, w=190, h=580, vx=2.0), dict(x=100.0, y=500.0, w=120, h=330, vx=5.0)]
+    for q in people:
+        q["tex"] = _blob_person(rng, q["h"], q["w"])
+    frames = np.empty((n, h, w, 3), np.uint8)
+    for t in range(n):
+        frames[t] = bg
+        for q in people:
+            x0, y0 = int(q["x"] + q["vx"] * t), int(q["y"])
+            frames[t, y0:y0 + q["h"], x0:x0 + q["w"]] = q["tex"]
+    return frames
+
+
+def _run_no_replay(ctx, frames, sds, chunk, **kw):
+    from posepipeline_amd.cascade import Cascade, collect
+    det_sd, pose_sd, lift_sd, spec = sds
+    cas = Cascade(ctx, det_sd, pose_sd, lift_sd, frames.shape[1], frames.shape[2], chunk=chunk, max_persons=4, pose_spec=spec, **kw)
+    outs = [cas.step(frames[i:i + chunk]) for i in range(0, len(frames), chunk)] + [cas.flush()]
+    tracks = [fr_ for o in outs for fr_ in o["tracks"]]
+    return cas, tracks, collect(outs, "keypoints"), collect(outs, "keypoints_3d")
+
+
+def test_integer_contract_1080p_64_frames_no_replay(ctx):
+    """north_star: "integer track-ids and bbox indices bit-exact" -- at 1080p, 64 frames in 4 chunks, >= 4 followed tracks, on boxes the
+    DETECTOR produced (no replay anywhere), seeded-random detector weights, nothing about the clip conditioned to pass:
+      exact         device detector -> product tracker -> PersonBbox  ==  oracle detector (anchor frame: the oracle itself at 1080p;
+                    every frame: the same kernels, whose equality with the oracle test_gpu_fullsize / test_gpu_detector hold) ->
+                    ORACLE tracker -> the reference's PersonBbox table logic: ids, tracked rows, bbox selection, `present` identical
+      integer-exact (numerics "split", id_numerics "exact": the detector on the float32-MFMA kernels, pose / lifting on the fp16-form
+                    kernels) the SAME integers on all 64 frames by construction -- asserted -- and every 2D / 3D joint within 1e-3 px /
+                    1e-3 mm of the exact cascade's
+      split         (everything on the fast kernels) is NOT held to integer identity: near-ties among ~5000 seeded-random proposal
+                    scores flip under ANY float32 reordering; it is held to the margin-aware set relation above, and what it does
+                    here is measured and printed (bench.py reports the same figures per run)."""
+    from posepipeline_amd.tracking import person_bbox
+    n, chunk = 64, 16
+    frames = _clip_1080p_four_persons(n, np.random.default_rng(41))
+    spec = hrnet.hrnet_w48_384x288()
+    sds = (_det_sd(), synth.smooth_state_dict(hrnet.hrnet_param_shapes(spec), seed=11), _lift_sd(), spec)
+    cas_e, tr_e, k2_e, k3_e = _run_no_replay(ctx, frames, sds, chunk, numerics="exact")
+    assert cas_e.detector.net_a.numerics == "exact"
+    per_frame = [len(t) for t in tr_e]
+    followed = sorted(k2_e)
+    print(f"[exact] tracked boxes per frame {min(per_frame)} .. {max(per_frame)}, {len({r[0] for t in tr_e for r in t})} ids, followed {followed}")
+    assert min(per_frame) >= 4 and len(followed) >= 4
+    # (a) anchor: the oracle detector itself on one 1080p frame == what the exact device detector fed the tracker
+    model = odet.FasterRCNNRef(sds[0])
+    dets_dev = cas_e.detector.run(frames[37:38])[0]
+    assert np.array_equal(dets_dev, odet.detect(model, frames[37][:, :, ::-1]))
+    # (b) oracle tracker over the exact detections of EVERY frame: ids and rows identical to the product tracker's
+    ref_trk = SortTrackerRef()
+    dets_all = [d for i in range(0, n, chunk) for d in cas_e.detector.run(frames[i:i + chunk])]
+    assert np.array_equal(dets_all[37], dets_dev)
+    for t in range(n):
+        rows = ref_trk.step(np.asarray(dets_all[t], np.float32).reshape(-1, 5))
+        assert [r[0] for r in tr_e[t]] == [int(x[0]) for x in rows], t
+        assert np.array_equal(np.array([r[1:] for r in tr_e[t]], np.float32).reshape(-1, 5), np.asarray(rows, np.float32).reshape(-1, 6)[:, 1:]), t
+    # (c) the reference's PersonBbox logic on the table rows == what the streaming cascade followed
+    dicts = [[{"track_id": r[0], "tlhw": np.array([r[1], r[2], r[3] - r[1], r[4] - r[2]], np.float64)} for r in fr_] for fr_ in tr_e]
+    present_e = {}
+    for tid in followed:
+        bbox, present = person_bbox(dicts, [tid])
+        f2, a2 = k2_e[tid]
+        filled = np.flatnonzero(present)
+        assert f2 == filled[0]
+        for t in range(f2, f2 + len(a2)):
+            assert a2[t - f2].any() == bool(present[t]), (tid, t)
+        present_e[tid] = present
+    # ---- integer-exact: the fast pose / lifting kernels under an exact detector ----
+    cas_h, tr_h, k2_h, k3_h = _run_no_replay(ctx, frames, sds, chunk, numerics="split", id_numerics="exact")
+    assert cas_h.detector.net_a.numerics == "exact" and cas_h.pose_net.numerics == "split" and (cas_h.pose_net.conv_kinds() == 2).any()
+    assert tr_h == tr_e or all(np.array_equal(np.array(a, np.float32), np.array(b, np.float32)) for a, b in zip(tr_h, tr_e))
+    assert sorted(k2_h) == followed
+    worst2 = worst3 = 0.0
+    for tid in followed:
+        (f_e, a_e), (f_h, a_h) = k2_e[tid], k2_h[tid]
+        assert f_e == f_h and a_e.shape == a_h.shape
+        assert np.array_equal(a_e.any(axis=(1, 2)), a_h.any(axis=(1, 2)))           # `present`: the same zero rows
+        worst2 = max(worst2, float(np.abs(a_e[:, :, :2] - a_h[:, :, :2]).max()))
+        (g_e, b_e), (g_h, b_h) = k3_e[tid], k3_h[tid]
+        assert g_e == g_h and b_e.shape == b_h.shape
+        worst3 = max(worst3, float(np.abs(b_e - b_h).max()))
+    print(f"[integer-exact] ids / rows / present identical on {n} frames; 2D max {worst2:.2e} px, 3D max {worst3:.2e} m vs the exact cascade")
+    assert worst2 <= TOL_PX and worst3 <= TOL_M
+    # ---- split everywhere: measured, not asserted identical ----
+    cas_s, tr_s, k2_s, _ = _run_no_replay(ctx, frames, sds, chunk, numerics="split")
+    assert (cas_s.detector.net_a.conv_kinds() == 2).any()
+    same_ids = sum([r[0] for r in a] == [r[0] for r in b] for a, b in zip(tr_s, tr_e))
+    matched = total = 0
+    for a, b in zip(tr_s, tr_e):
+        total += len(b)
+        ba = np.array([r[1:5] for r in a], np.float32).reshape(-1, 4)
+        for r in b:
+            if len(ba) and np.abs(ba - np.array(r[1:5], np.float32)).max(axis=1).min() <= BOX_TOL["split"]:
+                matched += 1
+    print(f"[split] frames with the exact cascade's id list: {same_ids} / {n}; tracked boxes re-found within {BOX_TOL['split']} px: {matched} / {total}")
+    assert matched >= 0.9 * total

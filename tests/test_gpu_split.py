@@ -1,7 +1,8 @@
-"""The library's default convolution numerics: float32 convolutions on the bf16 matrix cores (conv_split.hip).
+"""The library's default convolution numerics: float32 convolutions on the bf16 / fp16 matrix cores (conv_split.hip).
 
-Every float32 operand is split exactly into three bfloat16 values and six of the nine partial products are accumulated in
-float32; the dropped terms are <= 2^-23 of a product.  The result is NOT bit-identical to oracle/conv_ref.c (the other GPU
+Two forms.  bf16: every float32 operand is split exactly into three bfloat16 values and six of the nine partial products are
+accumulated in float32; the dropped terms are <= 2^-23 of a product.  fp16 (round 5, the default): two float16 terms per operand
+(22 significand bits under per-channel / per-sample power-of-two scales), three products.  The result is NOT bit-identical to oracle/conv_ref.c (the other GPU
 tests pin the float32-MFMA kernels to it bit for bit), so this file states what the default path guarantees instead:
   * per layer, the error against a float64 convolution is that of the float32 FMA chain (not larger than 1.25x);
   * whole networks agree with the bit-exact kernels to ~3e-6 of the output range;
@@ -27,11 +28,14 @@ TOL_PX = 1e-3        # north_star: 2D joints within 1e-3 px
 TOL_MM = 1e-3        # 3D joints within 1e-3 mm (VideoPose3D works in metres: 1e-6)
 
 
-@pytest.fixture
-def lib(ctx):
+@pytest.fixture(params=["f16", "bf16"])
+def lib(ctx, request):
     """the tests below switch the process-wide DEFAULT numerics (pp_conv_exact) around the creation of their nets / their
-    single-op calls; a net keeps what it was created with"""
+    single-op calls; a net keeps what it was created with.  Every test runs on BOTH split forms (pp_conv_split_kind): two float16
+    terms / three products (the default since round 5) and three bfloat16 terms / six products"""
+    L.check(ctx.lib.pp_conv_split_kind(1 if request.param == "f16" else 0), "pp_conv_split_kind")
     yield ctx.lib
+    L.check(ctx.lib.pp_conv_split_kind(-1), "pp_conv_split_kind")
     L.check(ctx.lib.pp_conv_exact(1), "pp_conv_exact")
 
 
@@ -546,12 +550,12 @@ def test_product_kernel_epilogues_agree_bit_for_bit(ctx, lib, monkeypatch):
 
     def run(fn):
         out = []
-        for epi in ("0", "1"):
-            monkeypatch.setenv("POSEPIPE_SPLIT_GEMM_EPI", epi)
+        for epi in (0, 1):
+            L.check(lib.pp_debug_knob(b"split_gemm_epilogue", epi), "pp_debug_knob")
             L.check(lib.pp_conv_exact(0), "pp_conv_exact")
             out.append(fn())
         L.check(lib.pp_conv_exact(1), "pp_conv_exact")
-        monkeypatch.delenv("POSEPIPE_SPLIT_GEMM_EPI")
+        L.check(lib.pp_debug_knob(b"split_gemm_epilogue", -1), "pp_debug_knob")
         assert np.isfinite(out[0]).all() and np.abs(out[0]).max() > 0
         assert np.array_equal(out[0], out[1])
 
@@ -587,3 +591,100 @@ def test_product_kernel_epilogues_agree_bit_for_bit(ctx, lib, monkeypatch):
         net.close()
         return y
     run(net_run)
+
+
+# ---- fp16 form (round 5): the activation scale follows the data, per sample ------------------------------------------------------
+@pytest.fixture
+def lib16(ctx):
+    L.check(ctx.lib.pp_conv_split_kind(1), "pp_conv_split_kind")
+    yield ctx.lib
+    L.check(ctx.lib.pp_conv_split_kind(-1), "pp_conv_split_kind")
+    L.check(ctx.lib.pp_conv_exact(1), "pp_conv_exact")
+
+
+# (n, h, w, cin, cout, k, stride): tap kernel (tile / stream), 48-channel form, 8-wave form, one-tap product, product kernel, tap-gather
+CASES_F16 = [(2, 24, 18, 64, 64, 3, 1), (3, 24, 18, 48, 48, 3, 1), (1, 40, 68, 256, 256, 3, 1), (8, 96, 96, 256, 256, 3, 1),
+             (2, 12, 20, 1024, 96, 1, 2), (2, 40, 68, 256, 1024, 1, 1), (2, 40, 68, 128, 128, 3, 2)]
+MAGNITUDES = [1e-30, 1e-6, 1.0, 3e3, 1e7]
+
+
+@pytest.mark.parametrize("case", CASES_F16)
+def test_f16_form_keeps_the_yardstick_at_any_magnitude(ctx, lib16, case):
+    """the fp32 yardstick (error against a float64 convolution <= the float32 kernel's, x 1.25 on the rms) with
+    inputs from 1e-30 to 1e7 -- far below float16's smallest normal and far above its largest value -- and with every SAMPLE of a
+    batch at its own magnitude (1e-6 .. 1e4): the scale is taken per sample from the tensor's running maximum, nothing saturates
+    and nothing underflows.  Weights: per-channel ranges over ~8 orders of magnitude (BatchNorm-folded kernels)."""
+    n, h, w, cin, cout, k, stride = case
+    rng = np.random.default_rng(sum(case) + 3)
+    wt = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+    wt *= np.exp(3 * rng.standard_normal((cout, 1, 1, 1))).astype(np.float32)
+    pad = k // 2
+    mags = [np.full(n, m) for m in MAGNITUDES] + [10.0 ** np.linspace(-6, 4, n)]
+    for mag in mags:
+        x = (rng.standard_normal((n, h, w, cin)) * np.exp(rng.standard_normal((n, h, w, cin))) * mag.reshape(-1, 1, 1, 1)).astype(np.float32)
+        b = (rng.standard_normal(cout) * np.abs(x).mean()).astype(np.float32)
+        ref = conv64(x, wt, b, pad, stride)
+        exact, split = both(lib16, lambda: hip_conv_op(ctx, x, wt, b, stride=stride, pad=(pad, pad)))
+        assert np.isfinite(split).all() and not np.array_equal(exact, split)
+        # per sample and per output channel (their ranges differ by orders of magnitude)
+        scale = np.abs(ref).reshape(n, -1, cout).max(1).reshape(n, 1, 1, cout) + 1e-300
+        rms = lambda y: float(np.sqrt(np.mean(((y - ref) / scale) ** 2)))
+        assert rms(split) <= 1.25 * rms(exact) + 1e-9, (mag[0], rms(split), rms(exact))
+        assert np.abs((split - ref) / scale).max() <= 1.5 * np.abs((exact - ref) / scale).max() + 1e-7
+
+
+def _chain_program(rng, c=64, h=20, w=12):
+    """3x3 -> 1x1 (product kernel, 128 output channels) -> 3x3 stride 2 -> 3x3 with a residual: every tracked-maximum path of a
+    program (fused epilogues of the tap / product kernels, zero-halo buffers, an external input)"""
+    pb = ProgramBuilder()
+    x = pb.buf(h, w, c, name="input")
+    mk = lambda co, ci, k: ((rng.standard_normal((co, ci, k, k)) / np.sqrt(ci * k * k)).astype(np.float32), (0.1 * rng.standard_normal(co)).astype(np.float32))
+    w1, b1 = mk(128, c, 3)
+    w2, b2 = mk(128, 128, 1)
+    w3, b3 = mk(128, 128, 3)
+    w4, b4 = mk(128, 128, 3)
+    y1 = pb.conv(x, w1, b1, pad=1, relu=L.PP_RELU_LAST)
+    y2 = pb.conv(y1, w2, b2, pad=0, relu=L.PP_RELU_LAST, res1=y1)
+    y3 = pb.conv(y2, w3, b3, pad=1, stride=2, relu=L.PP_RELU_LAST)
+    pb.conv(y3, w4, b4, pad=1, relu=L.PP_RELU_LAST, res1=y3, out=pb.buf(h // 2, w // 2, 128, name="output"))
+    return pb.build()
+
+
+def test_f16_form_results_do_not_depend_on_the_batch(ctx, lib16, monkeypatch):
+    """A sample's result is the same BITS whatever else is in the batch (the scale is per sample, the running maxima are per
+    sample): six samples whose magnitudes spread over 1e-8 .. 1e8 run together, alone, and in reversed order.  (What
+    tests/test_gpu_sharded.py relies on when it compares shards with the whole clip.)"""
+    monkeypatch.setenv("POSEPIPE_SPLIT_S2_MIN_CIN", "16")
+    rng = np.random.default_rng(77)
+    prog = _chain_program(rng)
+    x = (rng.standard_normal((6, 20, 12, 64)) * (10.0 ** np.linspace(-8, 8, 6)).reshape(-1, 1, 1, 1)).astype(np.float32)
+    net = Net(ctx, prog, max_batch=6, numerics="split_f16")
+    assert (net.conv_kinds() == 2).all() and net.split_kind == "split_f16"
+    together = net.forward(x)
+    assert np.isfinite(together).all()
+    for i in range(6):
+        assert np.array_equal(net.forward(x[i:i + 1])[0], together[i]), i
+    assert np.array_equal(net.forward(x[::-1].copy())[::-1], together)
+    # ... and close to the float32 kernels at every magnitude
+    exact = Net(ctx, prog, max_batch=6, numerics="exact").forward(x)
+    for i in range(6):
+        assert np.abs(together[i] - exact[i]).max() <= 1e-5 * np.abs(exact[i]).max(), i
+
+
+def test_f16_form_non_finite_input_stays_in_its_sample(ctx, lib16, monkeypatch):
+    """inf / NaN in one sample: that sample's outputs are unspecified (an infinite maximum collapses its scale, and fmaxf-style ReLUs
+    swallow NaNs on either kernel family); every OTHER sample of the batch is untouched, bit for bit"""
+    monkeypatch.setenv("POSEPIPE_SPLIT_S2_MIN_CIN", "16")
+    rng = np.random.default_rng(78)
+    prog = _chain_program(rng)
+    x = rng.standard_normal((4, 20, 12, 64)).astype(np.float32)
+    net = Net(ctx, prog, max_batch=4, numerics="split_f16")
+    clean = net.forward(x)
+    bad = x.copy()
+    bad[1, 3, 4, 5] = np.inf
+    bad[2, 7, 2, 9] = np.nan
+    out = net.forward(bad)
+    for i in (0, 3):
+        assert np.array_equal(out[i], clean[i])
+    # the maxima are reset per run: the next clean run is clean again
+    assert np.array_equal(net.forward(x), clean)
