@@ -214,6 +214,12 @@ int pp_net_split_kind(pp_net* net);
 void pp_net_destroy(pp_net* net);
 /* device address of activation buffer `buf` (batch-major, then the pp_buf layout) */
 int pp_net_buffer(pp_net* net, int buf, void** dptr, size_t* bytes_per_sample);
+/* fp16-form programs scale every convolution input per sample by a power of two taken from the running maximum of the tensor
+ * (pp_conv_split_kind).  For tensors produced inside the program the producing kernels track it; for a program INPUT the run takes
+ * one extra pass over the buffer -- unless the caller's own producer supplies the maxima: *dptr receives the device array
+ * (max_batch uint32: the bit pattern of max |x| over sample n, any upper bound >= it is valid) the caller must then fill before
+ * every pp_net_run, or NULL when no fp16-form convolution reads `buf` (nothing to do).  (The detector's RoIAlign does this.) */
+int pp_net_input_amax(pp_net* net, int buf, void** dptr);
 /* run ops [first, last) for `batch` samples (last < 0: to the end); inputs must already be in their buffers */
 int pp_net_run(pp_net* net, int batch, int first_op, int last_op);
 /* convenience: copy `in` into buffer in_buf, run everything, copy buffer out_buf to `out` */

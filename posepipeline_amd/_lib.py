@@ -127,6 +127,7 @@ SIGNATURES = {
     "pp_detector_input_size": (_i, [_i, _i] + [C.POINTER(C.c_int32)] * 4),
     "pp_detector_constants": (_i, [C.POINTER(C.c_double), _i]),
     "pp_debug_knob": (_i, [C.c_char_p, _i]),
+    "pp_net_input_amax": (_i, [_vp, _i, C.POINTER(_vp)]),
     "pp_rescale_size": (_i, [_i, _i, _i, _i, _i] + [C.POINTER(C.c_int32)] * 4),
     "pp_resize_pad_normalize": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp]),
     "pp_detector_create": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, C.POINTER(_vp)]),

@@ -1,4 +1,6 @@
 // Context, memory helpers, layer-program executor (pp_net_*) and the single-conv entry point.
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <memory>
 
@@ -17,6 +19,34 @@ void pp_set_error(const char* fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_last_error = buf;
+}
+
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void* h = dlopen(lib, RTLD_LAZY | RTLD_LOCAL);
+            if (!h) continue;
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+const Roctx& roctx() {
+    static const Roctx r;
+    return r;
+}
+}  // namespace
+
+void pp_range_push(const char* name) {
+    if (roctx().push) (void)roctx().push(name);
+}
+void pp_range_pop() {
+    if (roctx().pop) (void)roctx().pop();
 }
 
 int pp_ctx::ensure_scratch(size_t bytes) {
@@ -240,10 +270,13 @@ struct pp_net {
     // fp16 form (pp_amax.h): per-sample running maxima of the tensors its convolutions read, [slot][max_batch] bit patterns.  A slot
     // belongs to ONE tensor of the program (a buffer between two overwrites); it is raised by the fused epilogues of the tensor's
     // producers (op_y_slot) or, where a producer has none, by a stand-alone pass after the last of them (op_post_slot); tensors that
-    // come from outside the program get a pass in front of the reading op (op_pre_slot).  Slots are numbered in op order, so the
-    // slots a run of ops [first, last) has to zero are one contiguous range (slot_owner = the first op that raises the slot).
+    // come from outside the program (`ext`) get one pass at the start of the run, unless their producer supplies the maxima itself
+    // (pp_net_input_amax).  Tensor slots are numbered in op order, so the slots a run of ops [first, last) has to zero are one
+    // contiguous range (slot_owner = the first op that raises the slot).
     unsigned* amax = nullptr;
-    std::vector<int> op_x_slot, op_y_slot, op_pre_slot, op_post_slot, slot_owner;
+    std::vector<int> op_x_slot, op_y_slot, op_post_slot, slot_owner;
+    struct ExtAmax { int buf, slot, first_reader, last_reader; bool provided; };
+    std::vector<ExtAmax> ext;      // tensors from outside the program that fp16-form convolutions read
     float* arena = nullptr;
     size_t arena_floats = 0;
     int max_batch = 0;
@@ -274,9 +307,9 @@ static void net_plan_amax(pp_net* net) {
     const int n = (int)net->ops.size(), nb = (int)net->bufs.size();
     net->op_x_slot.assign(n, -1);
     net->op_y_slot.assign(n, -1);
-    net->op_pre_slot.assign(n, -1);
     net->op_post_slot.assign(n, -1);
     net->slot_owner.clear();
+    net->ext.clear();
     if (net->numerics != PP_NET_NUMERICS_SPLIT || !net->split_f16) return;
     auto is_h = [&](int i) { return net->ops[i].type == PP_OP_CONV && net->wsplit_off[i] >= 0; };
     // producers with a fused maximum: convolutions (pp_conv_tracks_amax) and PP_OP_UPSAMPLE_ADD
@@ -285,6 +318,28 @@ static void net_plan_amax(pp_net* net) {
         if (op.type == PP_OP_UPSAMPLE_ADD) return true;
         return op.type == PP_OP_CONV && pp_conv_tracks_amax(net_conv_args(net, op, 1), is_h(i));
     };
+    // pass 1: buffers a fp16-form convolution reads BEFORE any op of the program has written them = tensors from outside (the
+    // program's inputs).  One slot per buffer, numbered first; filled by one stand-alone pass at the start of a run that
+    // contains a reader -- or by the caller's own producer (pp_net_input_amax: the detector's RoIAlign)
+    {
+        std::vector<char> written(nb, 0);
+        for (int i = 0; i < n; ++i) {
+            const pp_op& op = net->ops[i];
+            if (is_h(i) && !written[op.in]) {
+                pp_net::ExtAmax* e = nullptr;
+                for (auto& x : net->ext)
+                    if (x.buf == op.in) e = &x;
+                if (!e) {
+                    net->ext.push_back({op.in, (int)net->slot_owner.size(), i, i, false});
+                    net->slot_owner.push_back(-1);    // (never part of the zeroed range: handled per run, below)
+                    e = &net->ext.back();
+                }
+                e->last_reader = i;
+                net->op_x_slot[i] = e->slot;
+            }
+            written[op.out] = 1;
+        }
+    }
     struct Tensor { int slot; std::vector<int> producers; bool wanted; };
     std::vector<Tensor> tensors;
     std::vector<int> cur(nb, -1);                 // tensor currently held by buffer b (-1: written outside the program)
@@ -292,14 +347,9 @@ static void net_plan_amax(pp_net* net) {
     std::vector<std::pair<int, int>> readers;     // (H conv, tensor)
     for (int i = 0; i < n; ++i) {
         const pp_op& op = net->ops[i];
-        if (is_h(i)) {
-            if (cur[op.in] < 0) {
-                net->op_pre_slot[i] = net->op_x_slot[i] = (int)net->slot_owner.size();
-                net->slot_owner.push_back(i);
-            } else {
-                tensors[cur[op.in]].wanted = true;
-                readers.push_back({i, cur[op.in]});
-            }
+        if (is_h(i) && cur[op.in] >= 0) {
+            tensors[cur[op.in]].wanted = true;
+            readers.push_back({i, cur[op.in]});
         }
         for (int b : {op.in, op.res1, op.res2, op.in2, op.in3})
             if (b >= 0) read_since[b] = 1;
@@ -325,8 +375,8 @@ static void net_plan_amax(pp_net* net) {
     for (const auto& r : readers) net->op_x_slot[r.first] = tensors[r.second].slot;
 }
 
-// zero the maxima that ops [first, last) raise (on `s`, ahead of them)
-static int net_reset_amax(pp_net* net, int first, int last, hipStream_t s) {
+// ahead of ops [first, last) on `s`: zero the maxima they raise, and take the maxima of the outside tensors they read
+static int net_reset_amax(pp_net* net, int first, int last, int batch, hipStream_t s) {
     if (!net->amax) return PP_OK;
     int s0 = -1, s1 = -1;
     for (int k = 0; k < (int)net->slot_owner.size(); ++k)
@@ -335,6 +385,12 @@ static int net_reset_amax(pp_net* net, int first, int last, hipStream_t s) {
             s1 = k + 1;
         }
     if (s0 >= 0) PP_HIP_CHECK(hipMemsetAsync(net->amax_slot(s0), 0, (size_t)(s1 - s0) * net->max_batch * sizeof(unsigned), s));
+    for (const auto& e : net->ext) {
+        if (e.provided || e.last_reader < first || e.first_reader >= last) continue;
+        PP_HIP_CHECK(hipMemsetAsync(net->amax_slot(e.slot), 0, (size_t)batch * sizeof(unsigned), s));
+        int rc = pp_launch_amax(net->buf_ptr(e.buf), batch, net->buf_elems[e.buf], net->amax_slot(e.slot), s);
+        if (rc != PP_OK) return rc;
+    }
     return PP_OK;
 }
 
@@ -516,10 +572,6 @@ static int net_launch_op_body(pp_net* net, const pp_op& op, int batch, hipStream
 
 static int net_launch_op(pp_net* net, const pp_op& op, int batch, hipStream_t s) {
     const size_t idx = &op - net->ops.data();
-    if (net->amax && net->op_pre_slot[idx] >= 0) {
-        int rc = pp_launch_amax(net->buf_ptr(op.in), batch, net->buf_elems[op.in], net->amax_slot(net->op_pre_slot[idx]), s);
-        if (rc != PP_OK) return rc;
-    }
     int rc = net_launch_op_body(net, op, batch, s);
     if (rc == PP_OK && net->amax && net->op_post_slot[idx] >= 0)
         rc = pp_launch_amax(net->buf_ptr(op.out), batch, net->buf_elems[op.out], net->amax_slot(net->op_post_slot[idx]), s);
@@ -701,6 +753,17 @@ int pp_net_create_ex(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* buf
     return PP_OK;
 }
 
+int pp_net_input_amax(pp_net* net, int buf, void** dptr) {
+    PP_REQUIRE(net && dptr && buf >= 0 && buf < (int)net->bufs.size(), "pp_net_input_amax: bad argument");
+    *dptr = nullptr;
+    for (auto& e : net->ext)
+        if (e.buf == buf && net->amax) {
+            e.provided = true;
+            *dptr = net->amax_slot(e.slot);
+        }
+    return PP_OK;
+}
+
 int pp_net_conv_kinds(pp_net* net, int* kinds) {
     PP_REQUIRE(net && kinds, "pp_net_conv_kinds: NULL argument");
     for (size_t i = 0; i < net->ops.size(); ++i) {
@@ -753,8 +816,9 @@ int pp_net_run(pp_net* net, int batch, int first_op, int last_op) {
         return PP_OK;
     }
     hipStream_t main = net->ctx->stream;
+    PpRange range("pp_net_run");
     {
-        int rc = net_reset_amax(net, first_op, last_op, main);
+        int rc = net_reset_amax(net, first_op, last_op, batch, main);
         if (rc != PP_OK) return rc;
     }
     if (net->lanes.empty() || !net->use_lanes || last_op - first_op < 8) {
@@ -817,7 +881,7 @@ int pp_net_capture(pp_net* net, int batch) {
     PP_HIP_CHECK(hipStreamSynchronize(s));
     hipGraph_t graph = nullptr;
     PP_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    int rc = net_reset_amax(net, 0, (int)net->ops.size(), s);
+    int rc = net_reset_amax(net, 0, (int)net->ops.size(), batch, s);
     for (size_t i = 0; i < net->ops.size() && rc == PP_OK; ++i) rc = net_launch_op(net, net->ops[i], batch, s);
     hipError_t e = hipStreamEndCapture(s, &graph);
     if (rc != PP_OK) {
@@ -855,7 +919,7 @@ int pp_net_profile(pp_net* net, int batch, float* ms_per_op) {
     const size_t n = net->ops.size();
     std::vector<hipEvent_t> ev(n + 1);
     for (auto& e : ev) PP_HIP_CHECK(hipEventCreate(&e));
-    int rc = net_reset_amax(net, 0, (int)n, s);
+    int rc = net_reset_amax(net, 0, (int)n, batch, s);
     PP_HIP_CHECK(hipEventRecord(ev[0], s));
     for (size_t i = 0; i < n && rc == PP_OK; ++i) {
         rc = net_launch_op(net, net->ops[i], batch, s);

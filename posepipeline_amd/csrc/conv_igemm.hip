@@ -684,6 +684,10 @@ extern "C" int pp_conv_exact(int exact) {
 
 // (the float32 kernels' condition is the one their "common case" epilogue tests)
 bool pp_conv_tracks_amax(const ConvArgs& a, bool split) {
+    // samples of a few pixels (the RoI head's FC layers: ONE pixel per sample): a workgroup's 256 pixels span hundreds of samples, the
+    // fused epilogue would issue an atomic per pixel and channel block (measured: fc6 at 64 000 RoIs 5.3 -> 8.4 ms) where a pass over
+    // the small output costs 0.1 ms
+    if (a.HWout < 64) return false;
     if (split) return true;
     const int Ho2 = a.Hout << a.up_log2, Wo2 = a.Wout << a.up_log2;
     const bool res1_plain = a.res1_shift == 0 && a.res1_off_w == 0 && a.res1_H == Ho2 && a.res1_W == Wo2;

@@ -184,25 +184,26 @@ __device__ __forceinline__ void split4(const float4 v, uint2& p0, uint2& p1, uin
 // ---- fp16 form (round 5): two-term operand split, THREE products per term ------------------------------------------------------
 // The six-product form's ceiling is 2500 / 6 = 417 TFLOP/s fp32-equivalent, and two rounds of tuning put the kernels at 0.46 of it
 // with the long-K layers at the chip's power limit.  float16 carries 11 significand bits: two terms carry 22,
-//     x s = h0 + 2^-11 h1,   h0 = f16(x s),  h1 = f16((x s - h0) 2^11)       (s: power-of-two scale of the tensor, exact)
-//     w c = g0 + g1,         g0 = f16(w c),  g1 = f16(w c - g0),  g2 = f16(2^-11 g0)   (c: power of two PER OUTPUT CHANNEL)
-//     (x s)(w c) ~ h0 g0 + h0 g1 + h1 g2                                      (dropped: h1 g1 2^-11 ~ 2^-22 |x w|, random sign)
-// -- three v_mfma_f32_32x32x16_f16 (same rate as bf16) into ONE float32 accumulator set; the epilogue multiplies by 1 / (s c)
-// (exact) inside the bias add's fma.  Representation error: |x s - h0 - 2^-11 h1| <= 2^-22 |x s| wherever h0 is a normal float16
-// (|x s| >= 2^-14), and <= 2^-36 absolutely below (h1 is scaled by 2^11 so that it stays normal down to there); weights are
-// normalised per channel to max |w c| in [2^14, 2^15), so |w c - g0 - g1| <= 2^-22 |w c| down to 2^-18 of the channel's largest weight
-// and <= 2^-25 (2^-40 of the largest) below -- no weight tensor can leave the format's range.  Per product that is ~2^-23.7 rms with
+//     x s = h0 + h1,   h0 = f16(x s),  h1 = f16(x s - h0)     (s: power of two PER SAMPLE, max |x| s in [2^14, 2^15), exact)
+//     w c = g0 + g1,   g0 = f16(w c),  g1 = f16(w c - g0)     (c: power of two PER OUTPUT CHANNEL, max |w| c in [2^14, 2^15))
+//     (x s)(w c) ~ h0 g0 + h1 g0 + h0 g1                      (dropped: h1 g1 ~ 2^-22 |x w|, random sign)
+// -- three v_mfma_f32_32x32x16_f16 (same rate as bf16) into ONE float32 accumulator set, TWO planes per operand (the weight planes
+// are a third smaller than the bf16 form's: LDS reads per tap 10 -> 8, weight bytes through L2 / the DMA ring -33 %); the epilogue
+// multiplies by 1 / (s c) (exact) inside the bias add's fma.  Representation error: |x s - h0 - h1| <= 2^-22 |x s| wherever the
+// residual is a normal float16 (|x s| >= 2^-2, i.e. down to 2^-17 of the sample's maximum) and <= 2^-25 absolutely = 2^-39 of the
+// sample's maximum below that -- far under what ONE float32 rounding of the running sum costs (2^-24 of the sum); the weights
+// likewise per channel.  Per product that is ~2^-23.7 rms with
 // random sign against the ~2^-24 EVERY step of a float32 FMA chain commits on the running sum: over K >= 144 terms the chain's own
 // rounding dominates (tests/test_gpu_split.py holds the same yardstick as for the six-product form: error against float64 <= the
 // float32 kernel's).  Range of activations: s = 2^k is chosen PER SAMPLE from the running maximum of the tensor (pp_amax.h: the kernel
 // that stores a tensor folds max |v| into amax[sample]; max |x| s lies in [2^14, 2^15)), so nothing can leave the format upwards,
-// values down to 2^-29 of the sample's maximum keep their 22 bits and smaller ones are off by <= 2^-51 of it -- whatever the
+// values down to 2^-17 of the sample's maximum keep their 22 bits and smaller ones are off by <= 2^-39 of it -- whatever the
 // magnitude of the data (1e-30 .. 1e30 alike).  Non-finite inputs stay non-finite (inf s = inf in float16, NaN stays NaN).
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 __device__ __forceinline__ void split4h(const float4 v, const float s, uint2& p0, uint2& p1) {
     const f32x2_t a = f32x2_t{v.x, v.y} * s, b = f32x2_t{v.z, v.w} * s;
     const f16x2_t a0 = __builtin_convertvector(a, f16x2_t), b0 = __builtin_convertvector(b, f16x2_t);
-    const f32x2_t ra = (a - __builtin_convertvector(a0, f32x2_t)) * 2048.f, rb = (b - __builtin_convertvector(b0, f32x2_t)) * 2048.f;   // exact
+    const f32x2_t ra = a - __builtin_convertvector(a0, f32x2_t), rb = b - __builtin_convertvector(b0, f32x2_t);   // exact
     const f16x2_t a1 = __builtin_convertvector(ra, f16x2_t), b1 = __builtin_convertvector(rb, f16x2_t);
     p0 = make_uint2(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, b0));
     p1 = make_uint2(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1));
@@ -285,6 +286,7 @@ template <int T, int NSLOT, int COB, int PXB = 2, int NW = 4, bool RING4 = false
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(SplitArgs a) {
     constexpr int NT = 64 * NW;
     constexpr int XP = H ? 2 : 3;                     // activation planes
+    constexpr int WPL = H ? 2 : 3;                    // weight planes (H: g0, g1 -- the third product reuses g0)
     constexpr bool WLDS = NW == 8 || RING4;
     static_assert(!RING4 || (NW == 4 && T == 9), "RING4 is the 4-wave 3x3 form");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -423,34 +425,34 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     };
     // ---- the first requests: weights of the first steps (DMA ring) / first step (registers), patch of chunk 0 -----------------
     PP_TL_MARK(4);
-    constexpr int WSLOT = COB * 3 * 1024;
-    constexpr int NDMA = (COB * 3 + NW - 1) / NW;  // 1 KB fragments each wave copies per step (8 waves: 1; 4 waves: 2 / 1 for COB 2 / 1)
+    constexpr int WSLOT = COB * WPL * 1024;
+    constexpr int NDMA = (COB * WPL + NW - 1) / NW;  // 1 KB fragments each wave copies per step (8 waves: 1; 4 waves: 2 / 1 for COB 2 / 1)
     const unsigned wring = (unsigned)((RING4 ? 1 : 2) * buf_bytes);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int nsteps = a.nchunks * T;
-    const size_t wstep = (size_t)a.ncb * 3 * 64;       // uint4 per step
+    const size_t wstep = (size_t)a.ncb * WPL * 64;       // uint4 per step
     // step s = chunk * T + tap.  Ring slot s & 3 holds the COB x 3 fragments of step s.
     auto issue_w = [&](int step) {
         if (step >= nsteps) return;
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
-            const int myslab = (wave + NW * i) % (COB * 3);      // (waves past COB * 3 copy a duplicate: same bytes, same place)
+            const int myslab = (wave + NW * i) % (COB * WPL);      // (waves past COB * 3 copy a duplicate: same bytes, same place)
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + wring + (unsigned)((step & 3) * WSLOT + myslab * 1024));
-            const uint4* g = a.w + (size_t)cb0 * 192 + myslab * 64 + lane + (size_t)step * wstep;
+            const uint4* g = a.w + (size_t)cb0 * (WPL * 64) + myslab * 64 + lane + (size_t)step * wstep;
             // raw instruction, see conv_split_gemm_kernel: the builtin makes the compiler order every later ds_read behind vmcnt(0)
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory", "m0");
         }
     };
     // weights: fragment (step, channel block cb, plane) at ((step * ncb + cb) * 3 + plane) * 64 + lane, step = chunk * T + tap
-    const uint4* wlane = a.w + (size_t)cb0 * 3 * 64 + lane;
-    uint4 wf[2][COB][3];
+    const uint4* wlane = a.w + (size_t)cb0 * WPL * 64 + lane;
+    uint4 wf[2][COB][WPL];
     uint4 xf[PXB][XP];
     const uint4* wp = wlane;                           // weights of the next step to fetch (one spare step at the end of the buffer)
-    auto load_w = [&](uint4 (&dst)[COB][3]) {
+    auto load_w = [&](uint4 (&dst)[COB][WPL]) {
 #pragma unroll
         for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) dst[cb][pl] = wp[(cb * 3 + pl) * 64];
+            for (int pl = 0; pl < WPL; ++pl) dst[cb][pl] = wp[(cb * WPL + pl) * 64];
         wp += wstep;
     };
     if constexpr (WLDS) {
@@ -547,9 +549,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
 
     // the six products with i + j <= 2 (smallest terms first) of one pixel block against every channel block; consecutive MFMAs
     // go to different accumulators (no back-to-back dependency on the matrix pipe)
-    auto mma = [&](const uint4 (&wc)[COB][3], int pb) {
-        if constexpr (H) {       // g2 h1 + g1 h0 + g0 h0
-            constexpr int WI[3] = {2, 1, 0}, XI[3] = {1, 0, 0};
+    auto mma = [&](const uint4 (&wc)[COB][WPL], int pb) {
+        if constexpr (H) {       // g1 h0 + g0 h1 + g0 h0
+            constexpr int WI[3] = {1, 0, 0}, XI[3] = {0, 1, 0};
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -573,12 +575,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         // s + 1 are read into the other register set (they landed before the barrier that ended step s - 1), the DMA of step
         // s + 3 is issued into the slot step s - 1 used, and before the closing barrier the DMA of step s + 2 is awaited -- by
         // counting: vmcnt is in issue order, so "all but the DMA of s + 3 and the patch loads issued after it" have landed.
-        auto read_w = [&](int step, uint4 (&dst)[COB][3]) {
+        auto read_w = [&](int step, uint4 (&dst)[COB][WPL]) {
             const unsigned char* base = smem + wring + (step & 3) * WSLOT + lane * 16;
 #pragma unroll
             for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) dst[cb][pl] = *reinterpret_cast<const uint4*>(base + (cb * 3 + pl) * 1024);
+                for (int pl = 0; pl < WPL; ++pl) dst[cb][pl] = *reinterpret_cast<const uint4*>(base + (cb * WPL + pl) * 1024);
         };
         // allow `n` (0, NDMA, NSLOT, NSLOT + NDMA) of the youngest vector-memory operations to stay in flight
         auto wait_all_but = [&](int n) {
@@ -889,6 +891,7 @@ template <int NSLOT, bool H = false>
 __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
     constexpr int NT = 256, NPAIR = 5, CB = 3, SB = 4;
     constexpr int XP = H ? 2 : 3;                     // activation planes (H: the fp16 form, see conv_split_kernel)
+    constexpr int WPL = H ? 2 : 3;                    // weight planes
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -971,14 +974,14 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
         }
     };
     // weights: fragment (step, block cb, plane) at ((step * ncb + cb) * 3 + plane) * 64 + lane, step = chunk * 5 + pair
-    const uint4* wp = a.w + (size_t)cbase * 3 * 64 + lane;
-    const size_t wstep = (size_t)a.ncb * 3 * 64;
-    uint4 wf[2][CB][3];
-    auto load_w = [&](uint4 (&dst)[CB][3]) {
+    const uint4* wp = a.w + (size_t)cbase * WPL * 64 + lane;
+    const size_t wstep = (size_t)a.ncb * WPL * 64;
+    uint4 wf[2][CB][WPL];
+    auto load_w = [&](uint4 (&dst)[CB][WPL]) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) dst[cb][pl] = wp[(cb * 3 + pl) * 64];
+            for (int pl = 0; pl < WPL; ++pl) dst[cb][pl] = wp[(cb * WPL + pl) * 64];
         wp += wstep;
     };
     // ---- the first requests ---------------------------------------------------------------------------------------------------------
@@ -1049,9 +1052,9 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
 #pragma unroll
         for (int pl = 0; pl < XP; ++pl) xf[sb & 1][pl] = *reinterpret_cast<const uint4*>(pbuf + pl * plane_bytes + aofs[sb] + tofs[q]);
     };
-    auto mma = [&](const uint4 (&wc)[CB][3], int sb) {
-        if constexpr (H) {       // g2 h1 + g1 h0 + g0 h0
-            constexpr int WI[3] = {2, 1, 0}, XI[3] = {1, 0, 0};
+    auto mma = [&](const uint4 (&wc)[CB][WPL], int sb) {
+        if constexpr (H) {       // g1 h0 + g0 h1 + g0 h0
+            constexpr int WI[3] = {1, 0, 0}, XI[3] = {0, 1, 0};
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -1201,8 +1204,8 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
     PP_TL_FLUSH();
 }
 
-// fp16 form: the three weight planes of one value under its channel's normalisation c = 2^e (g0 = f16(w c), g1 = f16(w c - g0),
-// g2 = f16(2^-11 g0)); cmax = max |w| of the output channel (0: an all-zero channel, c = 1)
+// fp16 form: the two weight planes of one value under its channel's normalisation c = 2^e (g0 = f16(w c), g1 = f16(w c - g0));
+// cmax = max |w| of the output channel (0: an all-zero channel, c = 1)
 __device__ __forceinline__ float channel_scale(float cmax) {
     if (!(cmax > 0.f) || !(cmax < 3.0e38f)) return 1.f;
     int e;
@@ -1214,10 +1217,9 @@ __device__ __forceinline__ void split_weight_h(float v, float c, unsigned short&
     const _Float16 g0 = (_Float16)vs;
     const float r = vs - (float)g0;            // exact
     const _Float16 g1 = (_Float16)r;
-    const _Float16 g2 = (_Float16)((float)g0 * (1.f / 2048.f));
     q0 = __builtin_bit_cast(unsigned short, g0);
     q1 = __builtin_bit_cast(unsigned short, g1);
-    q2 = __builtin_bit_cast(unsigned short, g2);
+    q2 = 0;                                    // (no third plane in this form)
 }
 // max |w| per output channel of a packed conv weight ([K / 32][CoutPad][32]); one wave per channel; also writes 1 / c
 __global__ __launch_bounds__(64) void weight_channel_max_kernel(const float* w, int kchunks, int CoutPad, int nout, float* cmax, float* inv_scale) {
@@ -1268,9 +1270,10 @@ __global__ __launch_bounds__(256) void split_weights48_kernel(const float* w, ui
         h[1][j] = __builtin_bit_cast(unsigned short, q1);
         h[2][j] = __builtin_bit_cast(unsigned short, q2);
     }
-    const size_t frag = (i >> 6) * 3;
+    constexpr int WPL = H ? 2 : 3;
+    const size_t frag = (i >> 6) * WPL;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < WPL; ++pl) {
         uint4 o;
         o.x = h[pl][0] | ((unsigned)h[pl][1] << 16);
         o.y = h[pl][2] | ((unsigned)h[pl][3] << 16);
@@ -1292,10 +1295,11 @@ __global__ __launch_bounds__(256) void split_weights48_kernel(const float* w, ui
 template <int WM, int WN, bool H = false>
 __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split_gemm_kernel(SplitArgs a) {
     constexpr int XP = H ? 2 : 3;                    // activation planes (H: the fp16 form, see conv_split_kernel)
+    constexpr int WPL = H ? 2 : 3;                   // weight planes
     constexpr int NT = 64 * WM * WN, NWAVE = WM * WN;
     constexpr int BM = 128 * WM, BN = 64 * WN;
     constexpr int XS = BM * 4 / NT;                  // float4 patch slots per thread and stage
-    constexpr int WU = BN * 6;                       // 16-byte units of split weights per stage: BN / 32 blocks x 3 planes x 64 lanes
+    constexpr int WU = BN * 2 * WPL;                 // 16-byte units of split weights per stage: BN / 32 blocks x WPL planes x 64 lanes
     constexpr int NPp = BM + 4;
     constexpr int XPLANE = 2 * NPp * 16;
     constexpr int XBYTES = XP * XPLANE, STAGE = XBYTES + WU * 16;
@@ -1335,7 +1339,7 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
     }
     const int woff0 = ((((tid & 3) >> 1) * NPp + (tid >> 2)) * 16 + (tid & 1) * 8);      // + (NT / 4) * 16 j: NT / 4 pixels further
     const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
-    const size_t wstep = (size_t)a.ncb * 192;
+    const size_t wstep = (size_t)a.ncb * (WPL * 64);
     float4 xr[XS];
     auto load_x = [&](int c) {
 #pragma unroll
@@ -1363,7 +1367,7 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
     constexpr int NSLAB = WU / 64;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     auto issue_w = [&](int c, int buf) {
-        const uint4* src = a.w + (size_t)c * wstep + (size_t)cbB * 192 + lane;
+        const uint4* src = a.w + (size_t)c * wstep + (size_t)cbB * (WPL * 64) + lane;
 #pragma unroll
         for (int i = 0; i < (NSLAB + NWAVE - 1) / NWAVE; ++i) {
             const int slab = i * NWAVE + wave;
@@ -1380,7 +1384,7 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
     };
 
     const int xofs = ((lane >> 5) * NPp + wm * 128 + (lane & 31)) * 16;                 // + plane * XPLANE + pb * 512
-    const int wofs = XBYTES + ((wn * 2) * 192 + lane) * 16;                             // + (cb * 3 + plane) * 1024
+    const int wofs = XBYTES + ((wn * 2) * (WPL * 64) + lane) * 16;                      // + (cb * WPL + plane) * 1024
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -1414,11 +1418,11 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
 
     for (int c = 0; c < a.nchunks; ++c) {
         const unsigned char* sb = smem + (c & 1) * STAGE;
-        uint4 wf[2][3], xf[2][XP];
+        uint4 wf[2][WPL], xf[2][XP];
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) wf[cb][pl] = *reinterpret_cast<const uint4*>(sb + wofs + (cb * 3 + pl) * 1024);
+            for (int pl = 0; pl < WPL; ++pl) wf[cb][pl] = *reinterpret_cast<const uint4*>(sb + wofs + (cb * WPL + pl) * 1024);
 #pragma unroll
         for (int pl = 0; pl < XP; ++pl) xf[0][pl] = *reinterpret_cast<const uint4*>(sb + xofs + pl * XPLANE);
 #pragma unroll
@@ -1436,8 +1440,8 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
                 issue_w(c + 1, (c + 1) & 1);
                 if (c + 2 < a.nchunks) load_x(c + 2);
             }
-            if constexpr (H) {       // g2 h1 + g1 h0 + g0 h0
-                constexpr int WI[3] = {2, 1, 0}, XI[3] = {1, 0, 0};
+            if constexpr (H) {       // g1 h0 + g0 h1 + g0 h0
+                constexpr int WI[3] = {1, 0, 0}, XI[3] = {0, 1, 0};
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
 #pragma unroll
@@ -1674,9 +1678,10 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const float* w, uint
         h[1][j] = __builtin_bit_cast(unsigned short, q1);
         h[2][j] = __builtin_bit_cast(unsigned short, q2);
     }
-    const size_t frag = (i >> 6) * 3;
+    constexpr int WPL = H ? 2 : 3;
+    const size_t frag = (i >> 6) * WPL;
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < WPL; ++pl) {
         uint4 o;
         o.x = h[pl][0] | ((unsigned)h[pl][1] << 16);
         o.y = h[pl][2] | ((unsigned)h[pl][3] << 16);
@@ -1805,12 +1810,13 @@ static bool split_c48(const ConvArgs& a) {
 }
 static int split_ncb16(const ConvArgs& a) { return (a.Cout + 47) / 48 * 3; }      // 16-channel blocks, whole columns of 3
 
-// bytes of the fragments (both forms: three planes) ...
+// bytes of the fragments ...
 static size_t split_frag_bytes(const ConvArgs& a, bool committed = false) {
     int taps = 1, cin = a.Cin, mode = 0;
     split_shape(a, &taps, &cin, &mode, committed);      // (committed: at launch the form is the one the split copy was built for)
-    if (split_c48(a)) return ((size_t)(cin / 16) * 5 + 1) * split_ncb16(a) * 3 * 64 * sizeof(uint4);
-    return ((size_t)(cin / 16) * taps + 1) * split_ncb(a) * 3 * 64 * sizeof(uint4);      // + one spare step: the kernel fetches one step ahead
+    const size_t wpl = a.split_f16 ? 2 : 3;              // weight planes: (g0, g1) of the fp16 form, three bf16 planes
+    if (split_c48(a)) return ((size_t)(cin / 16) * 5 + 1) * split_ncb16(a) * wpl * 64 * sizeof(uint4);
+    return ((size_t)(cin / 16) * taps + 1) * split_ncb(a) * wpl * 64 * sizeof(uint4);      // + one spare step: the kernel fetches one step ahead
 }
 // ... and, fp16 form, of what follows them: 1 / c per output channel, then max |w| per output channel
 static int split_nout(const ConvArgs& a) { return split_c48(a) ? split_ncb16(a) * 16 : split_ncb(a) * 32; }
@@ -1972,6 +1978,7 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     s.xcd_remap = a.xcd_remap;
     const bool f16 = a.split_f16 != 0;
     const int xp = f16 ? 2 : 3;              // activation planes in LDS
+    const int wpl = f16 ? 2 : 3;             // weight planes per fragment set
     s.wscale = f16 ? reinterpret_cast<const float*>(static_cast<const unsigned char*>(a.wsplit) + split_frag_bytes(a, true)) : nullptr;
     s.x_amax = a.x_amax;
     s.y_amax = a.y_amax;
@@ -2002,7 +2009,7 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         s.epi_lds = epi_knob >= 0 ? epi_knob : epi_env;
         const int nwave = 4;
         fill_divisors(s);
-        const size_t lds = std::max<size_t>((size_t)2 * (xp * 2 * (BM + 4) * 16 + BN * 6 * 16), s.epi_lds ? (size_t)nwave * (16384 + 2048) : 0);
+        const size_t lds = std::max<size_t>((size_t)2 * (xp * 2 * (BM + 4) * 16 + BN * 2 * wpl * 16), s.epi_lds ? (size_t)nwave * (16384 + 2048) : 0);
         static std::once_flag once;
         std::call_once(once, [] {
             (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
@@ -2100,8 +2107,8 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     }
     // 4 waves, 3x3: weights through the LDS ring with a single-buffered patch (RING4), two workgroups per CU
     static const int ring4_env = env_int("POSEPIPE_SPLIT_RING4", 1);
-    const bool ring4 = ring4_env && nw == 4 && mode != MODE_GEMM && (size_t)xp * 2 * s.NPp * 16 + (size_t)4 * cob * 3072 <= 80 * 1024;
-    const size_t lds = (size_t)(ring4 ? 1 : 2) * xp * 2 * s.NPp * 16 + ((nw == 8 || ring4) ? (size_t)4 * cob * 3072 : 0);
+    const bool ring4 = ring4_env && nw == 4 && mode != MODE_GEMM && (size_t)xp * 2 * s.NPp * 16 + (size_t)4 * cob * wpl * 1024 <= 80 * 1024;
+    const size_t lds = (size_t)(ring4 ? 1 : 2) * xp * 2 * s.NPp * 16 + ((nw == 8 || ring4) ? (size_t)4 * cob * wpl * 1024 : 0);
     fill_divisors(s);
 #define PP_SPLIT_LAUNCH_H(T_, NS_, NW_, R4_, H_)                                                                        \
     do {                                                                                                                \

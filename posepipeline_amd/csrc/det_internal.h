@@ -47,8 +47,10 @@ int det_enqueue_gather(hipStream_t s, const float* boxes, const float* scores, i
                        const int32_t* n_keep, int limit, float* out_box, float* out_score, int32_t* n_out, int out5,
                        int n_frames);
 // separable != 0: the default-numerics form (same samples, separable evaluation order); 0: the oracle's (iy, ix) order
+// amax (may be null; separable kernel only): per-RoI maxima for the RoI head's fp16-form input (pp_net_input_amax)
+bool det_roi_align_separable(int separable);
 int det_enqueue_roi_align(hipStream_t s, const DetFpnArgs& a, const float* rois, const int32_t* n_rois, int max_rois,
-                          float* out, int n_frames, int separable);
+                          float* out, int n_frames, int separable, unsigned* amax = nullptr);
 int det_enqueue_final_decode(hipStream_t s, const float* rois, const int32_t* n_rois, int max_rois, const float* cls,
                              const float* reg, float sfx, float sfy, float score_thr, float* boxes, float* scores,
                              int32_t* n_out, int n_frames);

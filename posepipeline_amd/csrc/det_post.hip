@@ -15,6 +15,7 @@
 // integer outputs (selected indices, kept boxes) are bit-exact and the float boxes equal.
 #include "pp_internal.h"
 #include "det_internal.h"
+#include "pp_amax.h"
 
 namespace {
 
@@ -436,8 +437,11 @@ __device__ __forceinline__ float4 fma4(float w, const float4 v, const float4 a) 
 
 constexpr int ROI_MAXW = 288;     // widest FPN map the table holds (level 0 of a 640 x 1088 input: 272 columns)
 
+// amax (may be null): per RoI, the bit pattern of max |out| -- what the RoI head's fp16-form fc6 scales its input by
+// (pp_net_input_amax; a wave owns its RoI, so the maximum is a plain store, no atomic and no zeroing)
 __global__ __launch_bounds__(256) void roi_align_sep_kernel(FpnLevels L, int C, const float* __restrict__ rois,
-                                                            const int32_t* __restrict__ n_rois, int max_rois, float* __restrict__ out) {
+                                                            const int32_t* __restrict__ n_rois, int max_rois, float* __restrict__ out,
+                                                            unsigned* __restrict__ amax) {
     __shared__ __attribute__((aligned(16))) float s_wx[4][ROI_MAXW][8];
     const int f = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -446,9 +450,16 @@ __global__ __launch_bounds__(256) void roi_align_sep_kernel(FpnLevels L, int C, 
     if (r >= max_rois) return;
     float* o = out + ((size_t)f * max_rois + r) * 49 * C + lane * 4;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float ymax = 0.f;
+    auto put_amax = [&]() {
+        if (!amax) return;
+        const float m = pp_wave_max(ymax);
+        if (lane == 0) amax[(size_t)f * max_rois + r] = __float_as_uint(m);
+    };
     if (r >= n_rois[f]) {
 #pragma unroll 7
         for (int b = 0; b < 49; ++b) *reinterpret_cast<float4*>(o + b * C) = zero4;
+        put_amax();
         return;
     }
     const float* roi = rois + ((size_t)f * max_rois + r) * 4;
@@ -479,12 +490,16 @@ __global__ __launch_bounds__(256) void roi_align_sep_kernel(FpnLevels L, int C, 
                         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                     }
                 }
-                *reinterpret_cast<float4*>(o + bin * C) = make_float4(acc.x / count, acc.y / count, acc.z / count, acc.w / count);
+                const float4 ov = make_float4(acc.x / count, acc.y / count, acc.z / count, acc.w / count);
+                *reinterpret_cast<float4*>(o + bin * C) = ov;
+                ymax = fmaxf(ymax, pp_abs4max(ov));
             }
+            put_amax();
             return;
         }
 #pragma unroll 7
         for (int b = 0; b < 49; ++b) *reinterpret_cast<float4*>(o + b * C) = zero4;        // no sample inside the map: mmcv's sum is 0
+        put_amax();
         return;
     }
     const int Xmin = __builtin_amdgcn_readfirstlane(min(max((int)floorf(fmaxf(xs_first, -1.0f)) - 1, 0), W - 1));
@@ -594,8 +609,12 @@ __global__ __launch_bounds__(256) void roi_align_sep_kernel(FpnLevels L, int C, 
             }
         }
 #pragma unroll
-        for (int pw = 0; pw < 7; ++pw) *reinterpret_cast<float4*>(o + (ph * 7 + pw) * C) = acc[pw];
+        for (int pw = 0; pw < 7; ++pw) {
+            *reinterpret_cast<float4*>(o + (ph * 7 + pw) * C) = acc[pw];
+            ymax = fmaxf(ymax, pp_abs4max(acc[pw]));
+        }
     }
+    put_amax();
 }
 
 // scalar statement of the same kernel (one thread per channel), kept as the readable reference of the arithmetic
@@ -711,16 +730,23 @@ int det_enqueue_gather(hipStream_t s, const float* boxes, const float* scores, i
     return PP_OK;
 }
 
+// which kernel det_enqueue_roi_align launches for a program of these numerics (POSEPIPE_ROI_SEPARABLE: A/B knob, read once)
+bool det_roi_align_separable(int separable) {
+    static const int sep_env = getenv("POSEPIPE_ROI_SEPARABLE") ? atoi(getenv("POSEPIPE_ROI_SEPARABLE")) : -1;
+    return sep_env >= 0 ? sep_env != 0 : separable != 0;
+}
+
 int det_enqueue_roi_align(hipStream_t s, const DetFpnArgs& a, const float* rois, const int32_t* n_rois, int max_rois,
-                          float* out, int n_frames, int separable) {
+                          float* out, int n_frames, int separable, unsigned* amax) {
     PP_REQUIRE(a.c == 256, "roi_align: C=%d (kernel launches one thread per channel, C must be 256)", a.c);
     FpnLevels L;
     for (int l = 0; l < 4; ++l) {
         L.feat[l] = a.feat[l]; L.h[l] = a.h[l]; L.w[l] = a.w[l]; L.stride[l] = a.stride[l];
     }
-    static const int sep_env = getenv("POSEPIPE_ROI_SEPARABLE") ? atoi(getenv("POSEPIPE_ROI_SEPARABLE")) : -1;   // A/B knob
-    if (sep_env >= 0 ? sep_env != 0 : separable != 0)
-        hipLaunchKernelGGL(roi_align_sep_kernel, dim3((max_rois + 3) / 4, n_frames), dim3(256), 0, s, L, a.c, rois, n_rois, max_rois, out);
+    const bool sep = det_roi_align_separable(separable);
+    PP_REQUIRE(!amax || sep, "roi_align: only the separable kernel writes the per-RoI maxima");
+    if (sep)
+        hipLaunchKernelGGL(roi_align_sep_kernel, dim3((max_rois + 3) / 4, n_frames), dim3(256), 0, s, L, a.c, rois, n_rois, max_rois, out, amax);
     else
         hipLaunchKernelGGL(roi_align_kernel, dim3(max_rois, n_frames), dim3(a.c), 0, s, L, a.c, rois, n_rois, max_rois, out);
     PP_HIP_CHECK(hipGetLastError());

@@ -22,6 +22,7 @@ struct pp_detector {
     pp_net* netB = nullptr;   // RoI features -> (cls, reg)
     int in_buf = 0, cls_buf[5], reg_buf[5], fpn_buf[4], roi_in = 0, roi_cls = 0, roi_reg = 0;
     int rpn_pitch = 0;       // 16: cls_buf[l] == reg_buf[l] is the fused head's 16-channel map
+    unsigned* roi_amax = nullptr;   // per-RoI maxima of the RoI head's input (its fp16-form fc6 reads them), written by RoIAlign
     int H = 0, W = 0, nh = 0, nw = 0, Hp = 0, Wp = 0;
     float sfx = 1.f, sfy = 1.f;
     int max_frames = 0, nms_pre = PP_DET_RPN_NMS_PRE, max_rois = PP_DET_RPN_MAX_PER_IMG, max_det = PP_DET_RCNN_MAX_PER_IMG, max_n = 0;
@@ -179,6 +180,13 @@ int pp_detector_create(pp_net* netA, pp_net* netB, const int32_t* bufs_a, const 
     PP_REQUIRE(pp_net_dims(netB, d->roi_cls, &h, &w, &c) == PP_OK && h * w == 1 && c == 2, "RoI head cls output must be 1x1x2");
     PP_REQUIRE(pp_net_dims(netB, d->roi_reg, &h, &w, &c) == PP_OK && h * w == 1 && c == 4, "RoI head reg output must be 1x1x4");
     d->max_frames = std::min(pp_net_max_batch(netA), pp_net_max_batch(netB) / d->max_rois);
+    // a fp16-form RoI head scales its input per RoI: the separable RoIAlign kernel writes the maxima itself (no extra pass)
+    if (det_roi_align_separable(pp_net_numerics(netB) == PP_NET_NUMERICS_SPLIT)) {
+        void* am = nullptr;
+        int rc_am = pp_net_input_amax(netB, d->roi_in, &am);
+        if (rc_am != PP_OK) return rc_am;
+        d->roi_amax = static_cast<unsigned*>(am);
+    }
     PP_REQUIRE(d->max_frames > 0, "pp_detector_create: RoI-head program needs max_batch >= %d", d->max_rois);
     memcpy(d->base, base_anchors, sizeof(d->base));
     d->max_n = 5 * d->nms_pre;
@@ -242,6 +250,8 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
     hipStream_t s = d->ctx->stream;
     const int F = n_frames;
     PP_HIP_CHECK(hipEventRecord(d->ev[0], s));
+    PpStages stage;
+    stage.next("det.preprocess");
     void* in_ptr = nullptr;
     int rc = pp_net_buffer(d->netA, d->in_buf, &in_ptr, nullptr);
     if (rc != PP_OK) return rc;
@@ -263,9 +273,11 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
         if (rc != PP_OK) return rc;
     }
     PP_HIP_CHECK(hipEventRecord(d->ev[1], s));
+    stage.next("det.image_program");
     rc = pp_net_run(d->netA, F, 0, -1);
     if (rc != PP_OK) return rc;
     PP_HIP_CHECK(hipEventRecord(d->ev[2], s));
+    stage.next("det.rpn_proposals");
     DetRpnArgs ra{};
     for (int l = 0; l < 5; ++l) {
         void *pc, *pr;
@@ -286,6 +298,7 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
     rc = det_enqueue_gather(s, d->boxes, d->scores, d->max_n, d->keep, d->n_keep, d->max_rois, d->rois, d->roi_scores, d->n_rois, 0, F);
     if (rc != PP_OK) return rc;
     PP_HIP_CHECK(hipEventRecord(d->ev[3], s));
+    stage.next("det.roi_align");
     DetFpnArgs fa{};
     for (int l = 0; l < 4; ++l) {
         void* p;
@@ -296,12 +309,14 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
     void* roi_in_ptr;
     pp_net_buffer(d->netB, d->roi_in, &roi_in_ptr, nullptr);
     rc = det_enqueue_roi_align(s, fa, d->rois, d->n_rois, d->max_rois, (float*)roi_in_ptr, F,
-                               pp_net_numerics(d->netB) == PP_NET_NUMERICS_SPLIT);
+                               pp_net_numerics(d->netB) == PP_NET_NUMERICS_SPLIT, d->roi_amax);
     if (rc != PP_OK) return rc;
     PP_HIP_CHECK(hipEventRecord(d->ev[4], s));
+    stage.next("det.roi_head_program");
     rc = pp_net_run(d->netB, F * d->max_rois, 0, -1);
     if (rc != PP_OK) return rc;
     PP_HIP_CHECK(hipEventRecord(d->ev[5], s));
+    stage.next("det.final_decode_nms");
     void *pcls, *preg;
     pp_net_buffer(d->netB, d->roi_cls, &pcls, nullptr);
     pp_net_buffer(d->netB, d->roi_reg, &preg, nullptr);

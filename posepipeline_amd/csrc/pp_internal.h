@@ -58,6 +58,28 @@ struct ScratchCursor {
     }
 };
 
+// ---- roctx ranges around the stages (rocprofv3 --marker-trace shows them on the host timeline, each enclosing the
+// launches of one stage; the per-stage DEVICE times are the HIP-event figures of pp_detector_timing / pp_topdown_timing).  The
+// marker library is looked up at run time (librocprofiler-sdk-roctx.so, else libroctx64.so): absent = no-ops, no link dependency.
+void pp_range_push(const char* name);
+void pp_range_pop();
+struct PpRange {
+    explicit PpRange(const char* name) { pp_range_push(name); }
+    ~PpRange() { pp_range_pop(); }
+    PpRange(const PpRange&) = delete;
+    PpRange& operator=(const PpRange&) = delete;
+};
+// consecutive stages of one function: next(name) closes the current range and opens the next; balanced on every return path
+struct PpStages {
+    bool open = false;
+    void next(const char* name) {
+        if (open) pp_range_pop();
+        open = name != nullptr;
+        if (open) pp_range_push(name);
+    }
+    ~PpStages() { next(nullptr); }
+};
+
 // ---- convolution (conv_igemm.hip) ----------------------------------------------------------
 struct ConvArgs {
     const float* x;

@@ -102,9 +102,12 @@ static int topdown_tail(pp_topdown* t, int n_person, float* kpts, int kpts_mem, 
     hipStream_t s = t->ctx->stream;
     const int batch = n_person * (t->flip ? 2 : 1);
     PP_HIP_CHECK(hipEventRecord(t->ev[1], s));
+    PpStages stage;
+    stage.next("topdown.backbone_program");
     int rc = pp_net_run(t->net, batch, 0, -1);
     if (rc != PP_OK) return rc;
     PP_HIP_CHECK(hipEventRecord(t->ev[2], s));
+    stage.next("topdown.flip_merge_decode");
     void* hm_ptr = nullptr;
     size_t hm_bytes = 0;
     rc = pp_net_buffer(t->net, t->out_buf, &hm_ptr, &hm_bytes);

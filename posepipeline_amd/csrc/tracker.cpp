@@ -20,6 +20,14 @@
 // The Hungarian solver restates scipy.optimize.linear_sum_assignment (rectangular LSAP, Crouse's
 // shortest augmenting path, scipy/optimize/rectangular_lsap), including its tie-breaking, because
 // bit-exact track ids depend on it; pinned by tests/golden/hungarian.npz.
+//
+// Third-party attribution: `solve_lsap` / `augmenting_path` below follow the structure and the identifier
+// names (row4col, col4row, SR, SC, remaining, shortestPathCosts) of SciPy's
+// scipy/optimize/rectangular_lsap/rectangular_lsap.cpp, "Copyright (c) 2019, PM Larsen (SciPy
+// Developers)", distributed under the 3-clause BSD licence (redistribution in source and binary form
+// permitted provided the copyright notice, the list of conditions and the disclaimer are retained; the
+// SciPy developers' names may not be used to endorse derived products; provided "as is" without
+// warranty).  It is not code of the reference repository (which only CALLS scipy, linear_assignment.py:55).
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
