@@ -1320,6 +1320,135 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
     const int cbB = by * (BN / 32);                  // first channel block of the workgroup
     const int cb0 = cbB + wn * 2;                    // ... of this wave
 
+    // sample of the wave's first / last pixel (clamped to the tensor): equal = the wave's 128 pixels lie in one sample
+    const unsigned mfirst = (unsigned)min(m0 + wm * 128, a.S - 1), mlast = (unsigned)min(m0 + wm * 128 + 127, a.S - 1);
+    const int img_first = __builtin_amdgcn_readfirstlane((int)pp_udiv(mfirst, a.dv_per)), img_last = __builtin_amdgcn_readfirstlane((int)pp_udiv(mlast, a.dv_per));
+    unsigned oam_first = 0;                          // fp16 form: maximum of that sample (the epilogue's 1 / s)
+    if constexpr (H) oam_first = a.x_amax[img_first];
+    const unsigned lds_base0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const size_t wstep0 = (size_t)a.ncb * (WPL * 64);
+    f32x16 acc[2][4];                                // (zeroed right in front of the K loops: 128 live registers less during the set-up)
+    if constexpr (H) {
+    // ---- fp16 form (round 5): the pixels travel global -> LDS by DMA as well, as raw float32; the two float16 terms are made when
+    // a wave reads its B fragment.  Why: with the pixels staged through registers (rounds 2 - 4, still the six-product form below) a
+    // stage could not be shorter than the latency of the loads issued ONE stage earlier -- ~1.3 us from HBM under load against
+    // 0.38 us of MFMAs in this form (fc6: a lone workgroup advanced one stage per ~2700 cycles; the product layers ran at 0.13 - 0.3
+    // of the matrix peak) -- and a second register set for a deeper prefetch does not fit beside 128 accumulator registers (it
+    // spilled 256 B per lane and stage).  A DMA needs no registers: a ring of THREE 16 KB pixel stages ([256 pixels][16 channels],
+    // rows of 64 B) + three weight stages, everything requested two stages ahead, every wait an exact count (all vector-memory
+    // operations of the loop are DMAs: 4 pixel blocks + 2 weight fragments per wave and stage).
+    // LDS layout of a pixel stage: pixel-major rows of 64 B, the row's four 16-byte quads XOR-swizzled by (pixel >> 1) & 3 -- applied
+    // on the GLOBAL side (DMA lane i of a block writes slot i, i.e. (pixel i / 4, slot i % 4), and fetches quad slot ^ swizzle of that
+    // pixel: the four lanes of a pixel still cover its 64 contiguous bytes).  A lane's fragment (pixel lane & 31, k half lane >> 5)
+    // is quads 2 half and 2 half + 1 = two ds_read_b128 at the row + ((2 half) ^ swizzle) * 16 and that address ^ 16: every service
+    // group of ds_read_b128 covers all 8 bank quads exactly twice (conflict-free).
+    // Conversion per fragment (8 floats of one pixel): scale (power of two per sample), h0 = f16(x s), h1 = f16(x s - h0):
+    // 24 vector instructions, 96 per wave and stage beside its 24 MFMAs of 32 cycles.
+    constexpr int XR = 3, XSTG = BM * 64, WR = 3, WBYTES = WU * 16;
+    constexpr int NXD = BM / 16 / NWAVE;             // 1 KB pixel blocks (16 pixels) per wave and stage
+    constexpr int NWD = WU / 64 / NWAVE;             // 1 KB weight fragments per wave and stage
+    static_assert(BM / 16 % NWAVE == 0 && WU / 64 % NWAVE == 0, "every wave issues the same number of DMAs (vmcnt arithmetic)");
+    unsigned gx[NXD];                                // byte offset of this lane's 16 bytes of stage 0 (the tensor is < 4 GiB)
+#pragma unroll
+    for (int i = 0; i < NXD; ++i) {
+        const int pl = (wave + NWAVE * i) * 16 + (lane >> 2);
+        const unsigned m = (unsigned)min(m0 + pl, a.S - 1);          // rows past the tensor: any valid address (never stored)
+        const int img = (int)pp_udiv(m, a.dv_per), rem = (int)(m - (unsigned)img * (unsigned)(a.H * a.W));
+        const int ho = (int)pp_udiv((unsigned)rem, a.dv_row), wo = rem - ho * a.W;
+        gx[i] = (unsigned)(((img * a.xp_h + ho * a.stride) * a.xp_w + wo * a.stride) * a.Cin) * 4u + (unsigned)(((lane & 3) ^ ((pl >> 1) & 3)) * 16);
+    }
+    float xsc[4];                                    // activation scale of the sample of pixel pb * 32 + (lane & 31)
+#pragma unroll
+    for (int pb = 0; pb < 4; ++pb) xsc[pb] = pp_act_scale(oam_first);
+    if (img_first != img_last) {
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            const unsigned mp = (unsigned)min(m0 + wm * 128 + pb * 32 + (lane & 31), a.S - 1);
+            xsc[pb] = pp_act_scale(a.x_amax[pp_udiv(mp, a.dv_per)]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (the maxima are in: from here on every vector-memory op is a DMA)
+    // (scalar base + 32-bit lane offset: one address register per DMA)
+    const unsigned wlane16 = (unsigned)lane * 16u;
+    auto issue = [&](int c) {                         // weights and pixels of stage c
+        const uint4* wsrc = a.w + (size_t)c * wstep0 + (size_t)cbB * (WPL * 64);          // workgroup-uniform
+#pragma unroll
+        for (int i = 0; i < NWD; ++i) {
+            const int slab = i * NWAVE + wave;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base0 + (unsigned)(XR * XSTG + (c % WR) * WBYTES + slab * 1024));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(wlane16 + (unsigned)(slab * 1024)), "s"(wsrc), "s"(dst) : "memory", "m0");
+        }
+        const float* xsrc = a.x + (size_t)c * 16;                                          // 64 bytes per stage
+#pragma unroll
+        for (int i = 0; i < NXD; ++i) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base0 + (unsigned)((c % XR) * XSTG + (wave + NWAVE * i) * 1024));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(gx[i]), "s"(xsrc), "s"(dst) : "memory", "m0");
+        }
+    };
+    const int fofs = (wm * 128 + (lane & 31)) * 64 + ((((lane >> 5) * 2) ^ ((lane >> 1) & 3)) * 16);     // + pb * 2048; second quad: ^ 16
+    const int wofs = XR * XSTG + ((wn * 2) * (WPL * 64) + lane) * 16;                                        // + slot * WBYTES + (cb * WPL + plane) * 1024
+    auto frag = [&](const unsigned char* sx_, int pb, uint4 (&h)[2]) {
+        const float4 q0 = *reinterpret_cast<const float4*>(sx_ + (fofs + pb * 2048));
+        const float4 q1 = *reinterpret_cast<const float4*>(sx_ + ((fofs + pb * 2048) ^ 16));
+        const float sc = xsc[pb];
+        const f32x2_t v[4] = {f32x2_t{q0.x, q0.y} * sc, f32x2_t{q0.z, q0.w} * sc, f32x2_t{q1.x, q1.y} * sc, f32x2_t{q1.z, q1.w} * sc};
+        unsigned a_[4], b_[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f16x2_t c0 = __builtin_convertvector(v[e], f16x2_t);
+            const f32x2_t r = v[e] - __builtin_convertvector(c0, f32x2_t);                                     // exact
+            const f16x2_t c1 = __builtin_convertvector(r, f16x2_t);
+            a_[e] = __builtin_bit_cast(unsigned, c0);
+            b_[e] = __builtin_bit_cast(unsigned, c1);
+        }
+        h[0] = make_uint4(a_[0], a_[1], a_[2], a_[3]);
+        h[1] = make_uint4(b_[0], b_[1], b_[2], b_[3]);
+    };
+    PP_TL_MARK(4);
+    issue(0);
+    if (a.nchunks > 1) issue(1);
+    PP_TL_MARK(5);
+    if (a.nchunks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NXD + NWD) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    PP_TL_MARK(1);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
+    for (int c = 0; c < a.nchunks; ++c) {
+        const unsigned char* sxp = smem + (c % XR) * XSTG;
+        const unsigned char* sw = smem + (c % WR) * WBYTES;
+        uint4 wf[2][WPL], xh[2][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int pl = 0; pl < WPL; ++pl) wf[cb][pl] = *reinterpret_cast<const uint4*>(sw + wofs + (cb * WPL + pl) * 1024);
+        frag(sxp, 0, xh[0]);
+        // stage c + 2 into the slots stage c - 1 used (every wave is past the barrier that closed it)
+        if (c + 2 < a.nchunks) issue(c + 2);
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb) {
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int WI[3] = {1, 0, 0}, XI[3] = {0, 1, 0};      // g1 h0 + g0 h1 + g0 h0
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+                    acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[cb][WI[p]]),
+                                                                         __builtin_bit_cast(f16x8, xh[pb & 1][XI[p]]), acc[cb][pb], 0, 0, 0);
+            // the next pixel block's fragment is read and converted in the shadow of these MFMAs
+            if (pb < 3) frag(sxp, pb + 1, xh[(pb + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // stage c + 1 has landed (younger in the queue: only what this stage requested for c + 2); every LDS read of this stage is done
+        if (c + 2 < a.nchunks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NXD + NWD) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    } else {
     // ---- loaders -------------------------------------------------------------------------------------------------------------
     unsigned goff[XS];
     int simg[H ? XS : 1];                            // fp16 form: the sample slot j belongs to (its activation scale)
@@ -1386,28 +1515,12 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
     const int xofs = ((lane >> 5) * NPp + wm * 128 + (lane & 31)) * 16;                 // + plane * XPLANE + pb * 512
     const int wofs = XBYTES + ((wn * 2) * (WPL * 64) + lane) * 16;                      // + (cb * WPL + plane) * 1024
 
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-        for (int pb = 0; pb < 4; ++pb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
 
     // vmcnt counts in issue order: a stage issues its weight DMA first and its pixel loads (for the stage after next) after it, so
     // "all but the XS youngest" = the DMA has landed while the pixel loads keep flying across the barrier
     PP_TL_MARK(4);
     issue_w(0, 0);
     load_x(0);
-    // sample of the wave's first / last pixel (clamped to the tensor): equal = the wave's 128 pixels lie in one sample
-    const unsigned mfirst = (unsigned)min(m0 + wm * 128, a.S - 1), mlast = (unsigned)min(m0 + wm * 128 + 127, a.S - 1);
-    const int img_first = __builtin_amdgcn_readfirstlane((int)pp_udiv(mfirst, a.dv_per)), img_last = __builtin_amdgcn_readfirstlane((int)pp_udiv(mlast, a.dv_per));
-    unsigned oam_first = 0;                          // fp16 form: maximum of that sample (the epilogue's 1 / s), requested here
-    if constexpr (H) {
-        oam_first = a.x_amax[img_first];
-#pragma unroll
-        for (int j = 0; j < XS; ++j) sx[j] = pp_act_scale(a.x_amax[simg[j]]);
-    }
     store_x(0);
     PP_TL_MARK(5);
     if (a.nchunks > 1) load_x(1);
@@ -1416,6 +1529,12 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
     __builtin_amdgcn_s_barrier();
     PP_TL_MARK(1);
 
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < 4; ++pb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
     for (int c = 0; c < a.nchunks; ++c) {
         const unsigned char* sb = smem + (c & 1) * STAGE;
         uint4 wf[2][WPL], xf[2][XP];
@@ -1465,6 +1584,8 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
+
+    }   // !H
 
     PP_TL_MARK(2);
     PP_TL_MARK(6);
@@ -1534,26 +1655,31 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
             // 4's timeline put the epilogue of the residual layers (256 -> 1024 at 40x68) at the length of their K loop
             const int co = (cb0 + cb) * 32 + rdchunk * 4;
             const unsigned* tabw = reinterpret_cast<const unsigned*>(tab);
-            float4 vv[16];
+            // two batches of eight lines (round 5): with all sixteen in flight (64 + 64 registers beside the 64 accumulator registers of
+            // the other channel block) the allocator spilled accumulator tuples -- and kept them spilled INSIDE the K loop
 #pragma unroll
-            for (int it = 0; it < 16; ++it) vv[it] = *reinterpret_cast<const float4*>(stg + (it * 8 + rdrow) * 128 + rdpos * 16);
+            for (int h8 = 0; h8 < 2; ++h8) {
+            float4 vv[8];
+#pragma unroll
+            for (int i8 = 0; i8 < 8; ++i8) vv[i8] = *reinterpret_cast<const float4*>(stg + ((h8 * 8 + i8) * 8 + rdrow) * 128 + rdpos * 16);
             if (a.res1) {
-                float4 rv[16];
+                float4 rv[8];
 #pragma unroll
-                for (int it = 0; it < 16; ++it) rv[it] = *reinterpret_cast<const float4*>(a.res1 + (size_t)tabw[(it * 8 + rdrow) * 4 + 1] * a.Cout + co);
+                for (int i8 = 0; i8 < 8; ++i8) rv[i8] = *reinterpret_cast<const float4*>(a.res1 + (size_t)tabw[((h8 * 8 + i8) * 8 + rdrow) * 4 + 1] * a.Cout + co);
 #pragma unroll
-                for (int it = 0; it < 16; ++it) { vv[it].x += rv[it].x; vv[it].y += rv[it].y; vv[it].z += rv[it].z; vv[it].w += rv[it].w; }
+                for (int i8 = 0; i8 < 8; ++i8) { vv[i8].x += rv[i8].x; vv[i8].y += rv[i8].y; vv[i8].z += rv[i8].z; vv[i8].w += rv[i8].w; }
             }
             if (a.res2) {
-                float4 rv[16];
+                float4 rv[8];
 #pragma unroll
-                for (int it = 0; it < 16; ++it) rv[it] = *reinterpret_cast<const float4*>(a.res2 + (size_t)tabw[(it * 8 + rdrow) * 4 + 2] * a.Cout + co);
+                for (int i8 = 0; i8 < 8; ++i8) rv[i8] = *reinterpret_cast<const float4*>(a.res2 + (size_t)tabw[((h8 * 8 + i8) * 8 + rdrow) * 4 + 2] * a.Cout + co);
 #pragma unroll
-                for (int it = 0; it < 16; ++it) { vv[it].x += rv[it].x; vv[it].y += rv[it].y; vv[it].z += rv[it].z; vv[it].w += rv[it].w; }
+                for (int i8 = 0; i8 < 8; ++i8) { vv[i8].x += rv[i8].x; vv[i8].y += rv[i8].y; vv[i8].z += rv[i8].z; vv[i8].w += rv[i8].w; }
             }
 #pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                float4 v = vv[it];
+            for (int i8 = 0; i8 < 8; ++i8) {
+                const int it = h8 * 8 + i8;
+                float4 v = vv[i8];
                 if (a.relu == PP_RELU_LAST) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 const uint2 t = *reinterpret_cast<const uint2*>(tabw + (it * 8 + rdrow) * 4);     // .x: output pixel; then (.w via the next read)
                 const unsigned tw = tabw[(it * 8 + rdrow) * 4 + 3];
@@ -1570,6 +1696,7 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
                         if (rdpos == 0 && m8 > 0.f) atomicMax(a.y_amax + (tw - 1u), __float_as_uint(m8));
                     }
                 }
+            }
             }
         }
         if (a.y_amax) {      // (a wave with more than two samples has issued its atomics above and passes zeros)
@@ -2009,7 +2136,9 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         s.epi_lds = epi_knob >= 0 ? epi_knob : epi_env;
         const int nwave = 4;
         fill_divisors(s);
-        const size_t lds = std::max<size_t>((size_t)2 * (xp * 2 * (BM + 4) * 16 + BN * 2 * wpl * 16), s.epi_lds ? (size_t)nwave * (16384 + 2048) : 0);
+        // fp16 form: three raw float32 pixel stages of BM x 64 B + three weight stages; six-product form: two stages of split planes + weights
+        const size_t lds_loop = f16 ? (size_t)3 * BM * 64 + (size_t)3 * BN * 2 * wpl * 16 : (size_t)2 * (xp * 2 * (BM + 4) * 16 + BN * 2 * wpl * 16);
+        const size_t lds = std::max<size_t>(lds_loop, s.epi_lds ? (size_t)nwave * (16384 + 2048) : 0);
         static std::once_flag once;
         std::call_once(once, [] {
             (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
