@@ -2159,7 +2159,11 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     static const int nw8_min_blocks = env_int("POSEPIPE_SPLIT_NW8_MIN_BLOCKS", 512), nw8_min_chunks = env_int("POSEPIPE_SPLIT_NW8_MIN_CHUNKS", 16);
     unsigned gx = 0;
     const bool c48 = split_c48(a);
-    int nw = c48 ? 4 : 8;
+    // fp16 form: the 4-wave ring form everywhere.  With half the matrix work per tap both forms sit at the same ~420 TFLOP/s on the
+    // long-K layers (LDS bandwidth: 8 b128 fragment reads per 12 MFMAs and wave), and two workgroups per CU hide each other's per-tap
+    // barrier: same-box A/B (profile_net det 64) 256 -> 256 at 160x272 414.7 -> 418.9, 80x136 366 -> 400, 40x68 354 -> 371 TFLOP/s
+    static const int nw8_f16 = env_int("POSEPIPE_SPLIT_NW8_F16", 0);
+    int nw = (c48 || (f16 && !nw8_f16)) ? 4 : 8;
     // geometry for the 8-wave form (512-pixel tiles, one workgroup per CU); if that gives fewer than ~2 workgroups per CU (or
     // the layer is a one-tap product), the 4-wave form (256-pixel tiles, two per CU)
     for (;;) {
