@@ -474,6 +474,7 @@ def run_cascade(args, D):
                                 "every frame (tests/test_gpu_parity_modes.py::test_integer_contract_1080p_64_frames_no_replay), joints "
                                 "within 1e-3 px / mm",
                         "ids_no_replay": ids_no_replay({"bit_exact_mode": cas_exact, "integer_exact_mode": cas_int, "default": cas}, dptr, B)}
+    split_peak_line = BF16_MFMA_PEAK_TFLOPS / fam.get("products", 6)
     out = {
         "metric": METRIC, "value": D.world * B * K / dt, "unit": "frames/s", "n_gpus": D.world, "steps": K,
         "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -497,6 +498,11 @@ def run_cascade(args, D):
     }
     if D.world > 1:
         out["per_rank_ms_per_step"] = per_rank
+        # (replicas: no data-path collective at all -- the only cross-rank traffic of the timed region is the barrier)
+        out["per_rank_roofline_frac"] = [flops_step / (ms * 1e-3) / 1e12 / split_peak_line for ms in per_rank]
+        out["collectives_in_timed_region"] = {"count": 0, "bytes": 0,
+                                               "note": "replicas mode shards FRAMES over ranks with no exchange; --mode shard (one clip over the "
+                                                       "ranks) reports collectives / collective_bytes / collective_wait per rank"}
     if side_legs:
         # PCIe-inclusive leg (reported beside `value`, never as it): the same chunks streamed from host memory through
         # page-locked staging buffers and the copy stream (posepipeline_amd/streaming.py), upload overlapped with compute
@@ -637,10 +643,16 @@ def run_cascade_sharded(args, D, ctx, cas):
     D.barrier(ctx)
     dt_own = time.perf_counter() - t0
     dt = D.max_time(dt_own)
-    per_rank = D.gather_obj({k: (int(v) if k == "rounds" else round(v * 1e3, 3)) for k, v in tm.items()})
+    flops_step = B * (cas.detector.flops_per_frame + 2 * P * cas.pose_net.prog.flops)
+    peak = BF16_MFMA_PEAK_TFLOPS / split_products([cas.pose_net])
+    mine = {k: (int(v) if k in ("rounds", "collectives", "collective_bytes") else round(v * 1e3, 3)) for k, v in tm.items()}
+    # what makes the first real multi-GPU run readable in one shot: every rank's own end-to-end rate against the kernel peak, its
+    # collective volume and the part of it that was exposed
+    mine["roofline_frac"] = flops_step * K / dt_own / 1e12 / peak
+    mine["collective_ms_per_round"] = mine.get("collective_wait", 0.0) / max(1, mine.get("rounds", 1))
+    per_rank = D.gather_obj(mine)
     if D.rank != 0:
         return
-    flops_step = B * (cas.detector.flops_per_frame + 2 * P * cas.pose_net.prog.flops)
     return {
         "metric": METRIC, "value": D.world * B * K / dt, "unit": "frames/s", "n_gpus": D.world, "steps": K, "warmup": args.warmup,
         "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" + DTYPE_NOTE, "data": "synthetic",
@@ -652,13 +664,14 @@ def run_cascade_sharded(args, D, ctx, cas):
                    "detector_boxes": "detector runs on every frame; downstream boxes are replayed synthetic GT (random-weight detector)"},
         "roofline": {"bound": "mfma", "kernel": "conv_split_kernel (+ the float32 MFMA kernels on the layers it does not take), whole step",
                      "achieved": flops_step * K / dt / 1e12,
-                     "peak": BF16_MFMA_PEAK_TFLOPS / split_products([cas.pose_net]), "unit": "TFLOP/s",
-                     "frac": flops_step * K / dt / 1e12 / (BF16_MFMA_PEAK_TFLOPS / split_products([cas.pose_net])),
+                     "peak": peak, "unit": "TFLOP/s", "frac": flops_step * K / dt / 1e12 / peak,
                      "traffic": None, "peak_note": "2500 TFLOP/s dense 16-bit MFMA / %d products per float32 term" % split_products([cas.pose_net]),
                      "note": "END-TO-END float32-equivalent conv FLOP rate per GPU over the whole sharded run (host phases and collectives "
                              "included) against the split kernel's peak; the per-kernel roofline line is the default mode's"},
         "host_cores_per_rank": (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", D.world))),
         "per_rank_phase_ms": per_rank,
+        "per_rank_note": "per rank: phase wall times (ms), roofline_frac = the rank's own end-to-end conv FLOP rate / kernel peak, collectives / "
+                         "collective_bytes (received, summed over the run), collective_wait = ms blocked in collectives (the rest overlapped compute)",
     }
 
 

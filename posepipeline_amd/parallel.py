@@ -98,10 +98,20 @@ class _Gather:
     `device` (RCCL: device memory, no per-rank tensor list, one D2H copy when the result is read; gloo: host memory).
     start() returns immediately (async_op), result() waits and returns [world][rows][cols] as numpy."""
 
+    # per-process totals since the last reset_stats(): collectives started, bytes every rank RECEIVES per collective summed
+    # (world x slab), seconds result() blocked (the exposed part: the rest of a collective's life overlapped compute)
+    stats = {"collectives": 0, "bytes": 0, "wait_s": 0.0}
+
+    @classmethod
+    def reset_stats(cls):
+        cls.stats = {"collectives": 0, "bytes": 0, "wait_s": 0.0}
+
     def __init__(self, dist, device, local: np.ndarray):
         self.world = dist.get_world_size()
         self.shape = local.shape
         self.host = None
+        _Gather.stats["collectives"] += 1
+        _Gather.stats["bytes"] += int(self.world * local.size * (local.dtype.itemsize if local.dtype in (np.float32, np.float64, np.int64, np.int32) else 4))
         if self.world == 1 and getattr(dist, "numpy_only", False):      # a one-rank stand-in: nothing to exchange, no torch
             self.host = np.array(local, copy=True)[None]
             self.work = None
@@ -123,9 +133,13 @@ class _Gather:
     def result(self) -> np.ndarray:
         if self.host is not None:
             return self.host
+        import time
+        t0 = time.perf_counter()
         if self.work is not None and hasattr(self.work, "wait"):
             self.work.wait()
-        return self.out.cpu().numpy().reshape((self.world,) + tuple(self.shape))
+        got = self.out.cpu().numpy().reshape((self.world,) + tuple(self.shape))
+        _Gather.stats["wait_s"] += time.perf_counter() - t0
+        return got
 
 
 def all_gather_ragged(local: np.ndarray, counts, dist, device="cpu") -> np.ndarray:
@@ -143,7 +157,8 @@ def all_gather_ragged(local: np.ndarray, counts, dist, device="cpu") -> np.ndarr
 def _takes_need(fn) -> bool:
     import inspect
     try:
-        return "need" in inspect.signature(fn).parameters
+        ps = inspect.signature(fn).parameters          # (follows functools.partial; a **kwargs wrapper takes `need` as well)
+        return "need" in ps or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in ps.values())
     except (TypeError, ValueError):
         return False
 
@@ -173,6 +188,7 @@ def process_video_sharded(dist, n_frames, chunks_fn, detect_fn, associate_fn, to
     frame, identical on every rank) runs between the two passes.
     Returns on every rank: dict(tracks = per-frame rows, keypoints / keypoints_3d = {track_id: (first_frame, array)})."""
     import time
+    _Gather.reset_stats()
     rank, world = dist.get_rank(), dist.get_world_size()
     # the round slabs carry frame indices and job indices next to float32 payload in ONE float32 tensor per collective: exact below 2^24
     assert n_frames < 2 ** 24, "frame indices travel in float32 slabs: shard clips of 16.7 M frames or more into several calls"
@@ -304,6 +320,8 @@ def process_video_sharded(dist, n_frames, chunks_fn, detect_fn, associate_fn, to
     out = ps.advance(final=True)        # lifting of every track, replicated (0.03 GFLOP per frame)
     t4 = time.perf_counter()
     if timings is not None:
+        timings.update(collectives=_Gather.stats["collectives"], collective_bytes=_Gather.stats["bytes"],
+                       collective_wait=_Gather.stats["wait_s"])
         timings.update(detect=t1 - t0, gather_dets=t2 - t1, associate=t3 - t2, topdown=t_2d[0], gather_2d=t_2d[1],
                        lift=t4 - t3 - t_2d[0] - t_2d[1], total=t4 - t0, rounds=rounds)
     return dict(tracks=tracks, keypoints=collect([out], "keypoints"), keypoints_3d=collect([out], "keypoints_3d"))

@@ -55,6 +55,46 @@ def test_yolox_preprocess_network_and_detections(ctx):
     det.close()
 
 
+def test_yolox_x_full_size_800x1440(ctx):
+    """the program `bench.py --workload cascade0`-style ByteTrack runs time -- a 1080p frame at the config's test
+    scale (800, 1440) (3rdparty/mmtracking/mot/bytetrack/bytetrack_yolox_x_crowdhuman_mot17-private-half.py:6,62-78) through
+    YOLOX-X -- against the oracle: resize / pad `==`, network outputs rtol 1e-4 (Swish in double precision on two libms),
+    decode + NMS from the device's head outputs `==`."""
+    rng = np.random.default_rng(13)
+    frames = np.stack([synth_frame(rng, 1080, 1920)])
+    # objectness bias: with the small tests' -3.0 ALL 23 625 priors of an 800 x 1440 input pass score_thr 0.01 (seeded-random heads
+    # barely vary) and the device's 8 192-candidate NMS capacity would cut them; -4.5 leaves ~1 100 (measured)
+    sd = _sd(obj_bias=-4.5)
+    det = yolox.YoloXDetector(ctx, sd, 1080, 1920, max_frames=1)               # default scale (800, 1440)
+    got = det.run(frames)
+    x, sf = oyx.preprocess(np.ascontiguousarray(frames[0][..., ::-1]))
+    assert (det.hp, det.wp) == x.shape[1:3] == (800, 1440) or x.shape[1:3] == (det.hp, det.wp)
+    assert np.array_equal(sf, det.scale_factor)
+    din, _, _ = det.net.buffer("input")
+    buf = np.empty((1, det.hp, det.wp, 4), np.float32)
+    ctx.d2h(buf, int(din))
+    assert np.array_equal(buf[0, :, :, 2::-1], x[0]) and not buf[0, :, :, 3].any()
+    cls, reg, obj = oyx.YOLOXRef(sd).forward(x)
+    total = exact = 0
+    dev = {}
+    for name, ref in (("cls", cls), ("reg", reg), ("obj", obj)):
+        dev[name] = []
+        for l in range(3):
+            dptr, _, _ = det.net.buffer(f"{name}{l}")
+            a = np.empty(ref[l].shape, np.float32)
+            ctx.d2h(a, int(dptr))
+            scale = max(1.0, float(np.abs(ref[l]).max()))
+            assert np.allclose(a, ref[l], rtol=1e-4, atol=1e-5 * scale), (name, l)
+            total += a.size
+            exact += int((a == ref[l]).sum())
+            dev[name].append(a)
+    ref_dets = oyx.detections(dev["cls"], dev["reg"], dev["obj"], sf)
+    assert ref_dets.shape == got[0].shape and np.array_equal(ref_dets, got[0])
+    print(f"YOLOX-X {det.hp}x{det.wp}: {exact} of {total} head outputs bit-identical, {len(ref_dets)} detections")
+    assert exact / total > 0.99 and 0 < len(ref_dets) < 8192
+    det.close()
+
+
 def test_mmtrack_bytetrack_wrapper(ctx, tmp_path, monkeypatch):
     monkeypatch.setenv("POSEPIPE_SYNTHETIC_WEIGHTS", "1")
     from posepipeline_amd import video

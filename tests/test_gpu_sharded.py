@@ -226,3 +226,33 @@ def test_bench_gpus2_launches_two_ranks_on_real_kernels():
     assert line["n_gpus"] == 2 and line["distributed"]["world_size"] == 2 and len(line["distributed"]["ranks"]) == 2
     assert line["value"] > 0 and len(line["per_rank_ms_per_step"]) == 2 and line["scaling"] == "weak"
     assert line["config"]["frames_per_step_per_gpu"] == 8 and "secondary" not in line      # side legs are N = 1 only
+    assert len(line["per_rank_roofline_frac"]) == 2 and all(0 < f < 1 for f in line["per_rank_roofline_frac"])
+    assert line["collectives_in_timed_region"]["count"] == 0 and line["distributed"]["backend"]
+
+
+def test_bench_gpus2_shard_mode_on_real_kernels():
+    """`python bench.py --gpus 2 --mode shard`: ONE clip sharded over two ranks through parallel.py on the real
+    cascade (gloo here, two ranks on this box's one GPU): one JSON line whose per-rank block carries what makes the first real
+    multi-GPU run readable -- phase times, each rank's end-to-end roofline fraction, collective count / bytes / blocked time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, POSEPIPE_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "POSEPIPE_CONV_EXACT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--mode", "shard", "--steps", "2", "--warmup", "1",
+                          "--chunk", "8", "--cpu-frames", "0"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["mode"] == "shard" and line["distributed"]["world_size"] == 2
+    assert line["value"] > 0 and line["config"]["frames_per_step_per_gpu"] == 8
+    ranks = line["per_rank_phase_ms"]
+    assert len(ranks) == 2
+    for r in ranks:
+        # two passes (detections, 2D rows) x `steps` rounds of one all_gather each, 2 ranks x slab bytes received
+        assert r["rounds"] == 2 and r["collectives"] >= 4 and r["collective_bytes"] > 0 and r["collective_wait"] >= 0
+        assert 0 < r["roofline_frac"] < 1 and r["total"] > 0
+    assert line["distributed"]["backend"] == "gloo"

@@ -167,3 +167,35 @@ def test_tracking_bounding_boxes_wrapper(ctx, tmp_path, monkeypatch):
         n_tracks += len(ids)
     assert n_tracks > 0
     parser._cache.clear()
+
+
+def test_yolov4_full_size_416_80_classes(ctx):
+    """the program `bench.py --workload track0 / cascade0` times -- 1080p frame, 416 x 416 letterbox, the 80-class
+    COCO head (255 channels per scale) -- against the oracle: letterbox and the integer stages `==`, network outputs rtol 1e-5
+    (Mish in double precision on two libms, see the module docstring).  wrappers/deep_sort_yolov4/yolo.py:18-129."""
+    sd = yolov4.synth_params(yolov4.yolov4_param_shapes(80), seed=4, head_bias=0.7)
+    frames = _frames(11, 1, 1080, 1920)
+    det = yolov4.YoloV4Detector(ctx, sd, 1080, 1920, max_frames=1)            # defaults: size 416, 80 classes
+    got = det.run(frames)
+    x = oyolo.network_input(np.ascontiguousarray(frames[0][..., ::-1]), (416, 416))
+    dptr, _, _ = det.net.buffer("input")
+    din = np.empty((1, 416, 416, 4), np.float32)
+    ctx.d2h(din, int(dptr))
+    assert np.array_equal(din[0, :, :, :3], x[0]) and not din[0, :, :, 3].any()
+    ref_outs = oyolo.YOLOv4Ref(sd, 80).forward(x)
+    assert [r.shape for r in ref_outs] == [(1, 13, 13, 255), (1, 26, 26, 255), (1, 52, 52, 255)]
+    total = exact = 0
+    dev_outs = []
+    for name, ref in zip(("y19", "y38", "y76"), ref_outs):
+        dptr, _, _ = det.net.buffer(name)
+        dev = np.empty(ref.shape, np.float32)
+        ctx.d2h(dev, int(dptr))
+        assert np.allclose(dev, ref, rtol=1e-5, atol=1e-6), name
+        total += dev.size
+        exact += int((dev == ref).sum())
+        dev_outs.append(dev)
+    rb, rs = oyolo.person_detections(dev_outs, (1080, 1920), num_classes=80)
+    assert np.array_equal(got[0][0], rb) and np.array_equal(got[0][1], rs)
+    print(f"YOLOv4 416 / 80 classes: {exact} of {total} head outputs bit-identical, {len(rb)} person boxes")
+    assert exact / total > 0.9999 and len(rb) > 0
+    det.close()
