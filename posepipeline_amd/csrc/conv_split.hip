@@ -774,21 +774,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
 #endif
     // all bias / residual loads are issued back to back from clamped (always valid) addresses before anything consumes them: one
     // memory round trip per operand instead of one per (pixel block, channel group) -- the epilogue was 17 % of W48's 48-channel
-    // layers (profiles/r02_conv_split_ablation.txt)
-    bool cok[COB][4];
-    int cos[COB][4];
-    float4 b4[COB][4];
-    float4 sc4[H ? COB : 1][H ? 4 : 1];                // H: 1 / (s c) of the lane's channels
-#pragma unroll
-    for (int cb = 0; cb < COB; ++cb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co = (cb0 + cb) * 32 + 8 * g + 4 * (lane >> 5);
-            cok[cb][g] = co < a.Cout;
-            cos[cb][g] = cok[cb][g] ? co : 0;
-            b4[cb][g] = *reinterpret_cast<const float4*>(a.bias + cos[cb][g]);
-            if constexpr (H) sc4[cb][g] = *reinterpret_cast<const float4*>(a.wscale + cos[cb][g]);
-        }
+    // layers (profiles/r02_conv_split_ablation.txt).  Wave tiles of three / four channel blocks (round 5) go block by block: all of
+    // them at once would hold 4 x 16 x COB registers beside the accumulators (and the allocator then spills accumulator tuples).
+    constexpr int CBB = COB >= 3 ? 1 : COB;            // channel blocks per epilogue batch
     size_t ypix[PXB], r1pix[PXB], r2pix[PXB];
     float xinv[H ? PXB : 1];                           // H: 1 / s of the pixel's sample
 #pragma unroll
@@ -799,22 +787,41 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         r1pix[pb] = ((size_t)n_ * (a.r1_H + a.r1_pad) + (y_ >> a.r1_shift)) * (a.r1_W + a.r1_pad) + (x_ >> a.r1_shift);
         r2pix[pb] = ((size_t)n_ * (a.H + a.r2_pad) + y_) * (a.W + a.r2_pad) + x_;
     }
-    float4 rv[PXB][COB][4];
+    float ymax[PXB];
+#pragma unroll
+    for (int pb = 0; pb < PXB; ++pb) ymax[pb] = 0.f;
+#pragma unroll
+    for (int cq = 0; cq < COB; cq += CBB) {
+    bool cok[CBB][4];
+    int cos[CBB][4];
+    float4 b4[CBB][4];
+    float4 sc4[H ? CBB : 1][H ? 4 : 1];                // H: 1 / (s c) of the lane's channels
+#pragma unroll
+    for (int cb = 0; cb < CBB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = (cb0 + cq + cb) * 32 + 8 * g + 4 * (lane >> 5);
+            cok[cb][g] = co < a.Cout;
+            cos[cb][g] = cok[cb][g] ? co : 0;
+            b4[cb][g] = *reinterpret_cast<const float4*>(a.bias + cos[cb][g]);
+            if constexpr (H) sc4[cb][g] = *reinterpret_cast<const float4*>(a.wscale + cos[cb][g]);
+        }
+    float4 rv[PXB][CBB][4];
     if (a.res1) {
 #pragma unroll
         for (int pb = 0; pb < PXB; ++pb)
 #pragma unroll
-            for (int cb = 0; cb < COB; ++cb)
+            for (int cb = 0; cb < CBB; ++cb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) rv[pb][cb][g] = *reinterpret_cast<const float4*>(a.res1 + r1pix[pb] * a.Cout + cos[cb][g]);
     }
 #pragma unroll
     for (int pb = 0; pb < PXB; ++pb)
 #pragma unroll
-        for (int cb = 0; cb < COB; ++cb)
+        for (int cb = 0; cb < CBB; ++cb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x16 cc = acc[cb][pb];
+                const f32x16 cc = acc[cq + cb][pb];
                 const float4 b = b4[cb][g];
                 float4 v;
                 if constexpr (H) {       // (the products with powers of two are exact: the fma rounds once, like the add)
@@ -835,19 +842,17 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
 #pragma unroll
         for (int pb = 0; pb < PXB; ++pb)
 #pragma unroll
-            for (int cb = 0; cb < COB; ++cb)
+            for (int cb = 0; cb < CBB; ++cb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const float4 r = *reinterpret_cast<const float4*>(a.res2 + r2pix[pb] * a.Cout + cos[cb][g]);
                     rv[pb][cb][g].x += r.x; rv[pb][cb][g].y += r.y; rv[pb][cb][g].z += r.z; rv[pb][cb][g].w += r.w;
                 }
     }
-    float ymax[PXB];
 #pragma unroll
     for (int pb = 0; pb < PXB; ++pb) {
-        ymax[pb] = 0.f;
 #pragma unroll
-        for (int cb = 0; cb < COB; ++cb)
+        for (int cb = 0; cb < CBB; ++cb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4 v = rv[pb][cb][g];
@@ -858,6 +863,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
                 }
             }
     }
+    }   // channel-block batches
     if (a.y_amax) {          // the consumer is a fp16-form convolution: max |y| per sample of what was stored (pp_amax.h)
         int wg_first = n, wg_last = n;                 // samples of the workgroup's pixels
         if (a.mode != MODE_TILE) {
@@ -2154,7 +2160,16 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         }
         return PP_OK;
     }
-    const int cob = (s.ncb & 1) ? 1 : 2;
+    // channel blocks (32 output channels) per wave = per workgroup column.  fp16 form, 4-wave ring kernels: THREE where the block
+    // count allows and enough workgroups remain (96 / 192 channels of HRNet-W48): 10 fragment reads per 18 MFMAs and wave instead
+    // of 6 per 6 (96 channels ran with ONE block per workgroup: three columns, each staging the patch again) or 8 per 12.
+    // Same-box A/B (profile_net w48 128): 96 -> 96 at 48x36 292 -> 315 TFLOP/s, 192 -> 192 at 24x18 328 -> 349; 384 -> 384 at 12x9
+    // LOSES (296 -> 227: 308 workgroups on 512 slots) -- hence the workgroup floor below.  FOUR blocks (128 accumulator registers + two
+    // weight register sets of 32) spill inside the K loop: 256 -> 256 at 160x272 442 -> 215 TFLOP/s -- not instantiated.
+    static const int cob_env = env_int("POSEPIPE_SPLIT_COB", 0);
+    const bool cob_wide_ok = a.split_f16 != 0 && mode != MODE_GEMM && !split_c48(a);
+    int cob = (s.ncb & 1) ? 1 : 2;
+    if (cob_wide_ok && s.ncb % 3 == 0 && (cob_env == 0 || cob_env == 3)) cob = 3;
     static const int stream_env = env_int("POSEPIPE_SPLIT_STREAM", -1);
     static const int nw8_min_blocks = env_int("POSEPIPE_SPLIT_NW8_MIN_BLOCKS", 512), nw8_min_chunks = env_int("POSEPIPE_SPLIT_NW8_MIN_CHUNKS", 16);
     unsigned gx = 0;
@@ -2205,6 +2220,11 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         nw = 4;
     }
     const int nslot = (s.NP + 16 * nw - 1) / (16 * nw);     // exactly: only the last patch slot of a thread can be partly outside
+    // (three / four blocks per wave exist for the 4-wave ring kernels only: back to one / two where that form does not apply)
+    static const int ring4_env0 = env_int("POSEPIPE_SPLIT_RING4", 1);
+    if (cob >= 3 && !(ring4_env0 && nw == 4 && (size_t)xp * 2 * s.NPp * 16 + (size_t)4 * cob * wpl * 1024 <= 80 * 1024 &&
+                      (cob_env == 3 || (long)gx * (s.ncb / cob) >= 400)))
+        cob = (s.ncb & 1) ? 1 : 2;
     dim3 grid(gx, (unsigned)(s.ncb / cob));
     s.gx = (int)grid.x; s.gy = (int)grid.y;
     if (s.xcd_remap) grid = dim3((unsigned)((s.gx + 7) / 8 * 8 * s.gy), 1);
@@ -2255,6 +2275,14 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         else                                                                                                            \
             hipLaunchKernelGGL((conv_split_kernel<T_, NS_, 1, 2, NW_, R4_, H_>), grid, dim3(64 * NW_), lds, stream, s); \
     } while (0)
+#define PP_SPLIT_LAUNCH_WIDE(NS_, COB_)                                                                                 \
+    do {                                                                                                                \
+        static std::once_flag once;                                                                                     \
+        std::call_once(once, [] {                                                                                       \
+            (void)hipFuncSetAttribute((const void*)conv_split_kernel<9, NS_, COB_, 2, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
+        });                                                                                                             \
+        hipLaunchKernelGGL((conv_split_kernel<9, NS_, COB_, 2, 4, true, true>), grid, dim3(256), lds, stream, s);       \
+    } while (0)
 #define PP_SPLIT_LAUNCH(T_, NS_, NW_, R4_)                                                                              \
     do {                                                                                                                \
         if (f16) PP_SPLIT_LAUNCH_H(T_, NS_, NW_, R4_, true);                                                            \
@@ -2265,6 +2293,11 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     else if (nw == 8) {
         if (nslot <= 5) PP_SPLIT_LAUNCH(9, 5, 8, false);
         else PP_SPLIT_LAUNCH(9, 6, 8, false);
+    } else if (ring4 && cob == 3) {
+        if (nslot <= 5) PP_SPLIT_LAUNCH_WIDE(5, 3);
+        else if (nslot == 6) PP_SPLIT_LAUNCH_WIDE(6, 3);
+        else if (nslot == 7) PP_SPLIT_LAUNCH_WIDE(7, 3);
+        else PP_SPLIT_LAUNCH_WIDE(8, 3);
     } else if (ring4) {
         if (nslot <= 5) PP_SPLIT_LAUNCH(9, 5, 4, true);
         else if (nslot == 6) PP_SPLIT_LAUNCH(9, 6, 4, true);

@@ -157,6 +157,10 @@ def build_image_program(sd: dict, hp: int, wp: int, prefix="detector.") -> Progr
     w_rpn = np.concatenate([sd[p + "rpn_head.rpn_cls.weight"], sd[p + "rpn_head.rpn_reg.weight"]], axis=0)
     b_rpn = np.concatenate([sd[p + "rpn_head.rpn_cls.bias"], sd[p + "rpn_head.rpn_reg.bias"]], axis=0)
     assert w_rpn.shape[:2] == (15, 256)
+    # a zero 16th output channel: every channel of the 16-channel map is WRITTEN (reproducible buffer dumps, whole float4 stores);
+    # rpn_select never reads it
+    w_rpn = np.concatenate([w_rpn, np.zeros((1,) + w_rpn.shape[1:], w_rpn.dtype)], axis=0)
+    b_rpn = np.concatenate([b_rpn, np.zeros(1, b_rpn.dtype)], axis=0)
     for l, f in enumerate(outs):
         h, w, _ = pb.dims(f)
         t = cbias(f, "rpn_head.rpn_conv", pad=1, relu=R)
