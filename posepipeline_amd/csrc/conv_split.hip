@@ -445,7 +445,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     };
     // weights: fragment (step, channel block cb, plane) at ((step * ncb + cb) * 3 + plane) * 64 + lane, step = chunk * T + tap
     const uint4* wlane = a.w + (size_t)cb0 * WPL * 64 + lane;
-    uint4 wf[2][COB][WPL];
+    // two register sets of weight fragments (step s + 1 is read while step s multiplies); FOUR channel blocks per wave have room for one
+    // only: its fragments of step s + 1 are read behind the last MFMA of step s, in front of the closing barrier
+    constexpr int WSETS = COB >= 4 ? 1 : 2;
+    uint4 wf[WSETS][COB][WPL];
     uint4 xf[PXB][XP];
     const uint4* wp = wlane;                           // weights of the next step to fetch (one spare step at the end of the buffer)
     auto load_w = [&](uint4 (&dst)[COB][WPL]) {
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
                         if (more_patch) store_patch((c + 1) & 1, 0, NSLOT);
                         issue_w(st + 3);
                     }
-                    mma(wf[cur], pb);
+                    mma(wf[cur % WSETS], pb);
                     __builtin_amdgcn_sched_barrier(0);
                     if (pb == 0) {
                         // (round 4) the next step's fragment reads and the DMA request sit BEHIND the first MFMAs of the step: straight
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
                         // TFLOP/s, 80x136 227 -> 233, 40x68 221 -> 228, HRNet 192 -> 192 179 -> 189.  Moving the BARRIER itself behind the
                         // first MFMA group as well (the group needs nothing the barrier guarantees) measured no further gain (260 vs 260):
                         // the loop runs at the chip's power limit there, a saved cycle comes back as a lower clock.
-                        if (st + 1 < nsteps) read_w(st + 1, wf[cur ^ 1]);
+                        if (st + 1 < nsteps) read_w(st + 1, wf[(cur ^ 1) % WSETS]);
                         if (t != T / 2) issue_w(st + 3);
                     }
                     if (t + 1 < T) load_x(pbuf, t + 1, pb);
@@ -667,15 +670,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
                         issue_w(st + 3);
                         if (c + 2 < a.nchunks) load_patch(c + 2);
                     }
-                    mma(wf[cur], pb);
+                    mma(wf[cur % WSETS], pb);
                     __builtin_amdgcn_sched_barrier(0);
                     if (pb == 0) {       // behind the first MFMAs of the step, see chunk8
-                        if (st + 1 < nsteps) read_w(st + 1, wf[cur ^ 1]);
+                        if (WSETS == 2 && st + 1 < nsteps) read_w(st + 1, wf[(cur ^ 1) % WSETS]);
                         if (t != T - 1) issue_w(st + 3);
                     }
                     if (t + 1 < T) load_x(smem, t + 1, pb);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (WSETS == 1 && st + 1 < nsteps) read_w(st + 1, wf[0]);
                 {
                     // closing barrier: the DMA of step st + 2 has landed.  Younger: the DMA(s) of st + 3, and the patch loads of the
                     // next-but-one chunk where they were issued after it -- in tap T - 1 (this step) and, seen from tap 0, in the
@@ -721,7 +725,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         for (int t = 0; t < T; ++t) {
             const int cur = (PAR + t) & 1;
 #if !(PP_SPLIT_ABLATE & 1)
-            load_w(wf[cur ^ 1]);
+            load_w(wf[(cur ^ 1) % WSETS]);
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -733,7 +737,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
                 if (pb == PXB - 1 && t == T / 2 && c + 1 < a.nchunks) store_patch((c + 1) & 1, 0, NSLOT);
 #endif
 #if !(PP_SPLIT_ABLATE & 16)
-                mma(wf[(PP_SPLIT_ABLATE & 1) ? 0 : cur], pb);
+                mma(wf[(PP_SPLIT_ABLATE & 1) ? 0 : cur % WSETS], pb);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
 #if !(PP_SPLIT_ABLATE & 8)
@@ -2164,12 +2168,15 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     // count allows and enough workgroups remain (96 / 192 channels of HRNet-W48): 10 fragment reads per 18 MFMAs and wave instead
     // of 6 per 6 (96 channels ran with ONE block per workgroup: three columns, each staging the patch again) or 8 per 12.
     // Same-box A/B (profile_net w48 128): 96 -> 96 at 48x36 292 -> 315 TFLOP/s, 192 -> 192 at 24x18 328 -> 349; 384 -> 384 at 12x9
-    // LOSES (296 -> 227: 308 workgroups on 512 slots) -- hence the workgroup floor below.  FOUR blocks (128 accumulator registers + two
-    // weight register sets of 32) spill inside the K loop: 256 -> 256 at 160x272 442 -> 215 TFLOP/s -- not instantiated.
+    // LOSES (296 -> 227: 308 workgroups on 512 slots) -- hence the workgroup floor below.  FOUR blocks (128, 256, 512 channels: the
+    // detector's 3x3 layers; 12 reads per 24 MFMAs, half the patch staging per output): 128 accumulator registers leave room for ONE
+    // weight register set (WSETS; with two the K loop spilled: 442 -> 215 TFLOP/s) -- 256 -> 256 at 160x272 429 -> 455 TFLOP/s,
+    // 80x136 409 -> 426, 40x68 386 -> 394.
     static const int cob_env = env_int("POSEPIPE_SPLIT_COB", 0);
     const bool cob_wide_ok = a.split_f16 != 0 && mode != MODE_GEMM && !split_c48(a);
     int cob = (s.ncb & 1) ? 1 : 2;
     if (cob_wide_ok && s.ncb % 3 == 0 && (cob_env == 0 || cob_env == 3)) cob = 3;
+    else if (cob_wide_ok && s.ncb % 4 == 0 && (cob_env == 0 || cob_env == 4)) cob = 4;
     static const int stream_env = env_int("POSEPIPE_SPLIT_STREAM", -1);
     static const int nw8_min_blocks = env_int("POSEPIPE_SPLIT_NW8_MIN_BLOCKS", 512), nw8_min_chunks = env_int("POSEPIPE_SPLIT_NW8_MIN_CHUNKS", 16);
     unsigned gx = 0;
@@ -2223,7 +2230,7 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     // (three / four blocks per wave exist for the 4-wave ring kernels only: back to one / two where that form does not apply)
     static const int ring4_env0 = env_int("POSEPIPE_SPLIT_RING4", 1);
     if (cob >= 3 && !(ring4_env0 && nw == 4 && (size_t)xp * 2 * s.NPp * 16 + (size_t)4 * cob * wpl * 1024 <= 80 * 1024 &&
-                      (cob_env == 3 || (long)gx * (s.ncb / cob) >= 400)))
+                      (cob_env >= 3 || (long)gx * (s.ncb / cob) >= 400)))
         cob = (s.ncb & 1) ? 1 : 2;
     dim3 grid(gx, (unsigned)(s.ncb / cob));
     s.gx = (int)grid.x; s.gy = (int)grid.y;
@@ -2298,6 +2305,11 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         else if (nslot == 6) PP_SPLIT_LAUNCH_WIDE(6, 3);
         else if (nslot == 7) PP_SPLIT_LAUNCH_WIDE(7, 3);
         else PP_SPLIT_LAUNCH_WIDE(8, 3);
+    } else if (ring4 && cob == 4) {
+        if (nslot <= 5) PP_SPLIT_LAUNCH_WIDE(5, 4);
+        else if (nslot == 6) PP_SPLIT_LAUNCH_WIDE(6, 4);
+        else if (nslot == 7) PP_SPLIT_LAUNCH_WIDE(7, 4);
+        else PP_SPLIT_LAUNCH_WIDE(8, 4);
     } else if (ring4) {
         if (nslot <= 5) PP_SPLIT_LAUNCH(9, 5, 4, true);
         else if (nslot == 6) PP_SPLIT_LAUNCH(9, 6, 4, true);
