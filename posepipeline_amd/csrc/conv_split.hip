@@ -897,7 +897,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
 // Weights: [chunk][pair][16-channel block][plane][lane] x 16 B (split_weights48_kernel), read per wave one step ahead.
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-template <int NSLOT, bool H = false>
+// WRING (round 5, fp16 form): the split weights through a 4-slot LDS ring filled by the DMA path three pair-steps ahead (as the
+// 4-wave ring form of conv_split_kernel), one barrier per pair-step.  Why: with per-wave fragment loads one step ahead a pair-step
+// (36 MFMAs of 16 cycles) could not be shorter than an L2 round trip -- the 15 steps of a 48 -> 48 tile took ~15 us for ~4 us of MFMAs.
+template <int NSLOT, bool H = false, bool WRING = false>
 __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
     constexpr int NT = 256, NPAIR = 5, CB = 3, SB = 4;
     constexpr int XP = H ? 2 : 3;                     // activation planes (H: the fp16 form, see conv_split_kernel)
@@ -994,10 +997,45 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
             for (int pl = 0; pl < WPL; ++pl) dst[cb][pl] = wp[(cb * WPL + pl) * 64];
         wp += wstep;
     };
+    // ring form: slot (step & 3) of the ring behind the two patch buffers holds the CB x WPL fragments of step = chunk * 5 + pair
+    constexpr int WSLOT = CB * WPL * 1024, NDMA = (CB * WPL + 3) / 4;
+    const int nsteps = a.nchunks * NPAIR;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned wring = (unsigned)(2 * buf_bytes);
+    auto issue_w = [&](int step) {
+        if (step >= nsteps) return;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const int myslab = (wave + 4 * i) % (CB * WPL);      // (waves past CB * WPL copy a duplicate: same bytes, same place)
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + wring + (unsigned)((step & 3) * WSLOT + myslab * 1024));
+            const uint4* g = a.w + (size_t)cbase * WPL * 64 + myslab * 64 + lane + (size_t)step * wstep;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(dst) : "memory", "m0");
+        }
+    };
+    auto read_w = [&](int step, uint4 (&dst)[CB][WPL]) {
+        const unsigned char* base = smem + wring + (step & 3) * WSLOT + lane * 16;
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int pl = 0; pl < WPL; ++pl) dst[cb][pl] = *reinterpret_cast<const uint4*>(base + (cb * WPL + pl) * 1024);
+    };
+    auto wait_all_but = [&](int n) {      // allow `n` (0, NDMA, NSLOT, NSLOT + NDMA) of the youngest vector-memory operations to stay in flight
+        if (n == NSLOT + NDMA) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSLOT + NDMA) : "memory");
+        else if (n == NSLOT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NSLOT) : "memory");
+        else if (n == NDMA) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
     // ---- the first requests ---------------------------------------------------------------------------------------------------------
     PP_TL_MARK(4);
-    load_patch(0);
-    load_w(wf[0]);
+    if constexpr (WRING) {
+        issue_w(0);
+        issue_w(1);
+        issue_w(2);
+        load_patch(0);
+    } else {
+        load_patch(0);
+        load_w(wf[0]);
+    }
     unsigned xam[H ? NSLOT : 1];                      // (requested with the first loads, consumed behind the index arithmetic)
     if constexpr (H) {
 #pragma unroll
@@ -1086,10 +1124,16 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) sx[j] = pp_act_scale(xam[j]);
     }
-    store_patch(0);              // (patch 0 and the first weights were requested above)
+    store_patch(0);              // (patch 0 and the first weights were requested above; ring form: waits, in order, for the DMAs as well)
     PP_TL_MARK(5);
     if (a.nchunks > 1) load_patch(1);
-    __syncthreads();
+    if constexpr (WRING) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        read_w(0, wf[0]);
+    } else {
+        __syncthreads();
+    }
     load_x(smem, 0, 0);
     // ---- K loop: 5 pair-steps per 16-channel chunk (odd: the weight register sets swap roles from chunk to chunk) -------------------
     auto chunk = [&](auto par, int c) {
@@ -1115,13 +1159,55 @@ __global__ __launch_bounds__(256, 2) void conv_split48_kernel(SplitArgs a) {
         if (c + 1 < a.nchunks) load_x(smem + ((c + 1) & 1) * buf_bytes, 0, 0);
         if (c + 2 < a.nchunks) load_patch(c + 2);
     };
+    // ring form.  Order of the vector-memory operations (vmcnt is in issue order): step st issues the DMA of step st + 3 behind its first
+    // sub-block -- in the middle step of a chunk (q = 2) behind the patch store instead (the compiler's wait for the staged patch must
+    // not cover a younger DMA), followed by the loads of the patch after next.  The closing barrier of step st needs the DMA of st + 2
+    // (issued in step st - 1) landed: younger are the DMA of st + 3 and, in steps q = 2 / 3, those patch loads.
+    auto chunk_ring = [&](auto par, int c) {
+        constexpr int PAR = decltype(par)::value;
+        const unsigned char* pbuf = smem + (c & 1) * buf_bytes;
+#pragma unroll
+        for (int q = 0; q < NPAIR; ++q) {
+            const int cur = (PAR + q) & 1;
+            const int st = c * NPAIR + q;
+#pragma unroll
+            for (int sb = 0; sb < SB; ++sb) {
+                if (sb == SB - 1 && q == NPAIR / 2) {
+                    if (c + 1 < a.nchunks) store_patch((c + 1) & 1);
+                    issue_w(st + 3);
+                    if (c + 2 < a.nchunks) load_patch(c + 2);
+                }
+                if (sb + 1 < SB) load_x(pbuf, q, sb + 1);
+                else if (q + 1 < NPAIR) load_x(pbuf, q + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(wf[cur], sb);
+                __builtin_amdgcn_sched_barrier(0);
+                if (sb == 0) {
+                    if (st + 1 < nsteps) read_w(st + 1, wf[cur ^ 1]);
+                    if (q != NPAIR / 2) issue_w(st + 3);
+                }
+            }
+            const int younger = (st + 3 < nsteps ? NDMA : 0) + (((q == NPAIR / 2 || q == NPAIR / 2 + 1) && c + 2 < a.nchunks) ? NSLOT : 0);
+            wait_all_but(younger);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (c + 1 < a.nchunks) load_x(smem + ((c + 1) & 1) * buf_bytes, 0, 0);
+    };
     PP_TL_MARK(1);
     int c = 0;
     for (; c + 1 < a.nchunks; c += 2) {           // 5 steps per chunk: the register-set parity alternates per chunk
-        chunk(std::integral_constant<int, 0>{}, c);
-        chunk(std::integral_constant<int, 1>{}, c + 1);
+        if constexpr (WRING) {
+            chunk_ring(std::integral_constant<int, 0>{}, c);
+            chunk_ring(std::integral_constant<int, 1>{}, c + 1);
+        } else {
+            chunk(std::integral_constant<int, 0>{}, c);
+            chunk(std::integral_constant<int, 1>{}, c + 1);
+        }
     }
-    if (c < a.nchunks) chunk(std::integral_constant<int, 0>{}, c);
+    if (c < a.nchunks) {
+        if constexpr (WRING) chunk_ring(std::integral_constant<int, 0>{}, c);
+        else chunk(std::integral_constant<int, 0>{}, c);
+    }
     PP_TL_MARK(2);
     // ---- epilogue: accumulator register i of a lane = channel 16 cb + 4 (lane >> 4) + i of pixel (lane & 15) -------------------------
     bool cok[CB];
@@ -2242,16 +2328,22 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         if (s.xcd_remap) grid = dim3((unsigned)((s.gx + 7) / 8 * 8 * s.gy), 1);
         else grid = dim3(gx, (unsigned)s.gy);
         fill_divisors(s);
-        const size_t lds48 = (size_t)2 * xp * 2 * s.NPp * 16;
+        // fp16 form: weights through a 4-slot LDS ring (3 blocks x 2 planes = 6 KB per pair-step) where patch + ring leave two workgroups per CU
+        static const int ring48_env = env_int("POSEPIPE_SPLIT_RING48", 1);
+        const size_t patch48 = (size_t)2 * xp * 2 * s.NPp * 16;
+        const bool ring48 = f16 && ring48_env && patch48 + (size_t)4 * 3 * wpl * 1024 <= 80 * 1024;
+        const size_t lds48 = patch48 + (ring48 ? (size_t)4 * 3 * wpl * 1024 : 0);
 #define PP_SPLIT48_LAUNCH(NS_)                                                                                          \
     do {                                                                                                                \
         static std::once_flag once;                                                                                     \
         std::call_once(once, [] {                                                                                       \
-            (void)hipFuncSetAttribute((const void*)conv_split48_kernel<NS_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
-            (void)hipFuncSetAttribute((const void*)conv_split48_kernel<NS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_split48_kernel<NS_, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_split48_kernel<NS_, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
+            (void)hipFuncSetAttribute((const void*)conv_split48_kernel<NS_, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
         });                                                                                                             \
-        if (f16) hipLaunchKernelGGL((conv_split48_kernel<NS_, true>), grid, dim3(256), lds48, stream, s);               \
-        else hipLaunchKernelGGL((conv_split48_kernel<NS_, false>), grid, dim3(256), lds48, stream, s);                  \
+        if (ring48) hipLaunchKernelGGL((conv_split48_kernel<NS_, true, true>), grid, dim3(256), lds48, stream, s);      \
+        else if (f16) hipLaunchKernelGGL((conv_split48_kernel<NS_, true, false>), grid, dim3(256), lds48, stream, s);   \
+        else hipLaunchKernelGGL((conv_split48_kernel<NS_, false, false>), grid, dim3(256), lds48, stream, s);           \
     } while (0)
         if (nslot <= 5) PP_SPLIT48_LAUNCH(5);
         else if (nslot == 6) PP_SPLIT48_LAUNCH(6);
