@@ -294,7 +294,9 @@ def process_video_sharded(dist, n_frames, chunks_fn, detect_fn, associate_fn, to
                 first, n, handle = next(it2)
                 while first + n <= job_frames[ks].min():       # chunks without a person-frame are passed over (see `need`)
                     first, n, handle = next(it2)
-                assert handle is not None and ((job_frames[ks] >= first) & (job_frames[ks] < first + n)).all()
+                assert handle is not None, ("chunks_fn yielded a None handle for a chunk that holds person-frames of this rank: a source may "
+                                            "return (first, n, None) ONLY for chunks whose `need` entry is False (see the docstring)")
+                assert ((job_frames[ks] >= first) & (job_frames[ks] < first + n)).all()
                 idx = (job_frames[ks] - first).astype(np.int32)
                 boxes = np.array([jobs[i][2] for i in ks], np.float64)
                 rows_k = np.asarray(topdown_fn(handle, n, idx, boxes), np.float32).reshape(len(ks), -1)
