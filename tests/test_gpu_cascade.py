@@ -269,3 +269,42 @@ def test_cascade_with_default_tracking_method(ctx):
     for i in range(4):
         assert np.abs(k2[i][:, :2] - ref2[i][:, :2]).max() <= 1e-3
     assert np.array_equal(out[2]["keypoints_3d"][tid], reference_3d(k2, 0, 4, w, h, lift_sd))
+
+
+def test_cascade_steady_state_keeps_device_memory_flat(ctx):
+    """A long-running cascade (tracks born and lost all the time: every 96 frames the person jumps to another place, so a new id
+    and a new person stream replace the old ones) must not grow: device memory in use after 12 chunks equals the level after 4
+    (hipMemGetInfo of the runtime the library itself is linked to; one allocation granule of slack), and no person stream outlives its track's lifting tail."""
+    import ctypes
+
+    from posepipeline_amd.cascade import Cascade
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def device_bytes_in_use():
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return total.value - free.value
+    rng = np.random.default_rng(5)
+    h, w, chunk, steps = 135, 240, 32, 12
+    base = np.stack([synth_frame(rng, h, w) for _ in range(4)])
+    det_sd, pose_spec, pose_sd, lift_sd = _setup(h, w)
+    cas = Cascade(ctx, det_sd, pose_sd, lift_sd, h, w, chunk=chunk, max_persons=2, pose_spec=pose_spec)
+
+    def boxes(t):
+        x = 15.0 + 90.0 * ((t // 96) % 2)                 # two places 90 px apart: no IoU between them -> a new track
+        return np.array([[x, 20, x + 60, 120, 0.9]], np.float32)
+
+    used, ids, live = [], set(), []
+    for k in range(steps):
+        fr_ = base[(np.arange(chunk) + k) % 4]
+        o = cas.step(fr_, replay=[boxes(k * chunk + i) for i in range(chunk)])
+        ids |= {r[0] for f in o["tracks"] for r in f}
+        ctx.synchronize()
+        used.append(device_bytes_in_use())
+        live.append(len(cas.persons.streams))
+    cas.flush()
+    assert len(ids) >= 3, ids                             # the scenario did create and retire tracks
+    assert max(live) <= 3, live                           # a retired track's stream is closed once its last 3D frames left
+    assert not cas.persons.streams
+    assert abs(used[-1] - used[3]) <= 2 << 20, [u >> 20 for u in used]
+    assert max(used[3:]) - min(used[3:]) <= 8 << 20, [u >> 20 for u in used]
