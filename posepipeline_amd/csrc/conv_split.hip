@@ -1964,7 +1964,225 @@ TileGeom pick_tile(int H, int W, int max_np, int pxb) {
     return best;
 }
 
+// ---- the 7x7 / stride 2 / 4 -> 64 stem (ResNet-50 conv1), fp16 form ---------------------------------------------------------------------
+// The float32 matrix kernels run this layer at 0.46 of THEIR peak (73 TFLOP/s) while it writes 2.85 GB per 64 frames: as a split product
+// it is bound by that write.  K is walked as (dy, dx8, c) with the 7 taps of a row padded to 8 (the eighth has zero weights):
+// K = 7 x 8 x 4 = 224 = 14 steps of 16, and the 8 k-values of a lane's fragment are TWO ADJACENT INPUT PIXELS x 4 channels -- with the patch
+// held as two float16 planes of 8 B per pixel (h0, h1: split once at staging, as in the tap kernels) that is ONE aligned ds_read_b128
+// per plane, 16 B apart between neighbouring output pixels (stride 2): conflict-free without a swizzle.
+// Persistent workgroups (one per CU, 8 waves): all split weights (14 x 2 x 2 KB = 56 KB) stay in LDS, the patch is double-buffered
+// (tile t + 1 is requested at the start of tile t and written half-way), tile = 16 x 32 outputs x 64 channels, a wave = 2 rows.
+// Epilogue through the patch buffer the tile just left: [32 px][32 ch] per (row, channel block), whole 128-byte lines to memory.
+struct StemArgs {
+    const float* x;
+    const uint4* w;
+    const float* wscale;
+    const float* bias;
+    float* y;
+    const unsigned* x_amax;
+    unsigned* y_amax;
+    int N, Hin, Win, xp_h, xp_w, Hout, Wout, y_pad, relu;
+    int tiles_x, tiles_y, ntiles;
+    unsigned dv_tx[2], dv_ty[2];
+    unsigned x_bytes;
+};
+constexpr int STEM_TH = 16, STEM_TW = 32, STEM_PH = 2 * STEM_TH + 5, STEM_PW = 72, STEM_STEPS = 14;
+constexpr int STEM_PLANE = STEM_PH * STEM_PW * 8, STEM_BUF = 2 * STEM_PLANE, STEM_WBYTES = STEM_STEPS * 2 * 2 * 1024;
+constexpr int STEM_SLOTS = (STEM_PH * STEM_PW + 511) / 512;
+constexpr int STEM_LDS = STEM_WBYTES + 2 * STEM_BUF + 256;
+
+__global__ __launch_bounds__(512, 1) void conv_split_stem7_kernel(StemArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const wl = smem;
+    unsigned char* const pbase = smem + STEM_WBYTES;
+    float* const red = reinterpret_cast<float*>(smem + STEM_WBYTES + 2 * STEM_BUF);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int px = lane & 31, hk = lane >> 5;
+
+    // weights -> LDS, once
+    for (int i = tid; i < STEM_WBYTES / 16; i += 512) reinterpret_cast<uint4*>(wl)[i] = a.w[i];
+
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+    float4 xr[STEM_SLOTS];
+    int tn = 0, ty0 = 0, tx0 = 0;                     // tile being requested / staged
+    auto locate = [&](int t, int& n, int& y0, int& x0) {
+        const unsigned q = pp_udiv((unsigned)t, a.dv_tx);
+        x0 = (int)((unsigned)t - q * (unsigned)a.tiles_x) * STEM_TW;
+        n = (int)pp_udiv(q, a.dv_ty);
+        y0 = (int)(q - (unsigned)n * (unsigned)a.tiles_y) * STEM_TH;
+    };
+    auto load_patch = [&](int t) {
+        locate(t, tn, ty0, tx0);
+#pragma unroll
+        for (int j = 0; j < STEM_SLOTS; ++j) {
+            const int p = tid + 512 * j;
+            const int pr = p / STEM_PW, pc = p - pr * STEM_PW;
+            const int iy = 2 * ty0 - 3 + pr, ix = 2 * tx0 - 3 + pc;
+            const bool ok = p < STEM_PH * STEM_PW && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            const unsigned off = ok ? (unsigned)(((tn * a.xp_h + iy) * a.xp_w + ix) * 16) : 0xffffffffu;
+            xr[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
+        }
+    };
+    auto store_patch = [&](int buf, float sx) {
+#pragma unroll
+        for (int j = 0; j < STEM_SLOTS; ++j) {
+            const int p = tid + 512 * j;
+            uint2 p0, p1;
+            split4h(xr[j], sx, p0, p1);
+            if (p >= STEM_PH * STEM_PW) continue;
+            unsigned char* d = pbase + buf * STEM_BUF + p * 8;
+            *reinterpret_cast<uint2*>(d) = p0;
+            *reinterpret_cast<uint2*>(d + STEM_PLANE) = p1;
+        }
+    };
+
+    // lane constants: fragment address of output row 2 wave (pixel block 0), step 0; weight fragments; epilogue roles
+    const int xofs = ((4 * wave) * STEM_PW + 2 * px + 2 * hk) * 8;
+    const unsigned char* const wlane = wl + lane * 16;
+    const int rdrow = lane >> 3, rdc = lane & 7;
+    float bias_l[2][4], wsc_l[2][4];       // epilogue read-back role: channels cb * 32 + 4 rdc .. + 3
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + cb * 32 + 4 * rdc);
+        const float4 c = *reinterpret_cast<const float4*>(a.wscale + cb * 32 + 4 * rdc);
+        bias_l[cb][0] = b.x; bias_l[cb][1] = b.y; bias_l[cb][2] = b.z; bias_l[cb][3] = b.w;
+        wsc_l[cb][0] = c.x; wsc_l[cb][1] = c.y; wsc_l[cb][2] = c.z; wsc_l[cb][3] = c.w;
+    }
+
+    int t = blockIdx.x;
+    if (t >= a.ntiles) return;
+    load_patch(t);
+    {
+        const float sx = pp_act_scale(a.x_amax[tn]);
+        store_patch(0, sx);
+    }
+    __syncthreads();
+    int it = 0;
+    for (; t < a.ntiles; t += gridDim.x, ++it) {
+        const int buf = it & 1;
+        int n, y0, x0;
+        locate(t, n, y0, x0);
+        const unsigned am = a.x_amax[n];
+        const int tnext = t + (int)gridDim.x;
+        const bool more = tnext < a.ntiles;
+        unsigned am_next = 0;
+        if (more) {
+            load_patch(tnext);
+            am_next = a.x_amax[tn];
+        }
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
+        const unsigned char* const pl = pbase + buf * STEM_BUF + xofs;
+#pragma unroll
+        for (int s = 0; s < STEM_STEPS; ++s) {
+            if (s == STEM_STEPS / 2 && more) store_patch(buf ^ 1, pp_act_scale(am_next));
+            uint4 wf[2][2], xf[2][2];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int pn = 0; pn < 2; ++pn) wf[cb][pn] = *reinterpret_cast<const uint4*>(wlane + ((s * 2 + cb) * 2 + pn) * 1024);
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                for (int pn = 0; pn < 2; ++pn)
+                    xf[pb][pn] = *reinterpret_cast<const uint4*>(pl + pn * STEM_PLANE + ((2 * pb + (s >> 1)) * STEM_PW + (s & 1) * 4) * 8);
+            constexpr int WI[3] = {1, 0, 0}, XI[3] = {0, 1, 0};      // g1 h0 + g0 h1 + g0 h0
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[cb][WI[p]]),
+                                                                             __builtin_bit_cast(f16x8, xf[pb][XI[p]]), acc[cb][pb], 0, 0, 0);
+        }
+        __syncthreads();                 // every fragment read of `buf` is done (and the next patch is in place)
+
+        // ---- epilogue: (row, channel block) at a time through this wave's 4 KiB of the buffer the tile just left -------------------
+        const float xinv = pp_act_unscale(am);
+        unsigned char* const stg = pbase + buf * STEM_BUF + wave * 4096;
+        float ymax = 0.f;
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) {
+            const int oy = y0 + 2 * wave + pb;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = make_float4(acc[cb][pb][4 * g], acc[cb][pb][4 * g + 1], acc[cb][pb][4 * g + 2], acc[cb][pb][4 * g + 3]);
+                    *reinterpret_cast<float4*>(stg + px * 128 + (((2 * g + hk) ^ (px & 7)) << 4)) = v;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int r = r4 * 8 + rdrow, ox = x0 + r;
+                    const float4 c = *reinterpret_cast<const float4*>(stg + r * 128 + ((rdc ^ (r & 7)) << 4));
+                    float4 v = make_float4(__builtin_fmaf(c.x, wsc_l[cb][0] * xinv, bias_l[cb][0]), __builtin_fmaf(c.y, wsc_l[cb][1] * xinv, bias_l[cb][1]),
+                                           __builtin_fmaf(c.z, wsc_l[cb][2] * xinv, bias_l[cb][2]), __builtin_fmaf(c.w, wsc_l[cb][3] * xinv, bias_l[cb][3]));
+                    if (a.relu != PP_RELU_NONE) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                    if (oy < a.Hout && ox < a.Wout) {
+                        *reinterpret_cast<float4*>(a.y + (((size_t)n * (a.Hout + a.y_pad) + oy) * (a.Wout + a.y_pad) + ox) * 64 + cb * 32 + 4 * rdc) = v;
+                        ymax = fmaxf(ymax, pp_abs4max(v));
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
+        if (a.y_amax) {
+            const int img[1] = {n};
+            const float m[1] = {ymax};
+            pp_amax_commit_wg<8, 1>(a.y_amax, img, m, n, n, red);
+        }
+        __syncthreads();                 // the staging area becomes the patch after next
+    }
+}
+
+// split weights of the stem: fragment (step s, channel block cb, plane) at ((s * 2 + cb) * 2 + plane) * 64 + lane; lane = (channel
+// cb * 32 + (lane & 31), k half lane >> 5); its 8 values: k = 16 s + 8 half + j -> dy = s >> 1, dx = 4 (s & 1) + 2 half + (j >> 2), c = j & 3
+__global__ __launch_bounds__(256) void split_weights_stem7_kernel(const float* w, uint4* out, int CoutPad, const float* cmax) {
+    const int i = blockIdx.x * 256 + threadIdx.x;      // (s, cb, lane)
+    if (i >= STEM_STEPS * 2 * 64) return;
+    const int lane = i & 63, cb = (i >> 6) & 1, s = i >> 7;
+    const int cout = cb * 32 + (lane & 31);
+    unsigned short h[2][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int dy = s >> 1, dx = 4 * (s & 1) + 2 * (lane >> 5) + (j >> 2), c = j & 3;
+        float v = 0.f;
+        if (dx < 7) {
+            const int k = (dy * 7 + dx) * 4 + c;
+            v = w[((size_t)(k >> 5) * CoutPad + cout) * 32 + 8 * (k & 3) + ((k & 31) >> 2)];
+        }
+        unsigned short q2;
+        split_weight_h(v, channel_scale(cmax[cout]), h[0][j], h[1][j], q2);
+    }
+#pragma unroll
+    for (int pn = 0; pn < 2; ++pn) {
+        uint4 o;
+        o.x = h[pn][0] | ((unsigned)h[pn][1] << 16);
+        o.y = h[pn][2] | ((unsigned)h[pn][3] << 16);
+        o.z = h[pn][4] | ((unsigned)h[pn][5] << 16);
+        o.w = h[pn][6] | ((unsigned)h[pn][7] << 16);
+        out[(size_t)(((s * 2 + cb) * 2 + pn) * 64 + lane)] = o;
+    }
+}
+
 }  // namespace
+
+// ResNet-50's stem on conv_split_stem7_kernel (fp16 form only: the six-product form keeps the float32 kernels there)
+static bool split_stem7(const ConvArgs& a) {
+    static const int on = env_int("POSEPIPE_SPLIT_STEM7", 1);
+    const bool f16 = a.split_f16 != 0 || (a.numerics == 0 && pp_conv_split_f16_default());
+    return on && f16 && a.KH == 7 && a.KW == 7 && a.stride == 2 && a.pad_h == 3 && a.pad_w == 3 && a.dil_h == 1 && a.dil_w == 1 &&
+           a.Cin == 4 && a.Cout == 64 && a.CoutPad >= 64 && a.up_log2 == 0 && !a.out_nchw && !a.res1 && !a.res2 &&
+           (a.relu == PP_RELU_NONE || a.relu == PP_RELU_FIRST || a.relu == PP_RELU_LAST) && (a.y_stride == 0 || a.y_stride == a.Cout) &&
+           a.y_coff == 0 && a.Hout == (a.Hin - 1) / 2 + 1 && a.Wout == (a.Win - 1) / 2 + 1;
+}
 
 // how the split kernel sees the layer: taps (9 / 1) and channels per tap (a full-cover 'valid' conv is a 1x1 over KH*KW*Cin)
 // committed: the layer was selected when its split weights were built (pp_net_create_ex / the caller of pp_conv_split_eligible), so
@@ -2013,6 +2231,7 @@ bool pp_conv_split_eligible(const ConvArgs& a) {
                                         ((a.Hout - 1) >> a.res1_shift) < a.res1_H && ((a.Wout - 1) >> a.res1_shift) < a.res1_W &&
                                         (a.res1_shift > 0 || (a.res1_H == a.Hout && a.res1_W == a.Wout)));
     int taps, cin, mode;
+    if (split_stem7(a)) return true;
     // 1x1 layers with Cout % 128 == 0: the 8-wave product kernel.  Others: the tap kernel's one-tap form wins from ~1024 input
     // channels only (its 256 x 64 tile re-reads X Cout / 64 times; below, the fp32 kernel's smaller tiles do as well or better).
     static const int gemm_min_cin = env_int("POSEPIPE_SPLIT_GEMM_MIN_CIN", 1024);
@@ -2038,6 +2257,7 @@ static size_t split_frag_bytes(const ConvArgs& a, bool committed = false) {
     int taps = 1, cin = a.Cin, mode = 0;
     split_shape(a, &taps, &cin, &mode, committed);      // (committed: at launch the form is the one the split copy was built for)
     const size_t wpl = a.split_f16 ? 2 : 3;              // weight planes: (g0, g1) of the fp16 form, three bf16 planes
+    if (split_stem7(a)) return STEM_WBYTES;
     if (split_c48(a)) return ((size_t)(cin / 16) * 5 + 1) * split_ncb16(a) * wpl * 64 * sizeof(uint4);
     return ((size_t)(cin / 16) * taps + 1) * split_ncb(a) * wpl * 64 * sizeof(uint4);      // + one spare step: the kernel fetches one step ahead
 }
@@ -2058,6 +2278,15 @@ int pp_conv_split_weights(const ConvArgs& a, void* out, hipStream_t stream) {
         inv_scale = reinterpret_cast<float*>(static_cast<unsigned char*>(out) + split_frag_bytes(a));
         cmax = inv_scale + nout;
         hipLaunchKernelGGL(weight_channel_max_kernel, dim3((unsigned)nout), dim3(64), 0, stream, a.w, a.Kpad / 32, a.CoutPad, nout, cmax, inv_scale);
+    }
+    if (split_stem7(a)) {
+        hipLaunchKernelGGL(split_weights_stem7_kernel, dim3((STEM_STEPS * 2 * 64 + 255) / 256), dim3(256), 0, stream, a.w, (uint4*)out, a.CoutPad, cmax);
+        hipError_t es = hipGetLastError();
+        if (es != hipSuccess) {
+            pp_set_error("split_weights_stem7 launch failed: %s", hipGetErrorString(es));
+            return PP_ERR_HIP;
+        }
+        return PP_OK;
     }
     if (split_c48(a)) {
         const size_t total48 = (size_t)(cin / 16) * 5 * split_ncb16(a) * 64;
@@ -2173,8 +2402,43 @@ static void fill_divisors(SplitArgs& s) {
     make_magic((unsigned)std::max(s.KW, 1), s.dv_kw);
 }
 
+static int launch_stem7(const ConvArgs& a, hipStream_t stream) {
+    if (!a.x_amax) {
+        pp_set_error("conv_split: the fp16 form needs the per-sample maximum of its input (ConvArgs::x_amax)");
+        return PP_ERR_STATE;
+    }
+    StemArgs s{};
+    s.x = a.x; s.w = (const uint4*)a.wsplit; s.bias = a.bias; s.y = a.y;
+    s.wscale = reinterpret_cast<const float*>(static_cast<const unsigned char*>(a.wsplit) + STEM_WBYTES);
+    s.x_amax = a.x_amax; s.y_amax = a.y_amax;
+    s.N = a.N; s.Hin = a.Hin; s.Win = a.Win; s.xp_h = a.Hin + a.x_pad; s.xp_w = a.Win + a.x_pad;
+    s.Hout = a.Hout; s.Wout = a.Wout; s.y_pad = a.y_pad; s.relu = a.relu;
+    s.tiles_x = (a.Wout + STEM_TW - 1) / STEM_TW;
+    s.tiles_y = (a.Hout + STEM_TH - 1) / STEM_TH;
+    s.ntiles = a.N * s.tiles_x * s.tiles_y;
+    s.x_bytes = a.x_bytes;
+    make_magic((unsigned)s.tiles_x, s.dv_tx);
+    make_magic((unsigned)s.tiles_y, s.dv_ty);
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    static std::once_flag once;
+    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)conv_split_stem7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS); });
+    const unsigned grid = (unsigned)std::min(s.ntiles, ncu);
+    hipLaunchKernelGGL(conv_split_stem7_kernel, dim3(grid), dim3(512), STEM_LDS, stream, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        pp_set_error("conv_split_stem7 launch failed: %s", hipGetErrorString(e));
+        return PP_ERR_HIP;
+    }
+    return PP_OK;
+}
+
 int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     int taps = 1, cin = a.Cin, mode = 0;
+    if (a.wsplit && split_stem7(a)) return launch_stem7(a, stream);
     if (!a.wsplit || !split_shape(a, &taps, &cin, &mode, true)) {
         pp_set_error("conv_split: layer not eligible");
         return PP_ERR_ARG;

@@ -41,7 +41,7 @@ struct DetFpnArgs {
 };
 
 int det_enqueue_preprocess(hipStream_t s, const uint8_t* frames, int n_frames, int H, int W, int nh, int nw, int Hp,
-                           int Wp, const int32_t* xtab, const int32_t* ytab, const float* lut, float pad_val, float* out);
+                           int Wp, const int32_t* xtab, const int32_t* ytab, const float* lut, float pad_val, float* out, unsigned* amax = nullptr);
 int det_enqueue_rpn(hipStream_t s, const DetRpnArgs& a, int n_frames);
 int det_enqueue_gather(hipStream_t s, const float* boxes, const float* scores, int max_n, const int32_t* keep,
                        const int32_t* n_keep, int limit, float* out_box, float* out_score, int32_t* n_out, int out5,

@@ -11,6 +11,7 @@
 
 #include "pp_internal.h"
 #include "det_internal.h"
+#include "pp_amax.h"
 
 int pp_net_dims(pp_net* net, int buf, int* h, int* w, int* c);
 int pp_net_max_batch(pp_net* net);
@@ -22,6 +23,7 @@ struct pp_detector {
     pp_net* netB = nullptr;   // RoI features -> (cls, reg)
     int in_buf = 0, cls_buf[5], reg_buf[5], fpn_buf[4], roi_in = 0, roi_cls = 0, roi_reg = 0;
     int rpn_pitch = 0;       // 16: cls_buf[l] == reg_buf[l] is the fused head's 16-channel map
+    unsigned* in_amax = nullptr;    // per-frame maxima of the image program's input (its fp16-form stem reads them), written by the preprocess kernel
     unsigned* roi_amax = nullptr;   // per-RoI maxima of the RoI head's input (its fp16-form fc6 reads them), written by RoIAlign
     int H = 0, W = 0, nh = 0, nw = 0, Hp = 0, Wp = 0;
     float sfx = 1.f, sfy = 1.f;
@@ -187,6 +189,12 @@ int pp_detector_create(pp_net* netA, pp_net* netB, const int32_t* bufs_a, const 
         if (rc_am != PP_OK) return rc_am;
         d->roi_amax = static_cast<unsigned*>(am);
     }
+    {   // likewise the image program's input, when its stem runs in the fp16 form: the preprocess kernel folds the maxima
+        void* am = nullptr;
+        int rc_am = pp_net_input_amax(netA, d->in_buf, &am);
+        if (rc_am != PP_OK) return rc_am;
+        d->in_amax = static_cast<unsigned*>(am);
+    }
     PP_REQUIRE(d->max_frames > 0, "pp_detector_create: RoI-head program needs max_batch >= %d", d->max_rois);
     memcpy(d->base, base_anchors, sizeof(d->base));
     d->max_n = 5 * d->nms_pre;
@@ -268,8 +276,13 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
             PP_HIP_CHECK(hipMemcpyAsync(d->d_frames, frames, bytes, hipMemcpyHostToDevice, s));
             df = d->d_frames;
         }
+        if (d->in_amax) PP_HIP_CHECK(hipMemsetAsync(d->in_amax, 0, (size_t)F * sizeof(unsigned), s));
         rc = det_enqueue_preprocess(s, df, F, d->H, d->W, d->nh, d->nw, d->Hp, d->Wp, d->d_xtab, d->d_ytab, d->d_lut, 0.f,
-                                    static_cast<float*>(in_ptr));
+                                    static_cast<float*>(in_ptr), d->in_amax);
+        if (rc != PP_OK) return rc;
+    } else if (d->in_amax) {      // the caller filled the input buffer itself: take the maxima in a pass of their own
+        PP_HIP_CHECK(hipMemsetAsync(d->in_amax, 0, (size_t)F * sizeof(unsigned), s));
+        rc = pp_launch_amax(static_cast<const float*>(in_ptr), F, (size_t)d->Hp * d->Wp * 4, d->in_amax, s);
         if (rc != PP_OK) return rc;
     }
     PP_HIP_CHECK(hipEventRecord(d->ev[1], s));

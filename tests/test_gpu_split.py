@@ -688,3 +688,34 @@ def test_f16_form_non_finite_input_stays_in_its_sample(ctx, lib16, monkeypatch):
         assert np.array_equal(out[i], clean[i])
     # the maxima are reset per run: the next clean run is clean again
     assert np.array_equal(net.forward(x), clean)
+
+
+# (n, h, w): whole tiles, ragged tiles on both axes, a map smaller than one tile, the smoke-size frame, many tiles per workgroup
+CASES_STEM = [(2, 64, 128), (3, 70, 101), (1, 21, 37), (2, 135, 240), (5, 270, 480)]
+
+
+@pytest.mark.parametrize("case", CASES_STEM)
+def test_f16_form_stem_7x7_stride_2(ctx, lib16, case):
+    """ResNet-50's conv1 (7x7, stride 2, pad 3, 3 (+1 zero) -> 64 channels, ReLU) on conv_split_stem7_kernel: the float32 yardstick as for
+    every other fp16-form layer, per sample and per output channel, at magnitudes from 1e-30 to 1e7 and with every sample at its own."""
+    n, h, w = case
+    rng = np.random.default_rng(h * w)
+    wt = (rng.standard_normal((64, 4, 7, 7)) / np.sqrt(147)).astype(np.float32)
+    wt[:, 3] = 0
+    wt *= np.exp(2 * rng.standard_normal((64, 1, 1, 1))).astype(np.float32)
+    for mag in [np.full(n, m) for m in (1.0, 1e-30, 1e7)] + [10.0 ** np.linspace(-6, 4, n)]:
+        x = (rng.standard_normal((n, h, w, 4)) * np.exp(rng.standard_normal((n, h, w, 4))) * mag.reshape(-1, 1, 1, 1)).astype(np.float32)
+        x[..., 3] = 0
+        b = (rng.standard_normal(64) * np.abs(x).mean()).astype(np.float32)
+        pre = conv64(x, wt, b, 3, 2)
+        # errors are measured against the range of the PRE-activation values of the (sample, channel): a channel that ReLU leaves
+        # almost empty would otherwise be judged relative to its last surviving element
+        scale = np.abs(pre).reshape(n, -1, 64).max(1).reshape(n, 1, 1, 64) + 1e-300
+        for relu in (L.PP_RELU_LAST, L.PP_RELU_NONE):
+            ref = np.maximum(pre, 0) if relu == L.PP_RELU_LAST else pre
+            exact, split = both(lib16, lambda: hip_conv_op(ctx, x, wt, b, stride=2, pad=(3, 3), relu=relu))
+            assert split.shape == ref.shape and np.isfinite(split).all() and not np.array_equal(exact, split)
+            rms = lambda y: float(np.sqrt(np.mean(((y - ref) / scale) ** 2)))
+            assert rms(split) <= 1.25 * rms(exact) + 1e-9, (mag[0], relu, rms(split), rms(exact))
+            m_s, m_e = float(np.abs((split - ref) / scale).max()), float(np.abs((exact - ref) / scale).max())
+            assert m_s <= 1.5 * m_e + 1e-7, (mag[0], relu, m_s, m_e)
