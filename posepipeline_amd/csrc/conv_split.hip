@@ -2212,7 +2212,13 @@ static bool split_shape(const ConvArgs& a, int* taps, int* cin, int* mode, bool 
     // POSEPIPE_SPLIT_S2_MIN_CIN (read per SELECTION, i.e. at net creation: tests set it to run the form on every shape it supports,
     // whatever the selection rule would pick); a committed layer keeps the form it was created with
     const char* s2_env = committed ? nullptr : getenv("POSEPIPE_SPLIT_S2_MIN_CIN");
-    const bool s2_pick = committed || (s2_env ? a.Cin >= atoi(s2_env) : (a.Cin >= 128 && (((a.Cout + 31) / 32) & 1) == 0));
+    // Round 5 (fp16 form: half the products of the form the rule above was measured on; same-box per-op tables, W48, 128 samples): 96 -> 192
+    // 1.26 -> 1.09 ms, 96 -> 96 0.19 -> 0.16, 96 -> 384 0.18 -> 0.15, 256 -> 96 (three blocks) 0.85 -> 0.67, 48 -> 192 0.55 -> 0.44, 48 -> 384
+    // 0.10 -> 0.08; it still LOSES on 48 -> 96 (1.34 -> 2.10) and 48 -> 48 (0.80 -> 0.89): from 96 input channels, or from 48 with >= 6 blocks.
+    const int s2_ncb = (a.Cout + 31) / 32;
+    const bool s2_f16 = a.split_f16 != 0 || (a.numerics == 0 && pp_conv_split_f16_default());
+    const bool s2_pick = committed || (s2_env ? a.Cin >= atoi(s2_env)
+                                              : s2_f16 ? (a.Cin >= 96 || (a.Cin >= 48 && s2_ncb >= 6)) : (a.Cin >= 128 && (s2_ncb & 1) == 0));
     const bool k3s2 = s2_on && a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad_h == 1 && a.pad_w == 1 && a.dil_h == 1 && a.dil_w == 1 && !full && s2_pick;
     if (!(k3 || k1 || full || k3s2)) return false;
     *taps = (k3 || k3s2) ? 9 : 1;
@@ -2227,9 +2233,11 @@ static bool split_shape(const ConvArgs& a, int* taps, int* cin, int* mode, bool 
 // workgroup per CU) had nothing to run beside it.  With the residual lines of the epilogue requested back to back, the two-per-CU
 // form wins on EVERY layer of the detector (per 64 frames, 8-wave form -> this one): 512 -> 2048 1.76 -> 1.48 ms, 512 -> 128 1.74 -> 1.52,
 // 512 -> 256 2.00 -> 1.88, 1024 -> 256 2.88 -> 2.76, 2048 -> 512 1.13 -> 0.90, fc6 (K = 12544) 6.41 -> 6.24 (264 TFLOP/s), and
-// 128 -> 512 leaves the fp32 kernels for it (4.06 -> 3.74); 64 -> 256 stays there (5.59 vs 5.91): profiles/r04_product_kernel_forms.txt.
+// 128 -> 512 leaves the fp32 kernels for it (4.06 -> 3.74); 64 -> 256 stayed there in round 4 (5.59 vs 5.91: profiles/r04_product_kernel_forms.txt).
+// Round 5, after the rewrite of this kernel (pixels by DMA, three stages): 64 -> 256 at 160x272 5.60 -> 4.74 ms per 64 frames (4.08 -> 4.81 TB/s
+// algorithmic), HRNet's 64 -> 256 at 96x72 2.34 -> 2.01 ms per 128 samples, same box -- the floor is 64 input channels now.
 static int gemm8_cfg(const ConvArgs& a, int mode, int cin) {
-    static const int on = env_int("POSEPIPE_SPLIT_GEMM8", 1), min_c4 = env_int("POSEPIPE_SPLIT_GEMM4_MIN_C", 128);
+    static const int on = env_int("POSEPIPE_SPLIT_GEMM8", 1), min_c4 = env_int("POSEPIPE_SPLIT_GEMM4_MIN_C", 64);
     const bool tap_gather = a.KH * a.KW > 1 && cin == a.Cin;        // 3x3 stride 2: the tap kernel's product form, not this one
     if (!on || mode != MODE_GEMM || tap_gather) return 0;
     return (cin >= min_c4 && a.Cout % 128 == 0) ? 3 : 0;
