@@ -2254,7 +2254,12 @@ bool pp_conv_split_eligible(const ConvArgs& a) {
     // channels only (its 256 x 64 tile re-reads X Cout / 64 times; below, the fp32 kernel's smaller tiles do as well or better).
     static const int gemm_min_cin = env_int("POSEPIPE_SPLIT_GEMM_MIN_CIN", 1024);
     if (!split_shape(a, &taps, &cin, &mode)) return false;
-    if (mode == MODE_GEMM && taps == 1 && cin < gemm_min_cin && !gemm8_cfg(a, mode, cin)) return false;
+    // Round 5 (fp16 form): ONE 64-channel column reads X once, and then the one-tap form beats the float32 kernel from 256 input
+    // channels on large maps -- 256 -> 64 at 160x272 1.88 -> 1.62 ms per 64 frames, at 96x72 0.92 -> 0.83 per 128 samples; 12x9 maps
+    // (384 -> 48: 0.05 -> 0.11) and the 16-channel RPN maps lose and stay where they were.
+    const bool f16_form = a.split_f16 != 0 || (a.numerics == 0 && pp_conv_split_f16_default());
+    const bool one_column = f16_form && cin >= 256 && a.Cout > 32 && a.Cout <= 64 && a.HWout >= 4096;   // (per SAMPLE: the choice must not depend on the batch)
+    if (mode == MODE_GEMM && taps == 1 && cin < gemm_min_cin && !one_column && !gemm8_cfg(a, mode, cin)) return false;
     return cin % 16 == 0 && a.Cout % 4 == 0 && a.up_log2 == 0 && !a.out_nchw && res1_plain && a.relu <= PP_ACT_SWISH &&
            (a.y_stride == 0 || a.y_stride == a.Cout) && a.y_coff == 0;
 }
