@@ -719,3 +719,17 @@ def test_f16_form_stem_7x7_stride_2(ctx, lib16, case):
             assert rms(split) <= 1.25 * rms(exact) + 1e-9, (mag[0], relu, rms(split), rms(exact))
             m_s, m_e = float(np.abs((split - ref) / scale).max()), float(np.abs((exact - ref) / scale).max())
             assert m_s <= 1.5 * m_e + 1e-7, (mag[0], relu, m_s, m_e)
+
+
+def test_kernel_selection_does_not_depend_on_the_batch_capacity(ctx, lib16):
+    """Which layers run on which split form is decided from per-SAMPLE quantities only (channels, map size), never from the net's batch
+    capacity: nets of the same program created for 1 and for 5 samples select the same kernels, so a rank that holds a shard of a clip
+    computes the same bits as the process that holds all of it (tests/test_gpu_sharded.py).  Programs: the detector's image program
+    (stem kernel, product kernel from 64 channels, one-column rule, stride-2 forms) and HRNet-W48."""
+    det_sd = synth.synth_state_dict(fr.faster_rcnn_param_shapes(), seed=2)
+    spec = hrnet.HRNetSpec(48, 17, 384, 288)
+    progs = [fr.build_image_program(det_sd, 320, 544), hrnet.build_hrnet_program(spec, synth.synth_state_dict(hrnet.hrnet_param_shapes(spec), seed=1))]
+    for prog in progs:
+        kinds = [Net(ctx, prog, max_batch=b, numerics="split_f16").conv_kinds() for b in (1, 5)]
+        assert np.array_equal(kinds[0], kinds[1])
+        assert (kinds[0] == 2).sum() >= 50
