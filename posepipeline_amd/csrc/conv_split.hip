@@ -2021,7 +2021,7 @@ __global__ __launch_bounds__(512, 1) void conv_split_stem7_kernel(StemArgs a) {
             const int pr = p / STEM_PW, pc = p - pr * STEM_PW;
             const int iy = 2 * ty0 - 3 + pr, ix = 2 * tx0 - 3 + pc;
             const bool ok = p < STEM_PH * STEM_PW && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
-            const unsigned off = ok ? (unsigned)(((tn * a.xp_h + iy) * a.xp_w + ix) * 16) : 0xffffffffu;
+            const unsigned off = ok ? (unsigned)((tn * a.xp_h + iy) * a.xp_w + ix) * 16u : 0xffffffffu;      // (< 4 GiB per launch: pp_launch_conv cuts larger batches)
             xr[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, (int)off, 0, 0));
         }
     };
