@@ -217,8 +217,12 @@ int pp_net_buffer(pp_net* net, int buf, void** dptr, size_t* bytes_per_sample);
 /* fp16-form programs scale every convolution input per sample by a power of two taken from the running maximum of the tensor
  * (pp_conv_split_kind).  For tensors produced inside the program the producing kernels track it; for a program INPUT the run takes
  * one extra pass over the buffer -- unless the caller's own producer supplies the maxima: *dptr receives the device array
- * (max_batch uint32: the bit pattern of max |x| over sample n, any upper bound >= it is valid) the caller must then fill before
- * every pp_net_run, or NULL when no fp16-form convolution reads `buf` (nothing to do).  (The detector's RoIAlign does this.) */
+ * (max_batch uint32: the bit pattern of max |x| over sample n, any upper bound >= it is valid), or NULL when no fp16-form
+ * convolution reads `buf` (nothing to do).  The call is a ONE-SHOT promise: it covers the NEXT pp_net_run / pp_net_profile /
+ * pp_net_capture whose op range reads `buf` -- the caller fills the array on the ctx stream before that run and calls this again
+ * before every further one; a run without a fresh promise takes the maxima itself, and pp_net_forward (which overwrites the
+ * buffer) voids a pending promise.  The address is stable for the life of the net.  (The detector's preprocess kernel and
+ * RoIAlign do this.) */
 int pp_net_input_amax(pp_net* net, int buf, void** dptr);
 /* run ops [first, last) for `batch` samples (last < 0: to the end); inputs must already be in their buffers */
 int pp_net_run(pp_net* net, int batch, int first_op, int last_op);
@@ -454,7 +458,7 @@ typedef struct pp_detector pp_detector;
 /* mmcv rescale_size for img_scale (1088,1088) + Pad(size_divisor=32): resized and padded input dims */
 int pp_detector_input_size(int src_h, int src_w, int32_t* nh, int32_t* nw, int32_t* hp, int32_t* wp);
 /* The same mmcv test pipeline on its own (Resize keep_ratio -> Normalize -> Pad(size_divisor, pad_val)), used by the
- * YOLOX detector of the ByteTrack config (mot/bytetrack/*.py: img_scale (800, 1440), mean 0 / std 1, pad 114):
+ * YOLOX detector of the ByteTrack config (mot/bytetrack/ *.py: img_scale (800, 1440), mean 0 / std 1, pad 114):
  * pp_rescale_size = mmcv.rescale_size + the padded dims; pp_resize_pad_normalize writes device [n][hp][wp][4] fp32
  * (lut[c][v] applied to channel c of the BGR frame, 4th channel 0, padding = pad_val). */
 int pp_rescale_size(int src_h, int src_w, int max_long, int max_short, int divisor, int32_t* nh, int32_t* nw,

@@ -385,8 +385,12 @@ static int net_reset_amax(pp_net* net, int first, int last, int batch, hipStream
             s1 = k + 1;
         }
     if (s0 >= 0) PP_HIP_CHECK(hipMemsetAsync(net->amax_slot(s0), 0, (size_t)(s1 - s0) * net->max_batch * sizeof(unsigned), s));
-    for (const auto& e : net->ext) {
-        if (e.provided || e.last_reader < first || e.first_reader >= last) continue;
+    for (auto& e : net->ext) {
+        if (e.last_reader < first || e.first_reader >= last) continue;
+        if (e.provided) {        // the caller's producer filled the slot for THIS run (pp_net_input_amax): a one-shot promise
+            e.provided = false;
+            continue;
+        }
         PP_HIP_CHECK(hipMemsetAsync(net->amax_slot(e.slot), 0, (size_t)batch * sizeof(unsigned), s));
         int rc = pp_launch_amax(net->buf_ptr(e.buf), batch, net->buf_elems[e.buf], net->amax_slot(e.slot), s);
         if (rc != PP_OK) return rc;
@@ -623,6 +627,13 @@ int pp_net_dims(pp_net* net, int buf, int* h, int* w, int* c) {
 }
 int pp_net_max_batch(pp_net* net) { return net ? net->max_batch : 0; }
 pp_ctx* pp_net_ctx(pp_net* net) { return net ? net->ctx : nullptr; }
+
+unsigned* pp_net_input_amax_slot(pp_net* net, int buf) {
+    if (!net || !net->amax) return nullptr;
+    for (auto& e : net->ext)
+        if (e.buf == buf) return net->amax_slot(e.slot);
+    return nullptr;
+}
 
 extern "C" {
 
@@ -905,6 +916,8 @@ int pp_net_forward(pp_net* net, int batch, int in_buf, const float* in, int out_
     const hipMemcpyKind kin = mem == PP_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     const hipMemcpyKind kout = mem == PP_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     PP_HIP_CHECK(hipMemcpyAsync(net->buf_ptr(in_buf), in, (size_t)batch * net->buf_elems[in_buf] * sizeof(float), kin, s));
+    for (auto& e : net->ext)      // the input was just overwritten here: a pending promise of maxima (pp_net_input_amax) is void
+        if (e.buf == in_buf) e.provided = false;
     int rc = pp_net_run(net, batch, 0, (int)net->ops.size());
     if (rc != PP_OK) return rc;
     PP_HIP_CHECK(hipMemcpyAsync(out, net->buf_ptr(out_buf), (size_t)batch * net->buf_elems[out_buf] * sizeof(float), kout, s));

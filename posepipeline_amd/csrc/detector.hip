@@ -184,17 +184,10 @@ int pp_detector_create(pp_net* netA, pp_net* netB, const int32_t* bufs_a, const 
     d->max_frames = std::min(pp_net_max_batch(netA), pp_net_max_batch(netB) / d->max_rois);
     // a fp16-form RoI head scales its input per RoI: the separable RoIAlign kernel writes the maxima itself (no extra pass)
     if (det_roi_align_separable(pp_net_numerics(netB) == PP_NET_NUMERICS_SPLIT)) {
-        void* am = nullptr;
-        int rc_am = pp_net_input_amax(netB, d->roi_in, &am);
-        if (rc_am != PP_OK) return rc_am;
-        d->roi_amax = static_cast<unsigned*>(am);
+        d->roi_amax = pp_net_input_amax_slot(netB, d->roi_in);       // (the promise itself is made per run, pp_detector_run)
     }
-    {   // likewise the image program's input, when its stem runs in the fp16 form: the preprocess kernel folds the maxima
-        void* am = nullptr;
-        int rc_am = pp_net_input_amax(netA, d->in_buf, &am);
-        if (rc_am != PP_OK) return rc_am;
-        d->in_amax = static_cast<unsigned*>(am);
-    }
+    // likewise the image program's input, when its stem runs in the fp16 form: the preprocess kernel folds the maxima
+    d->in_amax = pp_net_input_amax_slot(netA, d->in_buf);
     PP_REQUIRE(d->max_frames > 0, "pp_detector_create: RoI-head program needs max_batch >= %d", d->max_rois);
     memcpy(d->base, base_anchors, sizeof(d->base));
     d->max_n = 5 * d->nms_pre;
@@ -287,6 +280,11 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
     }
     PP_HIP_CHECK(hipEventRecord(d->ev[1], s));
     stage.next("det.image_program");
+    if (d->in_amax) {            // the maxima were written above: the promise covers this run only (pp_net_input_amax)
+        void* am = nullptr;
+        rc = pp_net_input_amax(d->netA, d->in_buf, &am);
+        if (rc != PP_OK) return rc;
+    }
     rc = pp_net_run(d->netA, F, 0, -1);
     if (rc != PP_OK) return rc;
     PP_HIP_CHECK(hipEventRecord(d->ev[2], s));
@@ -326,6 +324,11 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
     if (rc != PP_OK) return rc;
     PP_HIP_CHECK(hipEventRecord(d->ev[4], s));
     stage.next("det.roi_head_program");
+    if (d->roi_amax) {
+        void* am = nullptr;
+        rc = pp_net_input_amax(d->netB, d->roi_in, &am);
+        if (rc != PP_OK) return rc;
+    }
     rc = pp_net_run(d->netB, F * d->max_rois, 0, -1);
     if (rc != PP_OK) return rc;
     PP_HIP_CHECK(hipEventRecord(d->ev[5], s));

@@ -86,3 +86,6 @@ __device__ __forceinline__ void pp_amax_commit_wg(unsigned* amax, const int (&im
 // stand-alone pass: amax[n] = max |x[n][0 .. elems)| for n < N (x: N contiguous samples of `elems` floats, elems % 4 == 0; a zero
 // halo does not move a maximum).  The slots must be zero on entry (the kernel only raises them).
 int pp_launch_amax(const float* x, int n, size_t elems, unsigned* amax, hipStream_t stream);
+// the device array pp_net_input_amax hands out for program input `buf`, WITHOUT promising anything (null: no fp16-form reader)
+struct pp_net;
+unsigned* pp_net_input_amax_slot(pp_net* net, int buf);

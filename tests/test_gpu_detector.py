@@ -78,3 +78,51 @@ def test_roi_align_and_head_match_oracle(setup):
     cls_ref, reg_ref = model.roi_head(ref_feats)
     assert np.array_equal(det.net_b.read("cls", n).reshape(n, 2), cls_ref)
     assert np.array_equal(det.net_b.read("reg", n).reshape(n, 4), reg_ref)
+
+
+def test_direct_runs_of_the_detector_nets_take_their_own_input_maxima(ctx, setup):
+    """pp_net_input_amax is a ONE-SHOT promise: after pp_detector_create and after a detector run, a direct forward /
+    run / profile of net_a or net_b must scale its fp16-form stem / fc6 by the maxima of the input it is GIVEN -- a stale (or zero)
+    maximum would push x * s out of the float16 range and the outputs to inf / NaN."""
+    sd, frames, _ = setup
+    det = fr.Detector(ctx, sd, 135, 240, max_frames=2, numerics="split")
+    if det.net_a.split_kind != "split_f16":
+        pytest.skip("the per-sample activation scale belongs to the fp16 form")
+    rng = np.random.default_rng(5)
+    h, w, c = det.prog_a.bufs[det.prog_a.named["input"]]
+    x_small = (rng.standard_normal((2, h, w, c)) * 0.01).astype(np.float32)
+    x_big = (rng.standard_normal((2, h, w, c)) * 300.0).astype(np.float32)
+    x_small[..., 3] = 0
+    x_big[..., 3] = 0
+    # straight after creation (nothing has ever filled the maxima)
+    y0 = det.net_a.forward(x_big, out_name="rpn0")
+    assert np.isfinite(y0).all()
+    # after a detector run whose frames have maxima ~2.6 (normalised pixels), then inputs 100x larger, by forward and by run
+    det.run(frames)
+    y1 = det.net_a.forward(x_big, out_name="rpn0")
+    assert np.array_equal(y0, y1)
+    det.run(frames)
+    dptr, _, _ = det.net_a.buffer("input")
+    ctx.h2d(dptr, x_big)
+    det.net_a.run(2)
+    assert np.array_equal(det.net_a.read("rpn0", 2), y0)
+    # ... and 100x smaller ones keep their precision (a stale LARGE maximum would cost ~2^-14 of it)
+    det.run(frames)
+    ys = det.net_a.forward(x_small, out_name="p2")
+    ref = fr_exact_p2(ctx, sd, x_small)
+    assert np.abs(ys - ref).max() <= 2e-5 * np.abs(ref).max()
+    # the detector itself is unaffected by the direct runs in between
+    a = det.run(frames)
+    b = fr.Detector(ctx, sd, 135, 240, max_frames=2, numerics="split").run(frames)
+    assert all(np.array_equal(p, q) for p, q in zip(a, b))
+    # net_b: RoI features 50x what RoIAlign last promised
+    hb, wb, cb = det.prog_b.bufs[det.prog_b.named["roi_in"]]
+    r = (rng.standard_normal((8, hb, wb, cb)) * 50.0).astype(np.float32)
+    cls = det.net_b.forward(r, in_name="roi_in", out_name="cls")
+    assert np.isfinite(cls).all()
+
+
+def fr_exact_p2(ctx, sd, x):
+    from posepipeline_amd.program import Net
+    prog = fr.build_image_program(sd, x.shape[1], x.shape[2], "detector.")
+    return Net(ctx, prog, max_batch=x.shape[0], numerics="exact").forward(x, out_name="p2")
