@@ -267,10 +267,14 @@ int pp_conv_exact(int exact);
  * single-op entry point get.  f16 = 1 (the default since round 5): two float16 terms per operand and three
  * v_mfma_f32_32x32x16_f16 products per term (half the matrix work of the six-product form; same float32 accumulation).  Weights are
  * normalised per output channel, activations PER SAMPLE by a power of two taken from the running maximum of the tensor -- tracked by
- * the kernel that produces it, or by one extra pass for tensors that come from outside the program -- so the representation keeps 22
- * significand bits at ANY magnitude of the data (nothing saturates, nothing underflows) and a sample's result does not depend on
- * what else is in the batch.  Error against a float64 convolution: that of the float32 FMA chain or lower (tests/test_gpu_split.py,
- * inputs from 1e-30 to 1e7).  0: three bfloat16 terms, six products (rounds 2 - 4); -1: the environment's choice
+ * the kernel that produces it, or by one extra pass for tensors that come from outside the program -- so nothing saturates at any
+ * magnitude of the data and a sample's result does not depend on what else is in the batch.  The precision is RELATIVE TO THE
+ * SAMPLE'S MAXIMUM m (one scale per sample of the whole tensor, not per channel): elements down to 2^-17 m keep 22 significand
+ * bits; below that the residual term is a float16 subnormal and the absolute error is <= 2^-39 m -- a large RELATIVE error for a
+ * channel or pixel whose values are all below ~1e-5 of the sample's maximum (BN-folded nets can have such channels; the bf16 form
+ * below has no such range limit, and PP_NET_NUMERICS_EXACT none at all).  Error against a float64 convolution: that of the float32
+ * FMA chain or lower on inputs of one magnitude per sample, 1e-30 to 1e7 (tests/test_gpu_split.py; the test with channel ranges
+ * spread over 2^20 holds the absolute bound above).  0: three bfloat16 terms, six products (rounds 2 - 4); -1: the environment's choice
  * (POSEPIPE_SPLIT_F16, default 1). */
 int pp_conv_split_kind(int f16);
 

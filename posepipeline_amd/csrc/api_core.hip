@@ -275,6 +275,7 @@ struct pp_net {
     // contiguous range (slot_owner = the first op that raises the slot).
     unsigned* amax = nullptr;
     std::vector<int> op_x_slot, op_y_slot, op_post_slot, slot_owner;
+    std::vector<int> slot_first, slot_last;      // tracked slots: first / last op that raises them (-1: nobody reads the maxima)
     struct ExtAmax { int buf, slot, first_reader, last_reader; bool provided; };
     std::vector<ExtAmax> ext;      // tensors from outside the program that fp16-form convolutions read
     float* arena = nullptr;
@@ -363,10 +364,23 @@ static void net_plan_amax(pp_net* net) {
         tensors[cur[op.out]].producers.push_back(i);
         read_since[op.out] = 0;
     }
+    net->slot_first.assign(net->slot_owner.size(), -1);
+    net->slot_last.assign(net->slot_owner.size(), -1);
     for (const Tensor& t : tensors) {
         if (!t.wanted) continue;
+        net->slot_first[t.slot] = t.producers.front();
+        net->slot_last[t.slot] = t.producers.back();
         bool fused = true;
         for (int p : t.producers) fused = fused && tracks(p);
+        // the fused maxima cover what the producers WRITE: when their channel slices do not add up to the whole buffer, part of
+        // what the readers see is older content (a dense-connection pattern, a buffer partly filled from outside) that only the
+        // stand-alone pass over the whole buffer accounts for
+        {
+            int covered = 0;
+            const int out_b = net->ops[t.producers.front()].out;
+            for (int p : t.producers) covered += net->ops[p].type == PP_OP_CONV ? net->ops[p].cout : net->bufs[out_b].c;
+            if (covered < net->bufs[out_b].c) fused = false;
+        }
         if (fused)
             for (int p : t.producers) net->op_y_slot[p] = t.slot;
         else
@@ -379,6 +393,14 @@ static void net_plan_amax(pp_net* net) {
 static int net_reset_amax(pp_net* net, int first, int last, int batch, hipStream_t s) {
     if (!net->amax) return PP_OK;
     int s0 = -1, s1 = -1;
+    // a range that starts (or ends) between the producers of a tracked tensor would keep (or lose) part of its maxima: the scale
+    // would then depend on earlier runs, which the fp16 form promises it never does
+    for (int k = 0; k < (int)net->slot_first.size(); ++k) {
+        const int a = net->slot_first[k], b = net->slot_last[k];
+        if (a < 0 || b < first || a >= last) continue;
+        PP_REQUIRE(a >= first && b < last, "pp_net_run: op range [%d, %d) splits the producers (ops %d .. %d) of a tensor whose per-sample maxima are tracked",
+                   first, last, a, b);
+    }
     for (int k = 0; k < (int)net->slot_owner.size(); ++k)
         if (net->slot_owner[k] >= first && net->slot_owner[k] < last) {
             if (s0 < 0) s0 = k;

@@ -155,12 +155,24 @@ def all_gather_ragged(local: np.ndarray, counts, dist, device="cpu") -> np.ndarr
 
 
 def _takes_need(fn) -> bool:
+    """does chunks_fn accept the keyword `need`?  A **kwargs catch-all only counts when the callable it forwards to (found through
+    `__wrapped__` / functools.partial) names `need` itself: a plain forwarding wrapper around a source without the parameter must
+    keep being called without it."""
+    import functools
     import inspect
-    try:
-        ps = inspect.signature(fn).parameters          # (follows functools.partial; a **kwargs wrapper takes `need` as well)
-        return "need" in ps or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in ps.values())
-    except (TypeError, ValueError):
-        return False
+    seen = 0
+    while fn is not None and seen < 8:
+        seen += 1
+        try:
+            ps = inspect.signature(fn, follow_wrapped=False).parameters
+        except (TypeError, ValueError):
+            return False
+        if "need" in ps:
+            return True
+        if not any(p.kind is inspect.Parameter.VAR_KEYWORD for p in ps.values()):
+            return False
+        fn = getattr(fn, "__wrapped__", None) or (fn.func if isinstance(fn, functools.partial) else None)
+    return False
 
 
 def process_video_sharded(dist, n_frames, chunks_fn, detect_fn, associate_fn, topdown_fn, lift_fn, src_hw, device="cpu",

@@ -328,3 +328,30 @@ def test_single_rank_bench_never_imports_torch():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_takes_need_follows_wrappers_only_to_a_real_parameter():
+    """a **kwargs forwarding wrapper gets `need=` only when what it wraps names the parameter"""
+    import functools
+    from posepipeline_amd.parallel import _takes_need
+
+    def plain(lo, hi):
+        return []
+
+    def lazy(lo, hi, need=None):
+        return []
+
+    def forward_plain(*a, **k):
+        return plain(*a, **k)
+
+    @functools.wraps(lazy)
+    def wrapped_lazy(*a, **k):
+        return lazy(*a, **k)
+
+    @functools.wraps(plain)
+    def wrapped_plain(*a, **k):
+        return plain(*a, **k)
+
+    assert not _takes_need(plain) and _takes_need(lazy)
+    assert not _takes_need(forward_plain) and not _takes_need(wrapped_plain)
+    assert _takes_need(wrapped_lazy) and _takes_need(functools.partial(lazy, 0)) and not _takes_need(functools.partial(plain, 0))
