@@ -91,7 +91,10 @@ def gaussian_blur(heatmaps, kernel=11):
             origin_max = np.max(heatmaps[i, j])
             dr = gaussian_blur_f32(heatmaps[i, j], kernel)
             heatmaps[i, j] = dr
-            heatmaps[i, j] *= f32(origin_max / np.max(heatmaps[i, j]))
+            # (an all-zero map blurs to all zeros: 0 / 0 -- numpy warns and yields NaN, as the reference's own line does; the
+            # product path's maps are never all zero after the flip average, the oracle is only spared the warning)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                heatmaps[i, j] *= f32(origin_max / np.max(heatmaps[i, j]))
     return heatmaps
 
 

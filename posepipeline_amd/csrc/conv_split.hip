@@ -2447,8 +2447,8 @@ static int launch_stem7(const ConvArgs& a, hipStream_t stream) {
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
     }();
-    static std::once_flag once;
-    std::call_once(once, [] { (void)hipFuncSetAttribute((const void*)conv_split_stem7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS); });
+    static PpPerDeviceOnce once;
+    once.run([] { (void)hipFuncSetAttribute((const void*)conv_split_stem7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEM_LDS); });
     const unsigned grid = (unsigned)std::min(s.ntiles, ncu);
     hipLaunchKernelGGL(conv_split_stem7_kernel, dim3(grid), dim3(512), STEM_LDS, stream, s);
     hipError_t e = hipGetLastError();
@@ -2522,8 +2522,8 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         // fp16 form: three raw float32 pixel stages of BM x 64 B + three weight stages; six-product form: two stages of split planes + weights
         const size_t lds_loop = f16 ? (size_t)3 * BM * 64 + (size_t)3 * BN * 2 * wpl * 16 : (size_t)2 * (xp * 2 * (BM + 4) * 16 + BN * 2 * wpl * 16);
         const size_t lds = std::max<size_t>(lds_loop, s.epi_lds ? (size_t)nwave * (16384 + 2048) : 0);
-        static std::once_flag once;
-        std::call_once(once, [] {
+        static PpPerDeviceOnce once;
+        once.run([] {
             (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             (void)hipFuncSetAttribute((const void*)conv_split_gemm_kernel<2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
         });
@@ -2622,8 +2622,8 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
         const size_t lds48 = patch48 + (ring48 ? (size_t)4 * 3 * wpl * 1024 : 0);
 #define PP_SPLIT48_LAUNCH(NS_)                                                                                          \
     do {                                                                                                                \
-        static std::once_flag once;                                                                                     \
-        std::call_once(once, [] {                                                                                       \
+        static PpPerDeviceOnce once;                                                                                     \
+        once.run([] {                                                                                       \
             (void)hipFuncSetAttribute((const void*)conv_split48_kernel<NS_, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
             (void)hipFuncSetAttribute((const void*)conv_split48_kernel<NS_, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
             (void)hipFuncSetAttribute((const void*)conv_split48_kernel<NS_, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
@@ -2651,8 +2651,8 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     fill_divisors(s);
 #define PP_SPLIT_LAUNCH_H(T_, NS_, NW_, R4_, H_)                                                                        \
     do {                                                                                                                \
-        static std::once_flag once;                                                                                     \
-        std::call_once(once, [] {     /* > 64 KB of dynamic LDS has to be allowed per kernel */                         \
+        static PpPerDeviceOnce once;                                                                                     \
+        once.run([] {     /* > 64 KB of dynamic LDS has to be allowed per kernel */                         \
             (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 2, 2, NW_, R4_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, (NW_ == 8 ? 160 : 100) * 1024); \
             (void)hipFuncSetAttribute((const void*)conv_split_kernel<T_, NS_, 1, 2, NW_, R4_, H_>, hipFuncAttributeMaxDynamicSharedMemorySize, (NW_ == 8 ? 160 : 100) * 1024); \
         });                                                                                                             \
@@ -2663,8 +2663,8 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     } while (0)
 #define PP_SPLIT_LAUNCH_WIDE(NS_, COB_)                                                                                 \
     do {                                                                                                                \
-        static std::once_flag once;                                                                                     \
-        std::call_once(once, [] {                                                                                       \
+        static PpPerDeviceOnce once;                                                                                     \
+        once.run([] {                                                                                       \
             (void)hipFuncSetAttribute((const void*)conv_split_kernel<9, NS_, COB_, 2, 4, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
         });                                                                                                             \
         hipLaunchKernelGGL((conv_split_kernel<9, NS_, COB_, 2, 4, true, true>), grid, dim3(256), lds, stream, s);       \

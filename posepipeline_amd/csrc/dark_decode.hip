@@ -576,8 +576,8 @@ int pp_enqueue_decode(hipStream_t s, const DecodeParams& p, const float* hm, con
         g.inv_nseg = 1.0f / (float)g.nseg;
         g.inv_nsegy = 1.0f / (float)g.nsegy;
         const size_t lds_fast = ((size_t)(p.h / 2) * g.wpa * 2 + (blur ? (size_t)(w8 / 2) * g.hpb * 2 + 64 : 0)) * sizeof(float);
-        static std::once_flag fast_attr;      // (as the conv_split launch macros: once per process, thread-safe)
-        std::call_once(fast_attr, [] {
+        static PpPerDeviceOnce fast_attr;      // (once per device, thread-safe)
+        fast_attr.run([] {
             (void)hipFuncSetAttribute((const void*)flip_merge_decode_fast_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
             (void)hipFuncSetAttribute((const void*)flip_merge_decode_fast_kernel<11>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
             (void)hipFuncSetAttribute((const void*)flip_merge_decode_fast_kernel<17>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
@@ -588,11 +588,9 @@ int pp_enqueue_decode(hipStream_t s, const DecodeParams& p, const float* hm, con
         PP_HIP_CHECK(hipGetLastError());
         return PP_OK;
     }
-    static bool attr_set = false;
-    if (!attr_set && lds > 64 * 1024) {
-        PP_HIP_CHECK(hipFuncSetAttribute((const void*)flip_merge_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64));
-        attr_set = true;
-    }
+    static PpPerDeviceOnce attr_set;
+    if (lds > 64 * 1024)
+        attr_set.run([] { (void)hipFuncSetAttribute((const void*)flip_merge_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); });
     hipLaunchKernelGGL(flip_merge_decode_kernel, dim3(p.n * p.k), dim3(256), lds, s, a);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;

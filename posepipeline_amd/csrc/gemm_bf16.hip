@@ -493,11 +493,9 @@ int launch_cfg(const GemmArgs& a, hipStream_t stream) {
     constexpr int BM = WAVES_M * WM * 16, BN = WAVES_N * WN * 16;
     constexpr int lds = NSTAGE * (BM + BN) * BK * 2;
     auto* kern = &gemm_bf16_kernel<WAVES_M, WAVES_N, WM, WN, NSTAGE, BK>;
-    static bool configured = false;
-    if (!configured && lds > 64 * 1024) {
-        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured = true;
-    }
+    static PpPerDeviceOnce configured;
+    if (lds > 64 * 1024)
+        configured.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
     if (a.M <= 0) return PP_OK;        // configure-only call (pp_gemm_bf16_prepare)
     const int tiles = ((a.M + BM - 1) / BM) * (a.N / BN);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(64 * WAVES_M * WAVES_N), lds, stream, a);
@@ -509,11 +507,8 @@ template <int D4, int D1, int D2>
 int launch_pingpong(const GemmArgs& a, hipStream_t stream) {
     constexpr int lds = 128 * 1024;          // two 64 KiB operand buffers (the epilogue stages through them)
     auto* kern = &gemm_bf16_pingpong_kernel<D4, D1, D2>;
-    static bool configured = false;
-    if (!configured) {
-        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        configured = true;
-    }
+    static PpPerDeviceOnce configured;
+    configured.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
     if (a.M <= 0) return PP_OK;
     const int tiles = ((a.M + 255) / 256) * (a.N / 256);
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), lds, stream, a);

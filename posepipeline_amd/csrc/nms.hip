@@ -189,11 +189,8 @@ template <typename T, int CONV>
 int run_nms(hipStream_t s, const T* d_boxes, const T* d_scores, const int32_t* d_n, int max_n, int n_frames, T thr,
             int32_t* d_order, unsigned long long* d_mask, int32_t* d_keep, int32_t* d_nkeep) {
     const size_t lds = (size_t)MAX_N * (sizeof(T) + sizeof(int32_t));
-    static bool attr_set = false;
-    if (!attr_set) {
-        PP_HIP_CHECK(hipFuncSetAttribute((const void*)sort_desc_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
+    static PpPerDeviceOnce attr_set;
+    attr_set.run([&] { (void)hipFuncSetAttribute((const void*)sort_desc_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     hipLaunchKernelGGL((sort_desc_kernel<T>), dim3(n_frames), dim3(1024), lds, s, d_scores, d_n, max_n, d_order);
     const int words = (max_n + 63) / 64;
     hipLaunchKernelGGL((nms_mask_kernel<T, CONV>), dim3(words, words, n_frames), dim3(64), 0, s, d_boxes, d_order, d_n, max_n,

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <mutex>
 
 #include "posepipe_hip.h"
 
@@ -28,6 +29,21 @@ void pp_set_error(const char* fmt, ...);
             return PP_ERR_ARG;           \
         }                                \
     } while (0)
+
+// Per-kernel function attributes (hipFuncAttributeMaxDynamicSharedMemorySize) belong to the DEVICE's copy of the code object: a
+// process that drives several devices has to set them once per device, not once per process.  One object per call site.
+struct PpPerDeviceOnce {
+    std::mutex m;
+    unsigned long long done = 0;          // bit d: set on device d
+    template <class F> void run(F&& f) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> g(m);
+        if ((done >> (dev & 63)) & 1ull) return;
+        f();
+        done |= 1ull << (dev & 63);
+    }
+};
 
 struct pp_ctx {
     int device = 0;

@@ -245,12 +245,9 @@ template <int T, int HD>
 static int launch_attention(const void* qkv, int batch, int heads, void* out, int head_major, hipStream_t stream) {
     constexpr int HDP = (HD + 31) / 32 * 32;
     constexpr size_t lds = (size_t)T * (HDP * 2 + 16) + (size_t)HD * (T * 2 + 16);
-    static bool configured = false;
-    if (!configured) {
-        PP_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<T, HD>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = true;
-    }
+    static PpPerDeviceOnce configured;
+    configured.run([&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<T, HD>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
     const float scale = 1.0f / sqrtf((float)HD);
     hipLaunchKernelGGL((attention_kernel<T, HD>), dim3(batch * heads), dim3(256), lds, stream,
                        reinterpret_cast<const unsigned short*>(qkv), reinterpret_cast<unsigned short*>(out), heads, scale, head_major);
