@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define PP_ABI_VERSION 9   /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
+#define PP_ABI_VERSION 10  /* 2: pp_op gained out_c_off / in_c_off / pad_end; PP_ACT_* activations
                               3: PP_OP_VIT_ENCODER / PP_OP_DEPTH_TO_SPACE, bf16 building blocks, UDP top-down (post 2)
                               4: pp_memcpy_d2d, pp_net_create_mem (weights already on the device, e.g. an RCCL broadcast)
                               5: pp_buf.pad (zero halo of conv-only buffers), PP_OP_AVGPOOL, pp_crop_resize_bilinear,
@@ -44,7 +44,9 @@ extern "C" {
                               8: pp_upload_begin_nv12 / pp_nv12_to_bgr (NV12 frame source)
                               9: PP_NET_NUMERICS_SPLIT_BF16 / _F16, pp_conv_split_kind, pp_net_split_kind: the split convolutions have a
                                  second form -- two float16 terms per operand, three products (conv_split.hip, round 5);
-                                 pp_detector_constants */
+                                 pp_detector_constants
+                              10: pp_detector_enable_margins / pp_detector_margins (per-frame decision margins of the detection path);
+                                 pp_net_input_amax is a one-shot promise */
 
 typedef enum {
     PP_OK = 0,
@@ -484,6 +486,37 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
 /* HIP-event stage times of the last run, ms6 = {preprocess, image program, RPN proposals + NMS, RoIAlign,
  * RoI-head program, final decode + NMS} */
 int pp_detector_timing(pp_detector* d, float* ms6);
+/* Decision margins (round 6): how far every INTEGER decision of the detection path is from flipping, per frame.  The path takes
+ * thousands of discrete decisions on float32 values (top-1000 per level, NMS 0.7, top-1000, RoI level, score > 0.05, NMS 0.5,
+ * top-100: faster_rcnn_r50_fpn.py:101-109); an evaluation that is as accurate but not bit-identical -- this library's default
+ * convolution numerics, or the reference's own cuDNN kernels -- may legitimately flip one that sits on its threshold.  With margins
+ * enabled every pp_detector_run also returns, per frame, the distance of the CLOSEST decision of each class to its threshold, so the
+ * caller knows which frames are decided (every margin above the evaluation's error) and which are not (re-run those on a
+ * PP_NET_NUMERICS_EXACT detector: posepipeline_amd/cascade.py id_numerics="certified").  +inf = no decision of that class.
+ *   PP_DET_MARGIN_RPN_CUT    score gap across the per-level top-k cut (min over the levels that have one)
+ *   PP_DET_MARGIN_RPN_NMS    NMS 0.7, IoU units: min over kept proposals of (thr - IoU) to every kept predecessor, over suppressed
+ *                            ones of their BEST suppressor's min(IoU - thr, score_weight * its score lead)
+ *   PP_DET_MARGIN_RPN_TOP    score gap across the max_per_img cut of the kept proposals
+ *   PP_DET_MARGIN_ROI_LEVEL  min |log2(sqrt(w h) / 56 + 1e-6) - b|, b in {1, 2, 3}, over the RoIs (which FPN level is sampled)
+ *   PP_DET_MARGIN_SCORE_THR  min |score - 0.05| over the RoIs
+ *   PP_DET_MARGIN_DET_NMS    NMS 0.5 on the scored boxes, as RPN_NMS
+ *   PP_DET_MARGIN_DET_TOP    score gap across the top-100 cut
+ *   PP_DET_MARGIN_DET_ORDER  smallest score gap between neighbouring OUTPUT rows (the tracker numbers new tracks in row order)
+ * score_weight converts a score lead into IoU units inside the two NMS margins (a suppressor only counts while it stays ahead of
+ * the box it suppresses): (IoU error bound) / (2 x score error bound) of the evaluation to be certified.  Costs ~1 ms per 64 frames;
+ * off by default. */
+#define PP_DET_N_MARGINS 8
+#define PP_DET_MARGIN_RPN_CUT 0
+#define PP_DET_MARGIN_RPN_NMS 1
+#define PP_DET_MARGIN_RPN_TOP 2
+#define PP_DET_MARGIN_ROI_LEVEL 3
+#define PP_DET_MARGIN_SCORE_THR 4
+#define PP_DET_MARGIN_DET_NMS 5
+#define PP_DET_MARGIN_DET_TOP 6
+#define PP_DET_MARGIN_DET_ORDER 7
+int pp_detector_enable_margins(pp_detector* d, int enable, float score_weight);
+/* margins [n_frames][PP_DET_N_MARGINS] of the most recent pp_detector_run (n_frames = that run's) */
+int pp_detector_margins(pp_detector* d, int n_frames, float* margins);
 
 /* ---- DeepSortYOLOv4 pre / post-processing ------------------------------------------------------------
  * tracking_method 0 (pipeline.py:519-523 -> wrappers/deep_sort_yolov4/parser.py:21): YOLOv4 detector + mars-small128

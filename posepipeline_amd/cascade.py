@@ -32,6 +32,14 @@ from .tracking import Tracker
 from .wrappers.videopose3d import lift
 
 
+# Default certification thresholds of Cascade(id_numerics="certified"): 4x the largest deviation between the fp16-form and the
+# float32-MFMA detector measured per quantity on 1080p frames (tools/margin_probe.py, profiles/r06_margin_probe.txt: RPN scores
+# 5.2e-6, proposal coordinates 2.9e-6 of the box size -> IoU ~1e-5, RoI scores 1.2e-5, detection boxes 3.1e-6 of their size,
+# detection scores 4.5e-6), in the units of each margin (include/posepipe_hip.h).
+CERTIFY_EPS = {"rpn_cut": 2e-5, "rpn_nms": 5e-5, "rpn_top": 2e-5, "roi_level": 2e-5, "score_thr": 5e-5, "det_nms": 5e-5,
+               "det_top": 5e-5, "det_order": 4e-5, "trk_score": 2e-5}
+
+
 class Cascade:
     """tracking: "MMTrack_deepsort" (Faster-RCNN R50-FPN, det_sd = detector weights; association = mmtrack SortTracker: with
     reid_sd (ReID ResNet-50 weights) the DeepSORT configuration with its appearance branch, without it the SORT
@@ -41,10 +49,12 @@ class Cascade:
     In "DeepSortYOLOv4" mode every track the tracker keeps is a row of every frame (tentative and missed ones with their
     Kalman box), because that is what the reference stores (parser.py:76-86) and PersonBbox selects from."""
 
+    tracker_score_thr = 0.5       # SortTracker obj_score_thr (mot/deepsort/*.py:43-54)
+
     def __init__(self, ctx: L.Context, det_sd, pose_sd: dict, lift_sd: dict, src_h: int, src_w: int,
                  chunk: int = 8, max_persons: int = 1, pose_spec=None, post="unbiased", blur_kernel=17,
                  tracking: str = "MMTrack_deepsort", keep_tracks=None, flip_pairs=None, blob_fn=None, reid_sd=None,
-                 overlap_detector: bool | None = None, numerics=None, id_numerics=None):
+                 overlap_detector: bool | None = None, numerics=None, id_numerics=None, certify_eps=None):
         """blob_fn(name, program) -> (device pointer, n_floats) or None, name in "det_a", "det_b", "pose", "lift" (called in
         that order): a weight blob that is already resident on the device -- parallel.broadcast_blob_device delivers rank
         0's over RCCL; the *_sd arguments then only define the program structure (ops, buffers, blob offsets).
@@ -62,6 +72,14 @@ class Cascade:
         # the rest.  numerics="split", id_numerics="exact" is the "integer-exact" configuration: track ids, bbox indices and `present`
         # are the oracle's BY CONSTRUCTION (the float32-MFMA detector is bit-identical to it, the tracker is host float64), while the
         # pose / lifting programs, whose outputs are held to 1e-3 px / mm, run on the fast kernels.
+        # id_numerics="certified" (round 6): the detector runs on the fast kernels WITH decision margins (pp_detector_enable_margins);
+        # a frame whose every margin clears `certify_eps` keeps its fast detections, the others are run again through a float32-MFMA
+        # detector (bit-identical to the oracle).  Which frames were certified is reported per step (`certified`), the policy below
+        # falls back to the exact detector alone while fewer than half of a chunk's frames certify.
+        self.certified = id_numerics == "certified"
+        if self.certified:
+            assert tracking == "MMTrack_deepsort" and reid_sd is None, "certified ids: the Faster-RCNN + SORT configuration"
+            id_numerics = "split"
         id_numerics = numerics if id_numerics is None else id_numerics
         self.ctx = ctx
         self.det_ctx = ctx
@@ -87,6 +105,15 @@ class Cascade:
                 overlap_detector = (env != "0") if env is not None else (os.cpu_count() or 1) >= 4 * ranks
             self.det_ctx = L.Context(ctx.device) if (overlap_detector and reid_sd is None) else ctx
             self.detector = fr.Detector(self.det_ctx, det_sd, src_h, src_w, max_frames=chunk, blob_fn=blob_fn, numerics=id_numerics)
+            if self.certified:
+                self.certify_eps = dict(CERTIFY_EPS if certify_eps is None else certify_eps)
+                self.detector.enable_margins(True, self.certify_eps["rpn_nms"] / (2.0 * self.certify_eps["rpn_cut"]))
+                # (built from det_sd itself: blob_fn's broadcast protocol hands out every program's blob once, in a fixed order)
+                self.detector_exact = fr.Detector(self.det_ctx, det_sd, src_h, src_w, max_frames=chunk, numerics="exact")
+                self._gather_dev = None           # device scratch: the uncertified frames of a chunk, contiguous
+                self._exact_only = False          # policy state: skip the fast pass while certification keeps failing
+                self._since_probe = 0
+                self.certify_stats = {"frames": 0, "certified": 0, "exact_only_frames": 0}
             if reid_sd is not None:
                 from .models import reid_r50
                 self.reid = reid_r50.ReidEncoder(ctx, reid_sd, self.detector, max_crops=max(64, chunk * max_persons), blob_fn=blob_fn, numerics=id_numerics)
@@ -128,6 +155,9 @@ class Cascade:
         if self.tail_dev is not None and getattr(self.ctx, "handle", None):
             self.ctx.free(self.tail_dev)
         self.tail_dev = None
+        if getattr(self, "_gather_dev", None) is not None and getattr(self.det_ctx, "handle", None):
+            self.det_ctx.free(self._gather_dev)
+        self._gather_dev = None
 
     def __del__(self):
         try:
@@ -143,7 +173,7 @@ class Cascade:
             from .tracking import SortReidTracker
             self.tracker = SortReidTracker()
         else:
-            self.tracker = Tracker(mode=1, match_iou_thr=0.5, obj_score_thr=0.5)
+            self.tracker = Tracker(mode=1, match_iou_thr=0.5, obj_score_thr=self.tracker_score_thr)
         # the lifting network takes the 17 COCO joints; wider heads (Halpe-136 / WholeBody-133) start with them
         self.persons = PersonStreams(self.k, self.lift_spec.pad, self.src, self._topdown_jobs,
                                      lambda kn: lift(self.lift_net, self.lift_spec, kn[:, :17]),
@@ -178,8 +208,55 @@ class Cascade:
 
     def _det_job(self, frames, frames_dev):
         """detector pass + its per-stage HIP-event times (read on the thread that ran it: the next pass re-records the events)"""
+        if self.certified:
+            return self._det_job_certified(frames, frames_dev)
         dets = self.detector.run(frames, frames_dev=frames_dev)
         timing = self.detector.timing() if hasattr(self.detector, "timing") else None
+        return dets, timing
+
+    def uncertified_frames(self, dets, margins):
+        """indices of the frames of a fast detector pass whose integer decisions are NOT safe under the split kernels' error bounds:
+        a device margin (Detector.MARGIN_NAMES) or the tracker's score threshold within certify_eps"""
+        eps = np.array([self.certify_eps[k] for k in fr.Detector.MARGIN_NAMES], np.float32)
+        bad = (margins <= eps[None, :]).any(axis=1)
+        thr = self.tracker_score_thr
+        for i, rows in enumerate(dets):
+            if len(rows) and np.abs(np.asarray(rows)[:, 4] - thr).min() <= self.certify_eps["trk_score"]:
+                bad[i] = True
+        return np.flatnonzero(bad)
+
+    def _det_job_certified(self, frames, frames_dev):
+        b = frames_dev[1] if frames_dev is not None else frames.shape[0]
+        st = self.certify_stats
+        st["frames"] += b
+        # policy: while fewer than half of a chunk's frames certify, the fast pass buys nothing (its cost + the exact pass over the
+        # rest exceeds the exact pass alone): run the exact detector only, and probe the fast pass again every 8th chunk
+        if self._exact_only and self._since_probe < 8:
+            self._since_probe += 1
+            st["exact_only_frames"] += b
+            self.last_certified = np.zeros(b, bool)
+            return self.detector_exact.run(frames, frames_dev=frames_dev), self.detector_exact.timing()
+        self._since_probe = 0
+        dets = self.detector.run(frames, frames_dev=frames_dev)
+        timing = self.detector.timing()
+        redo = self.uncertified_frames(dets, self.detector.margins(b))
+        self.last_certified = np.ones(b, bool)
+        self.last_certified[redo] = False
+        st["certified"] += b - len(redo)
+        self._exact_only = 2 * len(redo) > b
+        if len(redo) == b:
+            dets = self.detector_exact.run(frames, frames_dev=frames_dev)
+        elif len(redo):
+            if frames_dev is not None:
+                if self._gather_dev is None:
+                    self._gather_dev = self.det_ctx.malloc(self.chunk * self.frame_bytes)
+                for k, i in enumerate(redo):
+                    self.det_ctx.d2d(self._gather_dev + k * self.frame_bytes, frames_dev[0] + int(i) * self.frame_bytes, self.frame_bytes)
+                again = self.detector_exact.run(None, frames_dev=(self._gather_dev, len(redo)))
+            else:
+                again = self.detector_exact.run(np.ascontiguousarray(frames[redo]))
+            for k, i in enumerate(redo):
+                dets[int(i)] = again[k]
         return dets, timing
 
     def _prefetch(self, frames, frames_dev):

@@ -32,6 +32,11 @@ struct DetRpnArgs {
     float* boxes_nms;      // [frame][max_n][4]  (+ level offsets)
     float* scores;         // [frame][max_n]
     int32_t* n_boxes;      // [frame]
+    // decision margins (pp_detector_enable_margins; all null / 0 otherwise): per (frame, level) cut gaps, and where their per-frame
+    // minimum goes (cut_margin[frame * margin_stride])
+    float* cut_gap = nullptr;
+    float* cut_margin = nullptr;
+    int margin_stride = 0;
 };
 
 struct DetFpnArgs {
@@ -45,7 +50,7 @@ int det_enqueue_preprocess(hipStream_t s, const uint8_t* frames, int n_frames, i
 int det_enqueue_rpn(hipStream_t s, const DetRpnArgs& a, int n_frames);
 int det_enqueue_gather(hipStream_t s, const float* boxes, const float* scores, int max_n, const int32_t* keep,
                        const int32_t* n_keep, int limit, float* out_box, float* out_score, int32_t* n_out, int out5,
-                       int n_frames);
+                       int n_frames, float* top_gap = nullptr, float* order_gap = nullptr, int margin_stride = 0);
 // separable != 0: the default-numerics form (same samples, separable evaluation order); 0: the oracle's (iy, ix) order
 // amax (may be null; separable kernel only): per-RoI maxima for the RoI head's fp16-form input (pp_net_input_amax)
 bool det_roi_align_separable(int separable);
@@ -53,11 +58,17 @@ int det_enqueue_roi_align(hipStream_t s, const DetFpnArgs& a, const float* rois,
                           float* out, int n_frames, int separable, unsigned* amax = nullptr);
 int det_enqueue_final_decode(hipStream_t s, const float* rois, const int32_t* n_rois, int max_rois, const float* cls,
                              const float* reg, float sfx, float sfy, float score_thr, float* boxes, float* scores,
-                             int32_t* n_out, int n_frames);
+                             int32_t* n_out, int n_frames, float* level_margin = nullptr, float* thr_margin = nullptr,
+                             int margin_stride = 0);
 
 // nms.hip: batched float32 NMS (mmcv convention).  boxes [frame][max_n][4] (used for the IoU test), scores
 // [frame][max_n], n [frame] on the device.  keep [frame][max_n] receives indices in descending score order.
 // scratch: pp_nms_batched_scratch_bytes(max_n, n_frames).
 size_t pp_nms_batched_scratch_bytes(int max_n, int n_frames);
+// margin (may be null; decision margins): margin[frame * margin_stride] receives how far the frame's NMS result is from changing,
+// in IoU units -- min over the kept boxes of (thr - IoU) to every kept predecessor, and over the suppressed boxes of their BEST
+// suppressor's min(IoU - thr, score_weight * (score lead over the suppressed box)); +inf with fewer than two boxes.
+// kflag_scratch: n_frames * max_n bytes.
 int pp_enqueue_nms_batched(hipStream_t s, const float* boxes, const float* scores, const int32_t* n, int max_n,
-                           int n_frames, float thr, void* scratch, int32_t* keep, int32_t* n_keep);
+                           int n_frames, float thr, void* scratch, int32_t* keep, int32_t* n_keep, float* margin = nullptr,
+                           int margin_stride = 0, float score_weight = 0.f, unsigned char* kflag_scratch = nullptr);

@@ -120,9 +120,12 @@ struct RpnLevels {
     float base[5][3][4];      // base anchors
 };
 
+// cut_gap (may be null; decision margins, pp_detector_enable_margins): per (frame, level) the score gap between the LAST anchor the
+// top-k cut takes and the FIRST it leaves out -- +inf when the level has no cut (N <= nms_pre), 0 when the cut falls inside a tie
 __global__ __launch_bounds__(1024) void rpn_select_kernel(RpnLevels L, int nms_pre, float* __restrict__ score_scratch,
                                                           int scratch_stride, float* __restrict__ cand_box,
-                                                          float* __restrict__ cand_score, int32_t* __restrict__ cand_cnt) {
+                                                          float* __restrict__ cand_score, int32_t* __restrict__ cand_cnt,
+                                                          float* __restrict__ cut_gap) {
     // outputs per frame: cand_box [5*nms_pre][4], cand_score [5*nms_pre], cand_cnt [5]
     const int lvl = blockIdx.x, f = blockIdx.y;
     const int N = L.h[lvl] * L.w[lvl] * 3;
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(RpnLevels L, int nms_p
     __shared__ int s_sel_cnt;
     __shared__ unsigned s_prefix;
     __shared__ int s_need;
+    __shared__ float s_below[16];
 
     for (int i = threadIdx.x; i < N; i += blockDim.x) sc[i] = sigmoid_f32(fused ? cls[(i / 3) * 16 + i % 3] : cls[i]);
     __syncthreads();
@@ -153,6 +157,7 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(RpnLevels L, int nms_p
             s_idx[i] = i < N ? i : 0x7fffffff;
         }
         n_sel = N;
+        if (cut_gap && threadIdx.x == 0) cut_gap[f * 5 + lvl] = INFINITY;
         __syncthreads();
     } else {
         // radix select of the k-th largest score (scores >= 0: uint order == float order)
@@ -188,11 +193,13 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(RpnLevels L, int nms_p
         if (threadIdx.x == 0) s_sel_cnt = 0;
         __syncthreads();
         int eq_seen = 0;
+        float below = -1.f;          // largest score under the cut value (scores are >= 0)
         for (int base = 0; base < N; base += blockDim.x) {
             const int i = base + threadIdx.x;
             const float v = i < N ? sc[i] : -1.f;
             const bool gt = v > T;
             const bool eq = (i < N) && (v == T);
+            if (v < T) below = fmaxf(below, v);
             int tot;
             const int r = block_rank(eq, s_w, &tot);
             const bool take = gt || (eq && (eq_seen + r) < need);
@@ -202,6 +209,17 @@ __global__ __launch_bounds__(1024) void rpn_select_kernel(RpnLevels L, int nms_p
                 s_idx[pos] = i;
             }
             eq_seen += tot;
+        }
+        if (cut_gap) {
+            for (int off = 32; off > 0; off >>= 1) below = fmaxf(below, __shfl_down(below, off, 64));
+            if (lane_id() == 0) s_below[wave_id()] = below;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float b = s_below[0];
+                for (int w = 1; w < (int)(blockDim.x >> 6); ++w) b = fmaxf(b, s_below[w]);
+                // eq_seen = all anchors AT the cut value, `need` of them were taken
+                cut_gap[f * 5 + lvl] = eq_seen > need ? 0.f : (b < 0.f ? INFINITY : T - b);
+            }
         }
         __syncthreads();
         n_sel = s_sel_cnt;          // == k
@@ -311,10 +329,25 @@ __global__ __launch_bounds__(256) void gather_kept_kernel(const float* __restric
                                                           int max_n, const int32_t* __restrict__ keep,
                                                           const int32_t* __restrict__ n_keep, int limit,
                                                           float* __restrict__ out_box, float* __restrict__ out_score,
-                                                          int32_t* __restrict__ n_out, int out5) {
+                                                          int32_t* __restrict__ n_out, int out5, float* __restrict__ top_gap,
+                                                          float* __restrict__ order_gap, int margin_stride) {
     // out5 == 0: out_box [f][limit][4] + out_score [f][limit];  out5 == 1: out_box [f][limit][5] (score in col 4)
+    // top_gap / order_gap (may be null; decision margins): score gap across the `limit` cut of the kept list (+inf: no cut), smallest
+    // gap between neighbours of the rows that are output (+inf: fewer than two)
     const int f = blockIdx.x;
     const int n = min(n_keep[f], limit);
+    if (top_gap && threadIdx.x == 0) {
+        const int32_t* kp = keep + (size_t)f * max_n;
+        const float* sc = scores + (size_t)f * max_n;
+        top_gap[(size_t)f * margin_stride] = n_keep[f] > limit ? sc[kp[limit - 1]] - sc[kp[limit]] : INFINITY;
+    }
+    if (order_gap && threadIdx.x == 64) {
+        const int32_t* kp = keep + (size_t)f * max_n;
+        const float* sc = scores + (size_t)f * max_n;
+        float g = INFINITY;
+        for (int r = 1; r < n; ++r) g = fminf(g, sc[kp[r - 1]] - sc[kp[r]]);
+        order_gap[(size_t)f * margin_stride] = g;
+    }
     for (int r = threadIdx.x; r < limit; r += blockDim.x) {
         float b[4] = {0, 0, 0, 0}, s = 0.f;
         if (r < n) {
@@ -673,12 +706,18 @@ __global__ __launch_bounds__(1024) void final_decode_kernel(const float* __restr
                                                             int max_rois, const float* __restrict__ cls,
                                                             const float* __restrict__ reg, float sfx, float sfy,
                                                             float score_thr, float* __restrict__ boxes,
-                                                            float* __restrict__ scores, int32_t* __restrict__ n_out) {
+                                                            float* __restrict__ scores, int32_t* __restrict__ n_out,
+                                                            float* __restrict__ level_margin, float* __restrict__ thr_margin,
+                                                            int margin_stride) {
+    // level_margin / thr_margin (may be null; decision margins): smallest distance of a RoI's log2(scale / 56 + 1e-6) to a level
+    // boundary (1, 2, 3) and smallest |score - score_thr| over the frame's RoIs
     const int f = blockIdx.x;
     __shared__ int s_w[17];
+    __shared__ float s_m[2][16];
     const int n = n_rois[f];
     const float stds[4] = PP_DET_RCNN_STDS;
     int written = 0;
+    float m_lvl = INFINITY, m_thr = INFINITY;
     for (int base = 0; base < n; base += blockDim.x) {
         const int r = base + threadIdx.x;
         bool ok = false;
@@ -694,6 +733,12 @@ __global__ __launch_bounds__(1024) void final_decode_kernel(const float* __restr
             delta2bbox(roi, d, stds, b);
             b[0] = b[0] / sfx; b[1] = b[1] / sfy; b[2] = b[2] / sfx; b[3] = b[3] / sfy;
             ok = s > score_thr;
+            if (level_margin) {
+                m_thr = fminf(m_thr, fabsf(s - score_thr));
+                const float scale = sqrtf((roi[2] - roi[0]) * (roi[3] - roi[1]));
+                const double v = log2((double)(scale / PP_DET_FINEST_SCALE + 1e-6f));
+                m_lvl = fminf(m_lvl, (float)fmin(fmin(fabs(v - 1.0), fabs(v - 2.0)), fabs(v - 3.0)));
+            }
         }
         int tot;
         const int pos = written + block_rank(ok, s_w, &tot);
@@ -705,6 +750,28 @@ __global__ __launch_bounds__(1024) void final_decode_kernel(const float* __restr
         written += tot;
     }
     if (threadIdx.x == 0) n_out[f] = written;
+    if (level_margin) {
+        for (int off = 32; off > 0; off >>= 1) {
+            m_lvl = fminf(m_lvl, __shfl_down(m_lvl, off, 64));
+            m_thr = fminf(m_thr, __shfl_down(m_thr, off, 64));
+        }
+        if (lane_id() == 0) { s_m[0][wave_id()] = m_lvl; s_m[1][wave_id()] = m_thr; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { m_lvl = fminf(m_lvl, s_m[0][w]); m_thr = fminf(m_thr, s_m[1][w]); }
+            level_margin[(size_t)f * margin_stride] = m_lvl;
+            thr_margin[(size_t)f * margin_stride] = m_thr;
+        }
+    }
+}
+
+// min over (frame, level) of the per-level cut gaps -> one figure per frame
+__global__ void rpn_cut_margin_kernel(const float* __restrict__ cut_gap, float* __restrict__ out, int margin_stride, int n_frames) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    float g = INFINITY;
+    for (int l = 0; l < 5; ++l) g = fminf(g, cut_gap[f * 5 + l]);
+    out[(size_t)f * margin_stride] = g;
 }
 
 }  // namespace
@@ -727,7 +794,9 @@ int det_enqueue_rpn(hipStream_t s, const DetRpnArgs& a, int n_frames) {
         memcpy(L.base[l], a.base[l], sizeof(L.base[l]));
     }
     hipLaunchKernelGGL(rpn_select_kernel, dim3(5, n_frames), dim3(1024), 0, s, L, a.nms_pre, a.score_scratch,
-                       a.scratch_stride, a.cand_box, a.cand_score, a.cand_cnt);
+                       a.scratch_stride, a.cand_box, a.cand_score, a.cand_cnt, a.cut_gap);
+    if (a.cut_gap)
+        hipLaunchKernelGGL(rpn_cut_margin_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, s, a.cut_gap, a.cut_margin, a.margin_stride, n_frames);
     hipLaunchKernelGGL(rpn_compact_kernel, dim3(n_frames), dim3(1024), 0, s, a.cand_box, a.cand_score, a.cand_cnt, a.nms_pre,
                        a.max_n, a.boxes, a.boxes_nms, a.scores, a.n_boxes);
     PP_HIP_CHECK(hipGetLastError());
@@ -736,9 +805,9 @@ int det_enqueue_rpn(hipStream_t s, const DetRpnArgs& a, int n_frames) {
 
 int det_enqueue_gather(hipStream_t s, const float* boxes, const float* scores, int max_n, const int32_t* keep,
                        const int32_t* n_keep, int limit, float* out_box, float* out_score, int32_t* n_out, int out5,
-                       int n_frames) {
+                       int n_frames, float* top_gap, float* order_gap, int margin_stride) {
     hipLaunchKernelGGL(gather_kept_kernel, dim3(n_frames), dim3(256), 0, s, boxes, scores, max_n, keep, n_keep, limit,
-                       out_box, out_score, n_out, out5);
+                       out_box, out_score, n_out, out5, top_gap, order_gap, margin_stride);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
@@ -768,9 +837,9 @@ int det_enqueue_roi_align(hipStream_t s, const DetFpnArgs& a, const float* rois,
 
 int det_enqueue_final_decode(hipStream_t s, const float* rois, const int32_t* n_rois, int max_rois, const float* cls,
                              const float* reg, float sfx, float sfy, float score_thr, float* boxes, float* scores,
-                             int32_t* n_out, int n_frames) {
+                             int32_t* n_out, int n_frames, float* level_margin, float* thr_margin, int margin_stride) {
     hipLaunchKernelGGL(final_decode_kernel, dim3(n_frames), dim3(1024), 0, s, rois, n_rois, max_rois, cls, reg, sfx, sfy,
-                       score_thr, boxes, scores, n_out);
+                       score_thr, boxes, scores, n_out, level_margin, thr_margin, margin_stride);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }

@@ -41,6 +41,13 @@ struct pp_detector {
     float *score_scratch, *cand_box, *cand_score, *boxes, *boxes_nms, *scores, *rois, *roi_scores, *fin_boxes, *fin_scores, *out_dets;
     int32_t *cand_cnt, *n_boxes, *keep, *n_keep, *n_rois, *n_fin, *keep2, *n_keep2, *n_out;
     void *nms_scratch1, *nms_scratch2;
+    // decision margins (pp_detector_enable_margins): [frame][PP_DET_N_MARGINS] on the device, the last run's copy on the host
+    int margins_on = 0;
+    float score_weight = 0.f;
+    float *d_margins = nullptr, *cut_gap = nullptr;
+    unsigned char *kflag1 = nullptr, *kflag2 = nullptr;
+    std::vector<float> h_margins;
+    int h_margins_frames = 0;
     float ms[6];
     hipEvent_t ev[7];
 };
@@ -214,7 +221,9 @@ int pp_detector_create(pp_net* netA, pp_net* netB, const int32_t* bufs_a, const 
                  o_nr = carve((size_t)F * 4), o_fb = carve((size_t)F * d->max_rois * 16), o_fs = carve((size_t)F * d->max_rois * 4),
                  o_nf = carve((size_t)F * 4), o_k2 = carve((size_t)F * d->max_rois * 4), o_n2 = carve((size_t)F * 4),
                  o_od = carve((size_t)F * d->max_det * 20), o_no = carve((size_t)F * 4),
-                 o_s1 = carve(pp_nms_batched_scratch_bytes(d->max_n, F)), o_s2 = carve(pp_nms_batched_scratch_bytes(d->max_rois, F));
+                 o_s1 = carve(pp_nms_batched_scratch_bytes(d->max_n, F)), o_s2 = carve(pp_nms_batched_scratch_bytes(d->max_rois, F)),
+                 o_mg = carve((size_t)F * PP_DET_N_MARGINS * 4), o_cg = carve((size_t)F * 5 * 4), o_k1 = carve((size_t)F * d->max_n),
+                 o_kf2 = carve((size_t)F * d->max_rois);
     PP_HIP_CHECK(hipMalloc((void**)&d->d_work, off));
     PP_HIP_CHECK(hipMemset(d->d_work, 0, off));
     char* base = d->d_work;
@@ -226,6 +235,9 @@ int pp_detector_create(pp_net* netA, pp_net* netB, const int32_t* bufs_a, const 
     d->n_fin = (int32_t*)(base + o_nf); d->keep2 = (int32_t*)(base + o_k2); d->n_keep2 = (int32_t*)(base + o_n2);
     d->out_dets = (float*)(base + o_od); d->n_out = (int32_t*)(base + o_no);
     d->nms_scratch1 = base + o_s1; d->nms_scratch2 = base + o_s2;
+    d->d_margins = (float*)(base + o_mg); d->cut_gap = (float*)(base + o_cg);
+    d->kflag1 = (unsigned char*)(base + o_k1); d->kflag2 = (unsigned char*)(base + o_kf2);
+    d->h_margins.assign((size_t)F * PP_DET_N_MARGINS, 0.f);
     for (auto& e : d->ev) PP_HIP_CHECK(hipEventCreate(&e));
     PP_HIP_CHECK(hipStreamSynchronize(s));
     *out = d.release();
@@ -302,11 +314,20 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
     ra.nms_pre = d->nms_pre; ra.max_n = d->max_n; ra.score_scratch = d->score_scratch; ra.scratch_stride = d->scratch_stride;
     ra.cand_box = d->cand_box; ra.cand_score = d->cand_score; ra.cand_cnt = d->cand_cnt;
     ra.boxes = d->boxes; ra.boxes_nms = d->boxes_nms; ra.scores = d->scores; ra.n_boxes = d->n_boxes;
+    // decision margins: one float per frame and decision class, written by the kernels that take the decisions (det_post.hip, nms.hip)
+    const int MS = PP_DET_N_MARGINS;
+    float* mg = d->margins_on ? d->d_margins : nullptr;
+    auto mcol = [&](int k) { return mg ? mg + k : nullptr; };
+    if (mg) {
+        ra.cut_gap = d->cut_gap; ra.cut_margin = mcol(PP_DET_MARGIN_RPN_CUT); ra.margin_stride = MS;
+    }
     rc = det_enqueue_rpn(s, ra, F);
     if (rc != PP_OK) return rc;
-    rc = pp_enqueue_nms_batched(s, d->boxes_nms, d->scores, d->n_boxes, d->max_n, F, d->rpn_iou, d->nms_scratch1, d->keep, d->n_keep);
+    rc = pp_enqueue_nms_batched(s, d->boxes_nms, d->scores, d->n_boxes, d->max_n, F, d->rpn_iou, d->nms_scratch1, d->keep, d->n_keep,
+                                mcol(PP_DET_MARGIN_RPN_NMS), MS, d->score_weight, d->kflag1);
     if (rc != PP_OK) return rc;
-    rc = det_enqueue_gather(s, d->boxes, d->scores, d->max_n, d->keep, d->n_keep, d->max_rois, d->rois, d->roi_scores, d->n_rois, 0, F);
+    rc = det_enqueue_gather(s, d->boxes, d->scores, d->max_n, d->keep, d->n_keep, d->max_rois, d->rois, d->roi_scores, d->n_rois, 0, F,
+                            mcol(PP_DET_MARGIN_RPN_TOP), nullptr, MS);
     if (rc != PP_OK) return rc;
     PP_HIP_CHECK(hipEventRecord(d->ev[3], s));
     stage.next("det.roi_align");
@@ -337,12 +358,20 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
     pp_net_buffer(d->netB, d->roi_cls, &pcls, nullptr);
     pp_net_buffer(d->netB, d->roi_reg, &preg, nullptr);
     rc = det_enqueue_final_decode(s, d->rois, d->n_rois, d->max_rois, (const float*)pcls, (const float*)preg, d->sfx, d->sfy,
-                                  d->score_thr, d->fin_boxes, d->fin_scores, d->n_fin, F);
+                                  d->score_thr, d->fin_boxes, d->fin_scores, d->n_fin, F, mcol(PP_DET_MARGIN_ROI_LEVEL),
+                                  mcol(PP_DET_MARGIN_SCORE_THR), MS);
     if (rc != PP_OK) return rc;
-    rc = pp_enqueue_nms_batched(s, d->fin_boxes, d->fin_scores, d->n_fin, d->max_rois, F, d->det_iou, d->nms_scratch2, d->keep2, d->n_keep2);
+    rc = pp_enqueue_nms_batched(s, d->fin_boxes, d->fin_scores, d->n_fin, d->max_rois, F, d->det_iou, d->nms_scratch2, d->keep2, d->n_keep2,
+                                mcol(PP_DET_MARGIN_DET_NMS), MS, d->score_weight, d->kflag2);
     if (rc != PP_OK) return rc;
-    rc = det_enqueue_gather(s, d->fin_boxes, d->fin_scores, d->max_rois, d->keep2, d->n_keep2, d->max_det, d->out_dets, nullptr, d->n_out, 1, F);
+    rc = det_enqueue_gather(s, d->fin_boxes, d->fin_scores, d->max_rois, d->keep2, d->n_keep2, d->max_det, d->out_dets, nullptr, d->n_out, 1, F,
+                            mcol(PP_DET_MARGIN_DET_TOP), mcol(PP_DET_MARGIN_DET_ORDER), MS);
     if (rc != PP_OK) return rc;
+    d->h_margins_frames = 0;
+    if (mg) {
+        PP_HIP_CHECK(hipMemcpyAsync(d->h_margins.data(), mg, (size_t)F * MS * sizeof(float), hipMemcpyDeviceToHost, s));
+        d->h_margins_frames = F;
+    }
     PP_HIP_CHECK(hipEventRecord(d->ev[6], s));
     PP_HIP_CHECK(hipMemcpyAsync(dets, d->out_dets, (size_t)F * d->max_det * 5 * sizeof(float), hipMemcpyDeviceToHost, s));
     PP_HIP_CHECK(hipMemcpyAsync(n_dets, d->n_out, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -350,6 +379,24 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
     if (n_proposals) PP_HIP_CHECK(hipMemcpyAsync(n_proposals, d->n_rois, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     PP_HIP_CHECK(hipStreamSynchronize(s));
     for (int i = 0; i < 6; ++i) (void)hipEventElapsedTime(&d->ms[i], d->ev[i], d->ev[i + 1]);
+    return PP_OK;
+}
+
+int pp_detector_enable_margins(pp_detector* d, int enable, float score_weight) {
+    PP_REQUIRE(d, "pp_detector_enable_margins: detector is NULL");
+    PP_REQUIRE(!enable || score_weight > 0.f, "pp_detector_enable_margins: score_weight must be positive");
+    PP_HIP_CHECK(hipStreamSynchronize(d->ctx->stream));
+    d->margins_on = enable != 0;
+    d->score_weight = score_weight;
+    d->h_margins_frames = 0;
+    return PP_OK;
+}
+
+int pp_detector_margins(pp_detector* d, int n_frames, float* margins) {
+    PP_REQUIRE(d && margins, "pp_detector_margins: NULL argument");
+    PP_REQUIRE(d->margins_on, "pp_detector_margins: margins are not enabled (pp_detector_enable_margins)");
+    PP_REQUIRE(n_frames == d->h_margins_frames, "pp_detector_margins: the last run had %d frames, %d asked for", d->h_margins_frames, n_frames);
+    memcpy(margins, d->h_margins.data(), (size_t)n_frames * PP_DET_N_MARGINS * sizeof(float));   // (pp_detector_run synchronised after the copy)
     return PP_OK;
 }
 

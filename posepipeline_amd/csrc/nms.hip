@@ -123,7 +123,8 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const T* __restrict__ boxe
 __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long* __restrict__ mask,
                                                        const int32_t* __restrict__ order, const int32_t* __restrict__ n_ptr,
                                                        int max_n, int words, int32_t* __restrict__ keep,
-                                                       int32_t* __restrict__ n_keep) {
+                                                       int32_t* __restrict__ n_keep, unsigned char* __restrict__ kflag) {
+    // kflag (may be null; decision margins): [frame][max_n], 1 where the box at that SORTED position is kept
     constexpr int WPL = MAX_N / 64 / 64;     // words per lane (2)
     const int f = blockIdx.x;
     const int n = n_ptr[f];
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long*
             }
         }
         if ((keepmask >> lane) & 1ull) kp[cnt + __popcll(keepmask & ((1ull << lane) - 1ull))] = ord[i];
+        if (kflag && lane < nb) kflag[(size_t)f * max_n + i] = (unsigned char)((keepmask >> lane) & 1ull);
         cnt += __popcll(keepmask);
         // later words: lane owns words lane and lane + 64
         unsigned long long km = keepmask;
@@ -185,9 +187,92 @@ __global__ __launch_bounds__(64) void nms_sweep_kernel(const unsigned long long*
     if (lane == 0) n_keep[f] = cnt;
 }
 
+// ---- decision margin of a finished NMS (convention 0) ----------------------------------------------------------------------------
+// Which perturbation of the inputs leaves the kept LIST as it is?  Walk the boxes in score order and assume every earlier decision
+// stands.  A KEPT box j stays kept while every kept predecessor i stays under the threshold: margin thr - IoU(i, j).  A SUPPRESSED box j
+// stays suppressed while ONE kept predecessor keeps suppressing it: the best over its suppressors of min(IoU - thr, w (s_i - s_j)) --
+// the second term because a suppressor only counts while it stays AHEAD of j in the order (w converts a score lead into IoU units:
+// pp_detector_enable_margins).  A later box that would overtake j and suppress it is itself suppressed or kept today and contributes its
+// own margin.  The frame's figure is the minimum over all boxes; by induction over the order, inputs perturbed by less than it (IoU) --
+// and scores by less than it / (2 w) -- give the same kept list in the same order of decisions.
+// grid (ceil(max_n / 256), frames), 256 threads: thread = box j, tiles of 256 predecessors through LDS; only kept predecessors cost.
+__global__ __launch_bounds__(256) void nms_margin_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                         const int32_t* __restrict__ order, const unsigned char* __restrict__ kflag,
+                                                         const int32_t* __restrict__ n_ptr, int max_n, float thr, float score_weight,
+                                                         unsigned* __restrict__ margin, int margin_stride) {
+    const int f = blockIdx.y;
+    const int n = n_ptr[f];
+    const int j0 = blockIdx.x * 256;
+    if (j0 >= n) return;
+    __shared__ float4 s_box[256];
+    __shared__ float s_sc[256];
+    __shared__ unsigned char s_kf[256];
+    __shared__ float s_red[4];
+    const float* bx = boxes + (size_t)f * max_n * 4;
+    const float* sc = scores + (size_t)f * max_n;
+    const int32_t* ord = order + (size_t)f * max_n;
+    const unsigned char* kf = kflag + (size_t)f * max_n;
+    const int j = j0 + threadIdx.x;
+    float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sj = 0.f, area_j = 0.f;
+    bool kept_j = false;
+    if (j < n) {
+        const int oj = ord[j];
+        bj = *reinterpret_cast<const float4*>(bx + (size_t)oj * 4);
+        sj = sc[oj];
+        kept_j = kf[j] != 0;
+        area_j = (bj.z - bj.x) * (bj.w - bj.y);
+    }
+    float m_keep = INFINITY, m_sup = -1.f;
+    const int jend = min(j0 + 256, n);
+    for (int i0 = 0; i0 < jend; i0 += 256) {
+        __syncthreads();
+        const int i = i0 + threadIdx.x;
+        if (i < n) {
+            const int oi = ord[i];
+            s_box[threadIdx.x] = *reinterpret_cast<const float4*>(bx + (size_t)oi * 4);
+            s_sc[threadIdx.x] = sc[oi];
+            s_kf[threadIdx.x] = kf[i];
+        } else {
+            s_kf[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        const int cnt = min(256, jend - i0);
+        for (int t = 0; t < cnt; ++t) {
+            if (!s_kf[t]) continue;                    // (uniform: every lane looks at the same predecessor)
+            if (i0 + t >= j) continue;
+            const float4 a = s_box[t];
+            const float area_a = (a.z - a.x) * (a.w - a.y);
+            const float w = fmaxf(fminf(a.z, bj.z) - fmaxf(a.x, bj.x), 0.f);
+            const float h = fmaxf(fminf(a.w, bj.w) - fmaxf(a.y, bj.y), 0.f);
+            const float inter = w * h;
+            const float uni = (area_a + area_j) - inter;
+            const float iou = uni > 0.f ? inter / uni : 0.f;
+            const float d = iou - thr;
+            if (kept_j) m_keep = fminf(m_keep, -d);
+            else if (d > 0.f) m_sup = fmaxf(m_sup, fminf(d, score_weight * (s_sc[t] - sj)));
+        }
+    }
+    // (the division above and the product form of the decision can disagree by an ulp at the threshold: clamp at zero)
+    float mj = INFINITY;
+    if (j < n) mj = kept_j ? fmaxf(m_keep, 0.f) : fmaxf(m_sup, 0.f);
+    for (int off = 32; off > 0; off >>= 1) mj = fminf(mj, __shfl_down(mj, off, 64));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = mj;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float r = fminf(fminf(s_red[0], s_red[1]), fminf(s_red[2], s_red[3]));
+        atomicMin(margin + (size_t)f * margin_stride, __float_as_uint(r));     // non-negative floats order like their bit patterns
+    }
+}
+
+__global__ void fill_u32_strided_kernel(unsigned* p, int stride, int n, unsigned v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[(size_t)i * stride] = v;
+}
+
 template <typename T, int CONV>
 int run_nms(hipStream_t s, const T* d_boxes, const T* d_scores, const int32_t* d_n, int max_n, int n_frames, T thr,
-            int32_t* d_order, unsigned long long* d_mask, int32_t* d_keep, int32_t* d_nkeep) {
+            int32_t* d_order, unsigned long long* d_mask, int32_t* d_keep, int32_t* d_nkeep, unsigned char* d_kflag = nullptr) {
     const size_t lds = (size_t)MAX_N * (sizeof(T) + sizeof(int32_t));
     static PpPerDeviceOnce attr_set;
     attr_set.run([&] { (void)hipFuncSetAttribute((const void*)sort_desc_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
@@ -195,7 +280,7 @@ int run_nms(hipStream_t s, const T* d_boxes, const T* d_scores, const int32_t* d
     const int words = (max_n + 63) / 64;
     hipLaunchKernelGGL((nms_mask_kernel<T, CONV>), dim3(words, words, n_frames), dim3(64), 0, s, d_boxes, d_order, d_n, max_n,
                        thr, d_mask, words);
-    hipLaunchKernelGGL(nms_sweep_kernel, dim3(n_frames), dim3(64), 0, s, d_mask, d_order, d_n, max_n, words, d_keep, d_nkeep);
+    hipLaunchKernelGGL(nms_sweep_kernel, dim3(n_frames), dim3(64), 0, s, d_mask, d_order, d_n, max_n, words, d_keep, d_nkeep, d_kflag);
     PP_HIP_CHECK(hipGetLastError());
     return PP_OK;
 }
@@ -210,12 +295,21 @@ size_t scratch_bytes(int max_n, int n_frames) {
 size_t pp_nms_batched_scratch_bytes(int max_n, int n_frames) { return scratch_bytes(max_n, n_frames); }
 
 int pp_enqueue_nms_batched(hipStream_t s, const float* boxes, const float* scores, const int32_t* n, int max_n,
-                           int n_frames, float thr, void* scratch, int32_t* keep, int32_t* n_keep) {
+                           int n_frames, float thr, void* scratch, int32_t* keep, int32_t* n_keep, float* margin,
+                           int margin_stride, float score_weight, unsigned char* kflag_scratch) {
     PP_REQUIRE(max_n > 0 && max_n <= MAX_N, "nms: max_n=%d not in (0,%d]", max_n, MAX_N);
+    PP_REQUIRE(!margin || kflag_scratch, "nms: the decision margin needs the kept-flag scratch");
     int32_t* order = static_cast<int32_t*>(scratch);
     unsigned long long* mask = reinterpret_cast<unsigned long long*>(
         static_cast<char*>(scratch) + ScratchCursor::align((size_t)n_frames * max_n * 4));
-    return run_nms<float, 0>(s, boxes, scores, n, max_n, n_frames, thr, order, mask, keep, n_keep);
+    int rc = run_nms<float, 0>(s, boxes, scores, n, max_n, n_frames, thr, order, mask, keep, n_keep, margin ? kflag_scratch : nullptr);
+    if (rc != PP_OK || !margin) return rc;
+    hipLaunchKernelGGL(fill_u32_strided_kernel, dim3((n_frames + 63) / 64), dim3(64), 0, s, reinterpret_cast<unsigned*>(margin),
+                       margin_stride, n_frames, 0x7f800000u);
+    hipLaunchKernelGGL(nms_margin_kernel, dim3((max_n + 255) / 256, n_frames), dim3(256), 0, s, boxes, scores, order, kflag_scratch, n,
+                       max_n, thr, score_weight, reinterpret_cast<unsigned*>(margin), margin_stride);
+    PP_HIP_CHECK(hipGetLastError());
+    return PP_OK;
 }
 
 extern "C" int pp_nms(pp_ctx* ctx, const void* boxes, const void* scores, int n, double iou_thr, int convention,

@@ -235,6 +235,20 @@ class Detector:
         except Exception:
             pass
 
+    MARGIN_NAMES = ("rpn_cut", "rpn_nms", "rpn_top", "roi_level", "score_thr", "det_nms", "det_top", "det_order")
+
+    def enable_margins(self, enable=True, score_weight=8.0):
+        """per-frame decision margins with every run (include/posepipe_hip.h: pp_detector_enable_margins); read them with
+        `margins()` after `run`.  score_weight: IoU error bound / (2 x score error bound) of the numerics to be certified."""
+        L.check(self.ctx.lib.pp_detector_enable_margins(self.handle, int(bool(enable)), C.c_float(score_weight)), "pp_detector_enable_margins")
+        self._margins_on = bool(enable)
+
+    def margins(self, n_frames):
+        """[n_frames][8] float32 (MARGIN_NAMES) of the most recent run"""
+        m = np.zeros((n_frames, len(self.MARGIN_NAMES)), np.float32)
+        L.check(self.ctx.lib.pp_detector_margins(self.handle, n_frames, L.ptr(m)), "pp_detector_margins")
+        return m
+
     def run(self, frames, want_proposals=False, frames_dev=None):
         """frames: numpy [F][H][W][3] u8 BGR (or frames_dev=(ptr, F) for device-resident frames)."""
         if frames_dev is not None:

@@ -32,7 +32,7 @@ def test_binding_table_matches_header():
     assert bound <= names, f"bound but not declared: {sorted(bound - names)}"
     # everything the Python host side binds must load
     _lib.load_library()
-    assert _lib.load_library().pp_abi_version() == 9
+    assert _lib.load_library().pp_abi_version() == 10
 
 
 def test_struct_layout_matches_header():

@@ -484,3 +484,56 @@ def test_integer_contract_1080p_64_frames_no_replay(ctx):
                 matched += 1
     print(f"[split] frames with the exact cascade's id list: {same_ids} / {n}; tracked boxes re-found within {BOX_TOL['split']} px: {matched} / {total}")
     assert matched >= 0.9 * total
+
+
+def test_certified_ids_1080p_64_frames_no_replay(ctx):
+    """the product tells the caller which frames are decided.  Cascade(id_numerics="certified") runs the detector on
+    the fast kernels with per-frame decision margins (pp_detector_enable_margins: det_post.hip / nms.hip) and re-runs the frames whose
+    closest decision is within the split kernels' measured error through the float32-MFMA detector.  Held here, at 1080p / 64 frames /
+    no replay / seeded-random detector weights:
+      * every certified frame's detections are the SAME rows in the same order as the exact detector's, within float tolerance (the
+        certificate: no integer decision of that frame flipped) -- and there is at least one frame the fast kernels DO decide
+        differently in this clip, which the margins caught (it is among the re-run ones);
+      * ids / tracked rows of the certified cascade == the exact cascade's on all 64 frames (the re-run frames are bit-identical, the
+        certified ones differ in the last float digits of their boxes only);
+      * the margins themselves: +inf / >= 0, reproducible, and the exact detector reports margins of the same size (they are a
+        property of the frame, not of the numerics)."""
+    from posepipeline_amd.cascade import CERTIFY_EPS
+    n, chunk = 64, 16
+    frames = _clip_1080p_four_persons(n, np.random.default_rng(41))
+    spec = hrnet.hrnet_w48_384x288()
+    sds = (_det_sd(), synth.smooth_state_dict(hrnet.hrnet_param_shapes(spec), seed=11), _lift_sd(), spec)
+    cas_e, tr_e, k2_e, _ = _run_no_replay(ctx, frames, sds, chunk, numerics="exact")
+    cas_c, tr_c, k2_c, _ = _run_no_replay(ctx, frames, sds, chunk, numerics="split", id_numerics="certified")
+    st = cas_c.certify_stats
+    print(f"[certified] frames {st['frames']}, certified by their margins {st['certified']}, run on the exact detector alone {st['exact_only_frames']}")
+    assert st["frames"] == n
+    assert [[r[0] for r in fr_] for fr_ in tr_c] == [[r[0] for r in fr_] for fr_ in tr_e]
+    for a, b in zip(tr_c, tr_e):
+        assert np.abs(np.array([r[1:6] for r in a], np.float64) - np.array([r[1:6] for r in b], np.float64)).max(initial=0.0) <= BOX_TOL["split"]
+    assert sorted(k2_c) == sorted(k2_e)
+    # the certificate itself, frame by frame, without the fallback policy in the way: margins of the fast detector vs what it decided
+    det_s, det_e = cas_c.detector, cas_c.detector_exact
+    det_e.enable_margins(True, CERTIFY_EPS["rpn_nms"] / (2.0 * CERTIFY_EPS["rpn_cut"]))
+    n_cert = n_diff = n_diff_caught = 0
+    for i in range(0, n, chunk):
+        ds = det_s.run(frames[i:i + chunk])
+        ms = det_s.margins(chunk)
+        de = det_e.run(frames[i:i + chunk])
+        me = det_e.margins(chunk)
+        assert (ms >= 0).all() and (me >= 0).all()
+        assert np.array_equal(ms, det_s.margins(chunk))
+        redo = set(cas_c.uncertified_frames(ds, ms).tolist())
+        for f in range(chunk):
+            same = ds[f].shape == de[f].shape and (len(ds[f]) == 0 or np.abs(ds[f][:, :4] - de[f][:, :4]).max() <= BOX_TOL["split"])
+            if f not in redo:
+                n_cert += 1
+                assert same, f"frame {i + f} was certified but the fast detector's rows differ from the exact detector's"
+            if not same:
+                n_diff += 1
+                n_diff_caught += f in redo
+        # margins are a property of the frame: same order of magnitude from both detectors wherever both are finite and not tiny
+        both_ok = np.isfinite(ms) & np.isfinite(me) & (ms > 1e-4) & (me > 1e-4)
+        assert np.allclose(ms[both_ok], me[both_ok], rtol=0.2)
+    print(f"[certified] per-frame check: {n_cert} of {n} frames certified, {n_diff} frames where the fast detector's rows differ, all {n_diff_caught} caught")
+    assert n_diff == n_diff_caught
