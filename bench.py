@@ -751,7 +751,7 @@ def cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames, gt, n_frames, cascade
     clib.lib()
     det_model, pose_model, lift_model = odet.FasterRCNNRef(det_sd), onets.HRNetRef(pose_sd, 48), onets.VideoPose3DRef(lift_sd)
     pick = sorted({int(round(i * (len(frames) - 1) / max(1, n_frames - 1))) for i in range(n_frames)})
-    ref, dt, t_det = [], 0.0, 0.0
+    ref, crops, dt, t_det = [], [], 0.0, 0.0
     for j, fi in enumerate(pick):
         frame_bgr, gt_box = frames[fi], gt[fi][0]
         t0 = time.perf_counter()
@@ -768,6 +768,7 @@ def cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames, gt, n_frames, cascade
             dt += time.perf_counter() - t0
             t_det += t1 - t0
         ref.append((fi, bb, dets, kp, k3))
+        crops.append((t, c, s, kp))
     n_timed = min(timed_frames, len(pick))
     readout = {}
     for mode, cas in cascades.items():
@@ -799,11 +800,47 @@ def cpu_baseline_cascade(det_sd, pose_sd, lift_sd, frames, gt, n_frames, cascade
                          "note": "seeded-random detector / pose weights (lifting weights: metre-sized contractions): the detector's 100-of-~1000 cut and NMS sit on near-ties, heat-maps are noise "
                                  "(ill-conditioned arg-max / DARK step); the tolerance claims are tests/test_gpu_parity_modes.py "
                                  "(well-conditioned weights, margin-aware detector check)"}
+    readout["fp32_reordering_control"] = reordering_control(cascades.get("default"), pose_sd, crops)
     readout["well_conditioned_end_to_end"] = parity_well_conditioned(cascades.get("default"), frames, gt, pick[:3])
     return {"value": n_timed / dt, "unit": "frames/s", "cores": clib.N_THREADS, "kind": "port",
             "sample": "%d synthetic 1080p frame(s) through the CPU restatement of detect + top-down 2D (W48, flip) + one lifting window "
                       "(%.1f s, detector %.1f s); parity readout over %d frames" % (n_timed, dt, t_det, len(ref)),
             "parity_vs_gpu": readout}
+
+
+def reordering_control(cas, pose_sd, crops):
+    """How far do the SAME frames' joints move under a float32 evaluation that is as valid as the oracle's but sums in another order?
+    The bit-exact float32-MFMA kernels on the TRANSPOSED network (inputs and every kernel transposed, heat-maps transposed back: the
+    FMA chain visits the taps in another order -- what separates the oracle from the reference's own cuDNN / BLAS), decoded by the
+    same decode kernel, against the oracle's joints.  It is what `max_abs_diff_2d_px` of the modes above is to be read against: with
+    the timed workload's seeded-random pose weights the heat-maps are noise and DARK's Taylor step is ill-conditioned.
+    crops: [(tensor [3][H][W], center, scale, oracle joints [1][K][3])]."""
+    if cas is None or not crops:
+        return None
+    from posepipeline_amd import ops
+    from posepipeline_amd.models import hrnet
+    from posepipeline_amd.program import Net
+    spec = hrnet.hrnet_w48_384x288()
+    tspec = hrnet.HRNetSpec(spec.width, spec.num_joints, spec.in_w, spec.in_h)
+    tsd = {k: (np.ascontiguousarray(np.transpose(v, (0, 1, 3, 2))) if np.ndim(v) == 4 else v) for k, v in pose_sd.items()}
+    tnet = Net(cas.ctx, hrnet.build_hrnet_program(tspec, tsd), max_batch=2, numerics="exact")
+    worst, n_over, n_joint = 0.0, 0, 0
+    for t, c, sc, kp in crops:
+        x = np.zeros((2, spec.in_w, spec.in_h, 4), np.float32)          # transposed NHWC: [W][H][c]
+        x[0, :, :, :3] = np.transpose(t, (2, 1, 0))
+        x[1, :, :, :3] = np.transpose(t[:, :, ::-1], (2, 1, 0))          # the flipped crop
+        hm = tnet.forward(x).reshape(2, 17, spec.in_w // 4, spec.in_h // 4)      # (heat-maps leave as NCHW planes: [K][W/4][H/4] here)
+        hm = np.ascontiguousarray(np.transpose(hm, (0, 1, 3, 2)))               # -> [2][K][H/4][W/4]
+        cs = np.array([[c[0], c[1], sc[0], sc[1]]], np.float32)
+        kc, _ = ops.flip_merge_decode(cas.ctx, hm[:1], hm[1:], cs, flip_perm=hrnet.flip_perm(17), post="unbiased", blur_kernel=17)
+        d = np.abs(kc[0, :, :2] - kp[0, :, :2]).max(axis=1)
+        worst = max(worst, float(d.max()))
+        n_over += int((d > 1e-3).sum())
+        n_joint += d.size
+    return {"max_abs_diff_2d_px": worst, "joints_beyond_1e-3_px": n_over, "joints": n_joint,
+            "note": "the bit-exact float32-MFMA kernels on the TRANSPOSED HRNet (another summation order of the same float32 arithmetic) "
+                    "vs the oracle's joints on the same crops: the movement ANY equally valid float32 evaluation shows on these "
+                    "(seeded-random, ill-conditioned) heat-maps -- the yardstick for the modes' max_abs_diff_2d_px"}
 
 
 def parity_well_conditioned(cas, frames, gt, pick):
