@@ -77,6 +77,7 @@ struct SplitArgs {
     long long S;                          // STREAM: positions of the padded input stream, GEMM: output pixels
     unsigned x_bytes;
     int xcd_remap;
+    int SP;                               // strided-patch form: slots per phase map ((TH + 1) x PWp)
     int gx, gy;                           // xcd_remap: logical grid (pixel tiles, channel columns) of the 1-D launch
     int col_major;                        // xcd_remap: an XCD walks its tiles column by column (small inputs) instead of tile by tile
     int epi_lds;                          // conv_split_gemm_kernel: epilogue transposed through LDS (whole 128-byte lines per store)
@@ -282,8 +283,18 @@ enum { MODE_TILE = 0, MODE_STREAM = 1, MODE_GEMM = 2 };
 // Every wave copies ceil(COB * 3 / 4) fragments per tap (duplicates where 4 does not divide: the counts must be wave-uniform).
 // H (round 5): the fp16 form -- TWO activation planes (h0, h1) in the patch, three weight planes (g0, g1, g2) in the same fragment
 // order and ring, three products per term instead of six; the epilogue multiplies by 1 / (s c) per output channel.
-template <int T, int NSLOT, int COB, int PXB = 2, int NW = 4, bool RING4 = false, bool H = false>
+// S2 (round 6; fp16 form, RING4, PXB = 1): 3x3 / STRIDE 2 / pad 1 with a strided patch.  Tap (dy, dx) of output pixel (y, x) is input
+// pixel (2y + dy - 1, 2x + dx - 1): in stored coordinates r = 2y + dy, c = 2x + dx, i.e. PHASE (dy & 1, dx & 1) of the input at position
+// (y + (dy >> 1), x + (dx >> 1)).  The patch of a TH x TW output tile -- (2 TH + 1) x (2 TW + 1) input pixels -- is therefore written to LDS
+// DE-INTERLEAVED into its four phases, each a (TH + 1) x (TW + 1) map of pitch PWp: within one phase neighbouring output pixels are
+// neighbouring slots, and the nine taps are nine offsets (phase base + shift) exactly as in the stride-1 kernel -- same fragment reads,
+// same weight fragments and ring, every input element staged ONCE per channel column and no padding products (the tap-gather product
+// staged every element 2.25 times; 95 - 210 TFLOP/s).  The de-interleave costs nothing at the LDS side: slot q of the patch is phase-major
+// and the GLOBAL address of a slot is computed from it (neighbouring slots load pixels two apart).  128-pixel tiles (the strided patch
+// of 256 would need 18 float4 of staging registers per thread): two workgroups per CU with the single-buffered patch (<= 40 KB) + ring.
+template <int T, int NSLOT, int COB, int PXB = 2, int NW = 4, bool RING4 = false, bool H = false, bool S2 = false>
 __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(SplitArgs a) {
+    static_assert(!S2 || (T == 9 && RING4 && H && PXB == 1), "S2 is the 4-wave fp16 ring form with one pixel block per wave");
     constexpr int NT = 64 * NW;
     constexpr int XP = H ? 2 : 3;                     // activation planes
     constexpr int WPL = H ? 2 : 3;                    // weight planes (H: g0, g1 -- the third product reuses g0)
@@ -353,7 +364,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
         const bool in_patch = p < a.NP;
         unsigned off = 0xffffffffu;
         if constexpr (H) simg[j] = n;
-        if (a.mode == MODE_TILE) {
+        if constexpr (S2) {
+            // slot p = (phase, row, column) of the de-interleaved patch (dv_row holds the reciprocal of SP in this form)
+            const int ph = (int)pp_udiv((unsigned)p, a.dv_row), r = p - ph * a.SP;
+            const int qr = (int)pp_udiv((unsigned)r, a.dv_pw), qc = r - qr * a.PWp;
+            const int pr = 2 * qr + (ph >> 1), pc = 2 * qc + (ph & 1);
+            const int iy = 2 * y0 - 1 + pr, ix = 2 * x0 - 1 + pc;
+            if (in_patch && pc <= 2 * a.TW && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win)
+                off = (unsigned)(((n * a.xp_h + iy) * a.xp_w + ix) * a.Cin) * 4u;
+        } else if (a.mode == MODE_TILE) {
             const int pr = (int)pp_udiv((unsigned)p, a.dv_pw), pc = p - pr * a.PWp;
             const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
             if (in_patch && pc < a.TW + 2 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
@@ -535,7 +554,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     }
 
     auto load_x = [&](const unsigned char* pbuf, int t, int pb) {
-        const int toff = T == 9 ? ((t / 3) * a.PWp + (t % 3)) * 16 : 0;
+        const int dy = t / 3, dx = t % 3;
+        const int toff = S2 ? ((((dy & 1) * 2 + (dx & 1)) * a.SP) + (dy >> 1) * a.PWp + (dx >> 1)) * 16 : T == 9 ? (dy * a.PWp + dx) * 16 : 0;
 #pragma unroll
         for (int pl = 0; pl < XP; ++pl) xf[pb][pl] = *reinterpret_cast<const uint4*>(pbuf + pl * plane_bytes + aofs[pb] + toff);
     };
@@ -1964,6 +1984,37 @@ TileGeom pick_tile(int H, int W, int max_np, int pxb) {
     return best;
 }
 
+// strided-patch form: the 128-pixel output tile (4 blocks of 32 pixels, one per wave) whose de-interleaved patch -- four phase maps of
+// (TH + 1) x PWp slots -- serves the map best: pixels wasted at the edges against slots staged per tile
+TileGeom pick_tile_s2(int H, int W, int max_np) {
+    static const int force = env_int("POSEPIPE_SPLIT_TILE_S2", -1);
+    TileGeom best{};
+    best.eff = -1.0;
+    // (bw_log2, gx_log2): 4x32 (1x32 blocks stacked), 8x16 (2x16 blocks stacked), 16x8 (4x8 blocks stacked), 4x32 as 2x2 blocks of 2x16
+    const int cand[4][2] = {{0, 0}, {1, 0}, {2, 0}, {1, 1}};
+    for (int i = 0; i < 4; ++i) {
+        if (force >= 0 && i != force) continue;
+        TileGeom g{};
+        g.bw_log2 = cand[i][0];
+        g.gx_log2 = cand[i][1];
+        const int BW = 32 >> g.bw_log2, BH = 1 << g.bw_log2, GX = 1 << g.gx_log2, GY = 4 / GX;
+        g.TW = GX * BW;
+        g.TH = GY * BH;
+        g.PWp = g.TW + 1;
+        if (g.bw_log2 == 2)
+            while (g.PWp % 8 != 4) ++g.PWp;       // two rows of a 4x8 block per lane group: 128 B apart mod 256
+        g.NP = 4 * (g.TH + 1) * g.PWp;
+        g.NPp = g.NP;
+        while (g.NPp % 8 != 4) ++g.NPp;
+        g.tiles_x = (W + g.TW - 1) / g.TW;
+        g.tiles_y = (H + g.TH - 1) / g.TH;
+        if (g.NP > max_np) continue;
+        g.eff = (double)H * W / ((double)g.tiles_x * g.tiles_y * 128.0) - 0.05 * g.NP / 612.0;
+        if (g.eff > best.eff) best = g;
+    }
+    return best;
+}
+
 // ---- the 7x7 / stride 2 / 4 -> 64 stem (ResNet-50 conv1), fp16 form ---------------------------------------------------------------------
 // The float32 matrix kernels run this layer at 0.46 of THEIR peak (73 TFLOP/s) while it writes 2.85 GB per 64 frames: as a split product
 // it is bound by that write.  K is walked as (dy, dx8, c) with the 7 taps of a row padded to 8 (the eighth has zero weights):
@@ -2197,6 +2248,12 @@ static bool split_stem7(const ConvArgs& a) {
 // how the split kernel sees the layer: taps (9 / 1) and channels per tap (a full-cover 'valid' conv is a 1x1 over KH*KW*Cin)
 // committed: the layer was selected when its split weights were built (pp_net_create_ex / the caller of pp_conv_split_eligible), so
 // the launch path derives the SAME form from the shape alone -- no knob is read at launch time (ABI 7: nothing is decided at launch)
+// POSEPIPE_SPLIT_S2P=0: the strided-patch form off (A/B runs; read once per process)
+static bool split_s2_patch_on() {
+    static const int on = env_int("POSEPIPE_SPLIT_S2P", 1);
+    return on != 0;
+}
+
 static bool split_shape(const ConvArgs& a, int* taps, int* cin, int* mode, bool committed = false) {
     const bool k3 = a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad_h == 1 && a.pad_w == 1 && a.dil_h == 1 && a.dil_w == 1 &&
                     a.Hout == a.Hin && a.Wout == a.Win;
@@ -2219,11 +2276,22 @@ static bool split_shape(const ConvArgs& a, int* taps, int* cin, int* mode, bool 
     const bool s2_f16 = a.split_f16 != 0 || (a.numerics == 0 && pp_conv_split_f16_default());
     const bool s2_pick = committed || (s2_env ? a.Cin >= atoi(s2_env)
                                               : s2_f16 ? (a.Cin >= 96 || (a.Cin >= 48 && s2_ncb >= 6)) : (a.Cin >= 128 && (s2_ncb & 1) == 0));
-    const bool k3s2 = s2_on && a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad_h == 1 && a.pad_w == 1 && a.dil_h == 1 && a.dil_w == 1 && !full && s2_pick;
+    // Round 6 (fp16 form): the STRIDED-PATCH form (conv_split_kernel<.., S2>) takes every 3x3 / stride-2 / pad-1 layer -- it stages each input
+    // element once and has no padding products, so the break-even rules above do not apply to it.  Same weight fragments ([chunk][tap]
+    // order) as the tap-gather product, which stays the bf16 form's (and POSEPIPE_SPLIT_S2P=0's) kernel: mode MODE_TILE + stride 2.
+    const bool s2_shape = a.KH == 3 && a.KW == 3 && a.stride == 2 && a.pad_h == 1 && a.pad_w == 1 && a.dil_h == 1 && a.dil_w == 1 && !full;
+    // Same-box per-op tables (profile_net w48 128 / det 64, S2P on / off): 48 -> 96 at 96x72 1.37 -> 0.91 ms (float32 kernel before), 256 -> 96
+    // 0.66 -> 0.39, 64 -> 64 at 192x144 0.55 -> 0.37, 96 -> 192 1.07 -> 0.97, 48 -> 48 0.81 -> 0.76; ResNet-50 128 -> 128 at 160x272 1.07 -> 0.88,
+    // 256 -> 256 1.01 -> 0.72, 512 -> 512 1.00 -> 0.93.  It LOSES where a 128-pixel tile does not fit the output map: 12x9 outputs (192 -> 384
+    // 0.39 -> 0.43, 96 -> 384 0.15 -> 0.16, 48 -> 384 0.09 -> 0.11) and 48 -> 48 onto 24x18 (0.07 -> 0.08) -- those keep their former kernels.
+    // The rule reads the layer's shape only (never the batch, never a knob at launch).
+    const bool s2p_map = a.Hout * a.Wout >= 1500 || (a.Hout * a.Wout >= 400 && a.Cout >= 96);
+    const bool s2p = split_s2_patch_on() && s2_f16 && s2_shape && s2p_map;
+    const bool k3s2 = s2_on && s2_shape && (s2_pick || s2p);
     if (!(k3 || k1 || full || k3s2)) return false;
     *taps = (k3 || k3s2) ? 9 : 1;
     *cin = full ? a.K : a.Cin;
-    *mode = k3 ? MODE_TILE : MODE_GEMM;
+    *mode = (k3 || (k3s2 && s2p)) ? MODE_TILE : MODE_GEMM;
     return true;
 }
 
@@ -2271,7 +2339,7 @@ static bool split_c48(const ConvArgs& a) {
     static const int on = env_int("POSEPIPE_SPLIT_C48", 1), mult = env_int("POSEPIPE_SPLIT_C48_MULT", 0);
     int taps, cin, mode;
     const bool shape = (a.Cout > 32 && a.Cout <= 48) || (mult == 1 && a.Cout % 48 == 0) || (mult == 2 && a.Cout == 192);
-    return on && shape && split_shape(a, &taps, &cin, &mode) && mode == MODE_TILE;
+    return on && shape && a.stride == 1 && split_shape(a, &taps, &cin, &mode) && mode == MODE_TILE;
 }
 static int split_ncb16(const ConvArgs& a) { return (a.Cout + 47) / 48 * 3; }      // 16-channel blocks, whole columns of 3
 
@@ -2545,6 +2613,59 @@ int pp_launch_conv_split(const ConvArgs& a, hipStream_t stream) {
     // detector's 3x3 layers; 12 reads per 24 MFMAs, half the patch staging per output): 128 accumulator registers leave room for ONE
     // weight register set (WSETS; with two the K loop spilled: 442 -> 215 TFLOP/s) -- 256 -> 256 at 160x272 429 -> 455 TFLOP/s,
     // 80x136 409 -> 426, 40x68 386 -> 394.
+    if (mode == MODE_TILE && a.stride == 2) {
+        // strided-patch form: 128-pixel tiles, one pixel block per wave, 1 .. 4 channel blocks per wave (the widest the block count and
+        // the LDS budget allow: every column stages the patch again)
+        static const int cob2_env = env_int("POSEPIPE_SPLIT_S2_COB", 0);
+        const TileGeom g = pick_tile_s2(a.Hout, a.Wout, 13 * 64);
+        if (g.eff < 0) {
+            pp_set_error("conv_split: no strided-patch tile for a %dx%d map", a.Hout, a.Wout);
+            return PP_ERR_STATE;
+        }
+        s.mode = MODE_TILE;
+        s.tiles_x = g.tiles_x; s.tiles_y = g.tiles_y; s.TH = g.TH; s.TW = g.TW; s.bw_log2 = g.bw_log2; s.gx_log2 = g.gx_log2;
+        s.PWp = g.PWp; s.NP = g.NP; s.NPp = g.NPp;
+        s.SP = (g.TH + 1) * g.PWp;
+        const unsigned gx2 = (unsigned)(g.tiles_x * g.tiles_y * a.N);
+        int cob2 = 1;
+        for (int c : {4, 3, 2})
+            if (s.ncb % c == 0 && (size_t)2 * 2 * s.NPp * 16 + (size_t)4 * c * 2 * 1024 <= 80 * 1024 && (cob2_env == 0 || cob2_env == c)) {
+                cob2 = c;
+                break;
+            }
+        const int nslot2 = (s.NP + 63) / 64;
+        dim3 grid2(gx2, (unsigned)(s.ncb / cob2));
+        s.gx = (int)grid2.x; s.gy = (int)grid2.y;
+        if (s.xcd_remap) grid2 = dim3((unsigned)((s.gx + 7) / 8 * 8 * s.gy), 1);
+        fill_divisors(s);
+        make_magic((unsigned)s.SP, s.dv_row);          // (this form decodes a patch slot into (phase, row, column): dv_row = 1 / SP)
+        const size_t lds2 = (size_t)2 * 2 * s.NPp * 16 + (size_t)4 * cob2 * 2 * 1024;
+#define PP_SPLIT_LAUNCH_S2(NS_, COB_)                                                                                   \
+    do {                                                                                                                \
+        static PpPerDeviceOnce once;                                                                                    \
+        once.run([] {                                                                                                   \
+            (void)hipFuncSetAttribute((const void*)conv_split_kernel<9, NS_, COB_, 1, 4, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024); \
+        });                                                                                                             \
+        hipLaunchKernelGGL((conv_split_kernel<9, NS_, COB_, 1, 4, true, true, true>), grid2, dim3(256), lds2, stream, s); \
+    } while (0)
+#define PP_SPLIT_LAUNCH_S2_NS(COB_)                                                                                     \
+    do {                                                                                                                \
+        if (nslot2 <= 10) PP_SPLIT_LAUNCH_S2(10, COB_);                                                                 \
+        else if (nslot2 == 11) PP_SPLIT_LAUNCH_S2(11, COB_);                                                            \
+        else PP_SPLIT_LAUNCH_S2(13, COB_);                                                                              \
+    } while (0)
+        if (cob2 == 4) PP_SPLIT_LAUNCH_S2_NS(4);
+        else if (cob2 == 3) PP_SPLIT_LAUNCH_S2_NS(3);
+        else if (cob2 == 2) PP_SPLIT_LAUNCH_S2_NS(2);
+        else PP_SPLIT_LAUNCH_S2_NS(1);
+        PP_TL_END("s2p", grid2.x * grid2.y);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) {
+            pp_set_error("conv_split (strided patch) launch failed: %s", hipGetErrorString(e2));
+            return PP_ERR_HIP;
+        }
+        return PP_OK;
+    }
     static const int cob_env = env_int("POSEPIPE_SPLIT_COB", 0);
     const bool cob_wide_ok = a.split_f16 != 0 && mode != MODE_GEMM && !split_c48(a);
     int cob = (s.ncb & 1) ? 1 : 2;

@@ -726,6 +726,36 @@ def test_f16_form_non_finite_input_stays_in_its_sample(ctx, lib16, monkeypatch):
     assert np.array_equal(net.forward(x), clean)
 
 
+# (n, h, w, cin, cout): 3x3 stride 2 on the STRIDED-PATCH form (round 6, fp16 form; output maps >= 1500 pixels, or >= 400 with >= 96 output
+# channels): odd and even maps on both axes (the last output row / column's far taps leave the image), 1 .. 4 channel blocks per wave
+# (32 / 64 / 96 / 128 output channels, and 48 = one and a half), 1 .. 16 channel chunks, every tile shape the picker has (4x32, 8x16, 16x8)
+CASES_S2P = [(2, 96, 72, 48, 96), (1, 96, 72, 48, 48), (2, 95, 71, 64, 64), (1, 81, 135, 128, 128), (1, 80, 136, 256, 256), (3, 47, 37, 96, 192),
+             (1, 192, 144, 64, 64), (2, 60, 100, 16, 32), (1, 40, 68, 256, 96), (1, 131, 33, 32, 160)]
+
+
+@pytest.mark.parametrize("case", CASES_S2P)
+def test_f16_form_3x3_stride_2_strided_patch(ctx, lib16, case):
+    """conv_split_kernel<.., S2>: the patch of a 128-pixel output tile de-interleaved into its four phases in LDS -- the yardstick of
+    every other form (error against a float64 convolution <= the float32 kernel's) with and without ReLU / residual, and the
+    per-sample scale (samples at different magnitudes)"""
+    n, h, w, cin, cout = case
+    rng = np.random.default_rng(sum(case) + 11)
+    x = (rng.standard_normal((n, h, w, cin)) * np.exp(2 * rng.standard_normal((n, h, w, cin))) *
+         (10.0 ** np.linspace(-3, 2, n)).reshape(-1, 1, 1, 1)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) / np.sqrt(cin * 9)).astype(np.float32)
+    b = (rng.standard_normal(cout) * np.abs(x).mean()).astype(np.float32)
+    ho, wo = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    r = (rng.standard_normal((n, ho, wo, cout)) * np.abs(x).mean()).astype(np.float32)
+    for relu, res in ((0, None), (L.PP_RELU_LAST, r)):
+        ref = conv64(x, wt, b, 1, 2, res, relu)
+        exact, split = both(lib16, lambda: hip_conv_op(ctx, x, wt, b, stride=2, pad=(1, 1), relu=relu, res1=res))
+        assert np.isfinite(split).all() and split.shape == ref.shape and not np.array_equal(exact, split)
+        scale = np.abs(ref).reshape(n, -1).max(1).reshape(n, 1, 1, 1) + 1e-300
+        rms = lambda y: float(np.sqrt(np.mean(((y - ref) / scale) ** 2)))
+        assert rms(split) <= 1.25 * rms(exact) + 1e-9, (rms(split), rms(exact))
+        assert np.abs((split - ref) / scale).max() <= 1.5 * np.abs((exact - ref) / scale).max() + 1e-7
+
+
 # (n, h, w): whole tiles, ragged tiles on both axes, a map smaller than one tile, the smoke-size frame, many tiles per workgroup
 CASES_STEM = [(2, 64, 128), (3, 70, 101), (1, 21, 37), (2, 135, 240), (5, 270, 480)]
 
