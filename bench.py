@@ -474,31 +474,32 @@ def run_cascade(args, D):
                                 "every frame (tests/test_gpu_parity_modes.py::test_integer_contract_1080p_64_frames_no_replay), joints "
                                 "within 1e-3 px / mm",
                         "ids_no_replay": ids_no_replay({"bit_exact_mode": cas_exact, "integer_exact_mode": cas_int, "default": cas}, dptr, B)}
-        # ... and the CERTIFIED configuration (round 6): the fast detector reports, per frame, how far its closest integer decision is from
-        # flipping (pp_detector_enable_margins); frames within the split kernels' error bound are re-run on the float32-MFMA detector.  No
-        # replay in this leg's id check; the timed steps replay boxes downstream like every other leg (the detector work is what differs).
-        cas_cert = Cascade(ctx, det_sd, pose_sd, lift_sd, 1080, 1920, chunk=B, max_persons=P, pose_spec=pose_spec, numerics="split", id_numerics="certified",
-                           overlap_detector=False)
-        cert_ids = ids_no_replay({"bit_exact_mode": cas_exact, "certified_mode": cas_cert}, dptr, B)
-        probe = dict(cas_cert.certify_stats)
-        cas_cert.step(None, frames_dev=(dptr, B), replay=replay_boxes())
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        for i in range(n_exact):
+        if P <= 4:     # (at 8 persons per frame the three cascades above hold the device's memory: their arenas are sized for 1024 pose samples)
+            # ... and the CERTIFIED configuration (round 6): the fast detector reports, per frame, how far its closest integer decision is from
+            # flipping (pp_detector_enable_margins); frames within the split kernels' error bound are re-run on the float32-MFMA detector.  No
+            # replay in this leg's id check; the timed steps replay boxes downstream like every other leg (the detector work is what differs).
+            cas_cert = Cascade(ctx, det_sd, pose_sd, lift_sd, 1080, 1920, chunk=B, max_persons=P, pose_spec=pose_spec, numerics="split", id_numerics="certified",
+                               overlap_detector=False)
+            cert_ids = ids_no_replay({"bit_exact_mode": cas_exact, "certified_mode": cas_cert}, dptr, B)
+            probe = dict(cas_cert.certify_stats)
             cas_cert.step(None, frames_dev=(dptr, B), replay=replay_boxes())
-        ctx.synchronize()
-        integer_mode["certified_mode"] = {
-            "value": B * n_exact / (time.perf_counter() - t0), "unit": "frames/s", "steps": n_exact,
-            "frames_certified": probe["certified"], "frames": probe["frames"] - probe["exact_only_frames"],
-            "ids_no_replay": cert_ids.get("certified_mode"),
-            "thresholds": cas_cert.certify_eps,
-            "note": "Cascade(numerics='split', id_numerics='certified'): `frames_certified` of `frames` cleared every decision margin of the fast "
-                    "detector pass (pp_detector_margins; thresholds = 4x the measured split-vs-exact deviation per quantity); the others were run "
-                    "again on the float32-MFMA detector.  While fewer than half of a chunk certify, the policy runs the exact detector alone "
-                    "(then this figure is the integer-exact mode's).  A detection path takes ~10^4 threshold decisions per frame (top-1000 of "
-                    "130 560 anchors per level, ~10^5 NMS pairs): with seeded-random weights the closest one sits within the float32 noise of "
-                    "ANY non-bit-identical evaluation in nearly every frame -- the margins say so per frame instead of leaving it to chance"}
-        cas_cert.close()
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_exact):
+                cas_cert.step(None, frames_dev=(dptr, B), replay=replay_boxes())
+            ctx.synchronize()
+            integer_mode["certified_mode"] = {
+                "value": B * n_exact / (time.perf_counter() - t0), "unit": "frames/s", "steps": n_exact,
+                    "frames_certified": probe["certified"], "frames": probe["frames"] - probe["exact_only_frames"],
+                "ids_no_replay": cert_ids.get("certified_mode"),
+                "thresholds": cas_cert.certify_eps,
+                "note": "Cascade(numerics='split', id_numerics='certified'): `frames_certified` of `frames` cleared every decision margin of the fast "
+                        "detector pass (pp_detector_margins; thresholds = 4x the measured split-vs-exact deviation per quantity); the others were run "
+                        "again on the float32-MFMA detector.  While fewer than half of a chunk certify, the policy runs the exact detector alone "
+                        "(then this figure is the integer-exact mode's).  A detection path takes ~10^4 threshold decisions per frame (top-1000 of "
+                        "130 560 anchors per level, ~10^5 NMS pairs): with seeded-random weights the closest one sits within the float32 noise of "
+                        "ANY non-bit-identical evaluation in nearly every frame -- the margins say so per frame instead of leaving it to chance"}
+            cas_cert.release()
     split_peak_line = BF16_MFMA_PEAK_TFLOPS / fam.get("products", 6)
     out = {
         "metric": METRIC, "value": D.world * B * K / dt, "unit": "frames/s", "n_gpus": D.world, "steps": K,

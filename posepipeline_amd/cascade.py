@@ -159,6 +159,23 @@ class Cascade:
             self.det_ctx.free(self._gather_dev)
         self._gather_dev = None
 
+    def release(self):
+        """close() + give the device memory of every program back (arenas, weights): the object is unusable afterwards.  A cascade at
+        8 persons per frame holds ~50 GB; a process that builds several (bench.py's mode legs) releases them as it goes."""
+        self.close()
+        for name in ("topdown", "detector_exact", "detector", "reid", "encoder"):
+            obj = getattr(self, name, None)
+            if obj is not None and hasattr(obj, "close"):
+                obj.close()
+        for det in (getattr(self, "detector", None), getattr(self, "detector_exact", None)):
+            for net in (getattr(det, "net_a", None), getattr(det, "net_b", None)):
+                if net is not None:
+                    net.close()
+        for name in ("pose_net", "lift_net"):
+            net = getattr(self, name, None)
+            if net is not None:
+                net.close()
+
     def __del__(self):
         try:
             self.close()
