@@ -235,6 +235,11 @@ int pp_net_forward(pp_net* net, int batch, int in_buf, const float* in, int out_
  * overlap, dependencies become event waits.  enable = 0 launches every op on the ctx stream in program order
  * (profiling: per-kernel durations are additive only then).  Results are identical either way. */
 int pp_net_set_lanes(pp_net* net, int enable);
+/* number of lanes (default 4, POSEPIPE_NET_LANES): re-plans the op -> stream assignment of an existing net (synchronises; a captured
+ * graph is dropped).  1 = every op on the ctx stream.  How many pays depends on the program: branches of small maps fill each other's
+ * tails (HRNet at 256x192), large maps that fill the chip on their own only disturb each other (measured round 6: the 1080p cascade
+ * runs 3 % faster on 2 lanes than on 4).  Results are identical for any count. */
+int pp_net_set_lane_count(pp_net* net, int n_lanes);
 /* capture ops [0, n_ops) at `batch` into a hipGraph and replay it on later pp_net_run calls */
 int pp_net_capture(pp_net* net, int batch);
 /* per-op elapsed time of the last profiled run (HIP events around each op), ms; NULL-safe */

@@ -111,6 +111,7 @@ SIGNATURES = {
     "pp_net_forward": (_i, [_vp, _i, _i, _vp, _i, _vp, _i]),
     "pp_net_capture": (_i, [_vp, _i]),
     "pp_net_set_lanes": (_i, [_vp, _i]),
+    "pp_net_set_lane_count": (_i, [_vp, _i]),
     "pp_net_conv_kinds": (_i, [_vp, _vp]),
     "pp_net_profile": (_i, [_vp, _i, _vp]),
     "pp_crop_resize_bilinear": (_i, [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),

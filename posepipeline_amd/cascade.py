@@ -40,6 +40,10 @@ CERTIFY_EPS = {"rpn_cut": 2e-5, "rpn_nms": 5e-5, "rpn_top": 2e-5, "roi_level": 2
                "det_top": 5e-5, "det_order": 4e-5, "trk_score": 2e-5}
 
 
+# HIP streams ("lanes") per program inside a cascade.  Filled in from the same-box A/B of round 6 (profiles/r06_lanes_ab.txt).
+LANES = {"detector": 2, "pose": 2}
+
+
 class Cascade:
     """tracking: "MMTrack_deepsort" (Faster-RCNN R50-FPN, det_sd = detector weights; association = mmtrack SortTracker: with
     reid_sd (ReID ResNet-50 weights) the DeepSORT configuration with its appearance branch, without it the SORT
@@ -54,7 +58,7 @@ class Cascade:
     def __init__(self, ctx: L.Context, det_sd, pose_sd: dict, lift_sd: dict, src_h: int, src_w: int,
                  chunk: int = 8, max_persons: int = 1, pose_spec=None, post="unbiased", blur_kernel=17,
                  tracking: str = "MMTrack_deepsort", keep_tracks=None, flip_pairs=None, blob_fn=None, reid_sd=None,
-                 overlap_detector: bool | None = None, numerics=None, id_numerics=None, certify_eps=None):
+                 overlap_detector: bool | None = None, numerics=None, id_numerics=None, certify_eps=None, det_lanes=None, pose_lanes=None):
         """blob_fn(name, program) -> (device pointer, n_floats) or None, name in "det_a", "det_b", "pose", "lift" (called in
         that order): a weight blob that is already resident on the device -- parallel.broadcast_blob_device delivers rank
         0's over RCCL; the *_sd arguments then only define the program structure (ops, buffers, blob offsets).
@@ -134,6 +138,16 @@ class Cascade:
         self.lift_spec = vp3d.VideoPose3DSpec()
         lift_prog = vp3d.build_videopose3d_program(self.lift_spec, lift_sd)
         self.lift_net = Net(ctx, lift_prog, max_batch=max(1, max_persons), blob_dev=blob_fn("lift", lift_prog), numerics=numerics)
+        # lanes per program (pp_net_set_lane_count; results identical for any count): measured round 6 on the 1080p cascade, see LANES
+        env_det, env_pose = os.environ.get("POSEPIPE_DET_LANES"), os.environ.get("POSEPIPE_POSE_LANES")
+        det_lanes = int(env_det) if env_det else (LANES["detector"] if det_lanes is None else det_lanes)
+        pose_lanes = int(env_pose) if env_pose else (LANES["pose"] if pose_lanes is None else pose_lanes)
+        if "POSEPIPE_NET_LANES" not in os.environ:
+            for det in (getattr(self, "detector", None), getattr(self, "detector_exact", None)):
+                if det is not None and hasattr(det, "net_a"):
+                    det.net_a.set_lane_count(det_lanes)
+            if not isinstance(self.pose_spec, vitpose.VitPoseSpec):
+                self.pose_net.set_lane_count(pose_lanes)
         self.frame_bytes = src_h * src_w * 3
         self.tail_dev = None          # device copy of the last FILL_LIMIT frames (slot = frame % FILL_LIMIT)
         self.tail_host = None

@@ -302,6 +302,7 @@ struct pp_net {
 };
 
 static ConvArgs net_conv_args(pp_net* net, const pp_op& op, int batch);
+static int net_make_lanes(pp_net* net, int n_lanes);
 
 // which tensors the fp16-form convolutions read, who produces them and who therefore tracks their maxima (see pp_net::amax)
 static void net_plan_amax(pp_net* net) {
@@ -771,8 +772,28 @@ int pp_net_create_ex(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* buf
         }
     const char* env_lanes = getenv("POSEPIPE_NET_LANES");
     const int n_lanes = env_lanes ? atoi(env_lanes) : 4;
+    int rc_l = net_make_lanes(net.get(), n_lanes);
+    if (rc_l != PP_OK) return rc_l;
+    *out = net.release();
+    return PP_OK;
+}
+
+// (re)build the lane streams, the op -> lane plan and its events for `n_lanes` (<= 1, or a program under 8 ops: none -- every op on the
+// ctx stream).  The caller has synchronised: nothing of the net is in flight.
+static int net_make_lanes(pp_net* net, int n_lanes) {
+    for (auto l : net->lanes) (void)hipStreamDestroy(l);
+    net->lanes.clear();
+    for (auto e : net->op_done)
+        if (e) (void)hipEventDestroy(e);
+    net->op_done.clear();
+    for (auto e : net->join_ev)
+        if (e) (void)hipEventDestroy(e);
+    net->join_ev.clear();
+    if (net->fork_ev) (void)hipEventDestroy(net->fork_ev);
+    net->fork_ev = nullptr;
+    const int n_ops = (int)net->ops.size();
     if (n_lanes > 1 && n_ops >= 8) {
-        net_plan_lanes(net.get(), n_lanes);
+        net_plan_lanes(net, n_lanes);
         net->lanes.resize(n_lanes);
         for (auto& l : net->lanes) PP_HIP_CHECK(hipStreamCreateWithFlags(&l, hipStreamNonBlocking));
         net->op_done.assign(n_ops, nullptr);
@@ -782,7 +803,6 @@ int pp_net_create_ex(pp_ctx* ctx, const pp_op* ops, int n_ops, const pp_buf* buf
         net->join_ev.resize(n_lanes);
         for (auto& e : net->join_ev) PP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    *out = net.release();
     return PP_OK;
 }
 
@@ -894,6 +914,17 @@ int pp_net_vit_timing(pp_net* net, int enable, float* ms3, int* n_gemm) {
     }
     pp_set_error("pp_net_vit_timing: the program has no PP_OP_VIT_ENCODER");
     return PP_ERR_STATE;
+}
+
+int pp_net_set_lane_count(pp_net* net, int n_lanes) {
+    PP_REQUIRE(net && n_lanes >= 1 && n_lanes <= 16, "pp_net_set_lane_count: net is NULL or n_lanes not in [1, 16]");
+    PP_HIP_CHECK(hipStreamSynchronize(net->ctx->stream));
+    for (auto l : net->lanes) PP_HIP_CHECK(hipStreamSynchronize(l));
+    if (net->graph_exec) {            // a captured graph holds the old plan
+        PP_HIP_CHECK(hipGraphExecDestroy(net->graph_exec));
+        net->graph_exec = nullptr;
+    }
+    return net_make_lanes(net, n_lanes);
 }
 
 int pp_net_set_lanes(pp_net* net, int enable) {

@@ -405,6 +405,10 @@ class Net:
         """multi-stream execution of independent ops on/off (off = serial launches, for additive kernel profiles)"""
         L.check(self.ctx.lib.pp_net_set_lanes(self.handle, int(bool(enable))), "pp_net_set_lanes")
 
+    def set_lane_count(self, n_lanes: int):
+        """how many HIP streams the program's independent ops are spread over (default 4; results identical for any count)"""
+        L.check(self.ctx.lib.pp_net_set_lane_count(self.handle, int(n_lanes)), "pp_net_set_lane_count")
+
     def capture(self, batch):
         L.check(self.ctx.lib.pp_net_capture(self.handle, batch), "pp_net_capture")
 
