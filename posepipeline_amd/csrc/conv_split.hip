@@ -427,13 +427,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     // split + write slots [j0, j1) of the staged chunk; branch-free (it sits between MFMAs) except for the last slot, the only
     // one that can be partly outside the patch (NSLOT = ceil(NP / (NT / 4)))
     const bool last_ok = (tid >> 2) + (NT / 4) * (NSLOT - 1) < a.NP;
-    float sx[H ? NSLOT : 1];                          // fp16 form: activation scale of slot j's sample (set behind the first requests)
+    // fp16 form: the activation scale of slot j's sample is a power of two: its EXPONENT byte (pp_amax_exp of the sample's maximum), four
+    // slots to a register (round 6: NSLOT floats were live through the K loop), set behind the first requests
+    unsigned sxe[H ? (NSLOT + 3) / 4 : 1];
     auto store_patch = [&](int buf, int j0, int j1) {
 #pragma unroll
         for (int j = 0; j < NSLOT; ++j) {
             if (j < j0 || j >= j1) continue;
             uint2 p0, p1, p2;
-            if constexpr (H) split4h(xr[j], sx[j], p0, p1);
+            if constexpr (H) split4h(xr[j], __uint_as_float((268u - ((sxe[j >> 2] >> (8 * (j & 3))) & 0xffu)) << 23), p0, p1);
             else split4(xr[j], p0, p1, p2);
             if (j == NSLOT - 1 && !last_ok) continue;
             unsigned char* d = smem + buf * buf_bytes + woff0 + (NT / 4) * 16 * j;
@@ -495,52 +497,51 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- operand addresses and output pixels (behind the first loads) ------------------------------------------------------------
-    int aofs[PXB];           // LDS byte offset of this lane's pixel (tap (0,0), plane 0) per pixel block
-    int on[PXB], oy[PXB], ox[PXB];
-    bool ook[PXB];
-    if (a.mode == MODE_TILE) {
-        const int BW = 32 >> a.bw_log2, BH = 1 << a.bw_log2;
-        int by, bx;
-        block_pixel(lane & 31, a.bw_log2, by, bx);
-#pragma unroll
-        for (int pb = 0; pb < PXB; ++pb) {
-            const int b = wave * PXB + pb;
+    // ---- operand addresses (behind the first loads) and output pixels ------------------------------------------------------------------
+    // (round 6) a lane's output pixels are needed by the EPILOGUE only: computing them here kept 8 - 10 registers alive through the K loop of
+    // kernels that sit at the 256-register limit (the fp16-form 3 / 4-block kernels spilled 12 - 124 bytes per lane).  The same arithmetic
+    // runs once before the loop for the LDS offsets and once after it -- from a laundered thread id, so that the compiler does not keep
+    // the first evaluation -- for the coordinates.
+    auto pixel_coords = [&](int lane_, int wave_, int pb, int& aofs_, int& on_, int& oy_, int& ox_, bool& ok_) {
+        if (a.mode == MODE_TILE) {
+            const int BW = 32 >> a.bw_log2, BH = 1 << a.bw_log2;
+            int by, bx;
+            block_pixel(lane_ & 31, a.bw_log2, by, bx);
+            const int b = wave_ * PXB + pb;
             const int gy = b >> a.gx_log2, gx = b & ((1 << a.gx_log2) - 1);
             const int ry = gy * BH + by, rx = gx * BW + bx;
-            aofs[pb] = (((lane >> 5) * a.NPp) + ry * a.PWp + rx) * 16;
-            on[pb] = n;
-            oy[pb] = y0 + ry;
-            ox[pb] = x0 + rx;
-            ook[pb] = oy[pb] < a.H && ox[pb] < a.W;
-        }
-    } else {
-        // STREAM: (image, row, column) of a position of the padded input stream; GEMM: of an output pixel (dv_per / dv_row hold
-        // the reciprocals of the positions per image / per row of that mode)
-        const unsigned per = a.mode == MODE_STREAM ? (unsigned)(a.xp_h * a.PWp) : (unsigned)(a.H * a.W);
-        const unsigned row = a.mode == MODE_STREAM ? (unsigned)a.PWp : (unsigned)a.W;
-#pragma unroll
-        for (int pb = 0; pb < PXB; ++pb) {
-            const int pl = (wave * PXB + pb) * 32 + (lane & 31);
-            aofs[pb] = (((lane >> 5) * a.NPp) + pl) * 16;
+            aofs_ = (((lane_ >> 5) * a.NPp) + ry * a.PWp + rx) * 16;
+            on_ = n;
+            oy_ = y0 + ry;
+            ox_ = x0 + rx;
+            ok_ = oy_ < a.H && ox_ < a.W;
+        } else {
+            // STREAM: (image, row, column) of a position of the padded input stream; GEMM: of an output pixel (dv_per / dv_row hold
+            // the reciprocals of the positions per image / per row of that mode)
+            const unsigned per = a.mode == MODE_STREAM ? (unsigned)(a.xp_h * a.PWp) : (unsigned)(a.H * a.W);
+            const unsigned row = a.mode == MODE_STREAM ? (unsigned)a.PWp : (unsigned)a.W;
+            const int pl = (wave_ * PXB + pb) * 32 + (lane_ & 31);
+            aofs_ = (((lane_ >> 5) * a.NPp) + pl) * 16;
             const unsigned sp = s0 + (unsigned)pl;
             const bool in = sp < (unsigned)a.S;
             const unsigned sc = in ? sp : 0u;
             const unsigned img = pp_udiv(sc, a.dv_per);
             const unsigned rem = sc - img * per;
             const unsigned yy = pp_udiv(rem, a.dv_row);
-            on[pb] = (int)img;
-            oy[pb] = (int)yy;
-            ox[pb] = (int)(rem - yy * row);
-            ook[pb] = in && oy[pb] < a.H && ox[pb] < a.W;
+            on_ = (int)img;
+            oy_ = (int)yy;
+            ox_ = (int)(rem - yy * row);
+            ok_ = in && oy_ < a.H && ox_ < a.W;
         }
+    };
+    int aofs[PXB];           // LDS byte offset of this lane's pixel (tap (0,0), plane 0) per pixel block
+#pragma unroll
+    for (int pb = 0; pb < PXB; ++pb) {
+        int on_, oy_, ox_;
+        bool ok_;
+        pixel_coords(lane, wave, pb, aofs[pb], on_, oy_, ox_, ok_);
     }
 
-    unsigned oam[H ? PXB : 1];                         // fp16 form: maximum of the output pixel's sample (the epilogue's 1 / s)
-    if constexpr (H) {
-#pragma unroll
-        for (int pb = 0; pb < PXB; ++pb) oam[pb] = a.x_amax[on[pb]];
-    }
     f32x16 acc[COB][PXB];
 #pragma unroll
     for (int cb = 0; cb < COB; ++cb)
@@ -550,7 +551,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
             for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
     if constexpr (H) {
 #pragma unroll
-        for (int j = 0; j < NSLOT; ++j) sx[j] = pp_act_scale(xam[j]);
+        for (int q = 0; q < (NSLOT + 3) / 4; ++q) sxe[q] = 0;
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j) sxe[j >> 2] |= pp_amax_exp(xam[j]) << (8 * (j & 3));
     }
 
     auto load_x = [&](const unsigned char* pbuf, int t, int pb) {
@@ -790,6 +793,22 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void conv_split_kernel(Sp
     PP_TL_MARK(2);
 
     // ---- epilogue: bias, residuals, ReLU; accumulator register i of a lane = channel 8 (i / 4) + 4 (lane / 32) + i % 4 ---
+    int on[PXB], oy[PXB], ox[PXB];
+    bool ook[PXB];
+    unsigned oam[H ? PXB : 1];                         // fp16 form: maximum of the output pixel's sample (the epilogue's 1 / s)
+    {
+        int tid_e = tid;
+        asm volatile("" : "+v"(tid_e));                // (see pixel_coords: evaluate again instead of carrying the results through the loop)
+#pragma unroll
+        for (int pb = 0; pb < PXB; ++pb) {
+            int aofs_;
+            pixel_coords(tid_e & 63, tid_e >> 6, pb, aofs_, on[pb], oy[pb], ox[pb], ook[pb]);
+        }
+        if constexpr (H) {
+#pragma unroll
+            for (int pb = 0; pb < PXB; ++pb) oam[pb] = a.x_amax[on[pb]];
+        }
+    }
 #if (PP_SPLIT_ABLATE & 32)
     if (a.relu != 77) {       // keep the accumulators alive with one store per lane
         if (ook[0]) a.y[(((size_t)on[0] * (a.H + a.y_pad) + oy[0]) * (a.W + a.y_pad) + ox[0]) * a.Cout + (lane >> 5)] = acc[0][0][0] + acc[COB - 1][PXB - 1][15];

@@ -22,6 +22,17 @@ def ctx():
 
 
 @pytest.fixture(autouse=True)
+def _collect_device_objects(request):
+    """nets / detectors / cascades free their device memory in __del__; cascades are reference cycles, so a full suite in one process
+    kept tens of GB alive between collections (round 6: the 1080p parity tests pushed a later test out of memory).  Collect after
+    every GPU test."""
+    yield
+    if request.node.get_closest_marker("gpu"):
+        import gc
+        gc.collect()
+
+
+@pytest.fixture(autouse=True)
 def _conv_numerics(request):
     """GPU tests create their nets with the float32-MFMA convolution kernels, which are bit-identical to oracle/conv_ref.c, so
     that `==` against the oracle is meaningful.  A net keeps the numerics it was created with (ABI 7).  The library's DEFAULT

@@ -484,6 +484,8 @@ def test_integer_contract_1080p_64_frames_no_replay(ctx):
                 matched += 1
     print(f"[split] frames with the exact cascade's id list: {same_ids} / {n}; tracked boxes re-found within {BOX_TOL['split']} px: {matched} / {total}")
     assert matched >= 0.9 * total
+    for c in (cas_e, cas_h, cas_s):
+        c.release()
 
 
 def test_certified_ids_1080p_64_frames_no_replay(ctx):
@@ -537,3 +539,5 @@ def test_certified_ids_1080p_64_frames_no_replay(ctx):
         assert np.allclose(ms[both_ok], me[both_ok], rtol=0.2)
     print(f"[certified] per-frame check: {n_cert} of {n} frames certified, {n_diff} frames where the fast detector's rows differ, all {n_diff_caught} caught")
     assert n_diff == n_diff_caught
+    for c in (cas_e, cas_c):        # (a cascade is a reference cycle: give its ~15 GB back now, not at the next collection)
+        c.release()
