@@ -519,7 +519,7 @@ def run_cascade(args, D):
                                "well-conditioned weights, integer outputs NOT guaranteed on near-tie detector decisions); the modes that hold "
                                "north_star's integer contract are `integer_exact_mode` (detector on the float32 MFMA kernels) and "
                                "`integer_exact_mode.certified_mode` (fast detector + per-frame decision margins + exact re-runs)",
-                   "detector_lookahead": bool(getattr(cas, "det_ctx", ctx) is not ctx),
+                   "detector_lookahead": getattr(cas, "lookahead", "off"),
                    "host_cores_per_rank": (os.cpu_count() or 1) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", D.world))),
                    "profile_serial": bool(args.profile_serial)},
         "roofline": roof,

@@ -491,6 +491,14 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
 /* HIP-event stage times of the last run, ms6 = {preprocess, image program, RPN proposals + NMS, RoIAlign,
  * RoI-head program, final decode + NMS} */
 int pp_detector_timing(pp_detector* d, float* ms6);
+/* The same pass in two halves (ABI 10): pp_detector_enqueue queues everything on the ctx stream -- resize, both programs, RPN / NMS /
+ * RoIAlign, the copies of the results into the detector's page-locked staging -- and returns; pp_detector_collect waits for that pass
+ * (an event: work queued BEHIND it on the stream is not waited for) and hands the results over.  One pass in flight per detector.
+ * A caller that enqueues chunk k + 1 before it processes chunk k's detections on the host keeps the stream fed across its own host
+ * work (tracker, bookkeeping) without a second stream or thread: posepipeline_amd/cascade.py.  Host frames (PP_MEM_HOST) must stay
+ * valid until the collect.  pp_detector_run = enqueue + collect. */
+int pp_detector_enqueue(pp_detector* d, const uint8_t* frames, int n_frames, int frames_mem, int want_proposals);
+int pp_detector_collect(pp_detector* d, float* dets, int32_t* n_dets, float* proposals, int32_t* n_proposals);
 /* Decision margins (round 6): how far every INTEGER decision of the detection path is from flipping, per frame.  The path takes
  * thousands of discrete decisions on float32 values (top-1000 per level, NMS 0.7, top-1000, RoI level, score > 0.05, NMS 0.5,
  * top-100: faster_rcnn_r50_fpn.py:101-109); an evaluation that is as accurate but not bit-identical -- this library's default

@@ -135,6 +135,8 @@ SIGNATURES = {
     "pp_detector_destroy": (None, [_vp]),
     "pp_detector_run": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "pp_detector_timing": (_i, [_vp, _vp]),
+    "pp_detector_enqueue": (_i, [_vp, _vp, _i, _i, _i]),
+    "pp_detector_collect": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "pp_detector_enable_margins": (_i, [_vp, _i, C.c_float]),
     "pp_detector_margins": (_i, [_vp, _i, _vp]),
     "pp_nms": (_i, [_vp, _vp, _vp, _i, C.c_double, _i, _vp, C.POINTER(C.c_int32), _i]),

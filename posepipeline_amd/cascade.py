@@ -62,13 +62,12 @@ class Cascade:
         """blob_fn(name, program) -> (device pointer, n_floats) or None, name in "det_a", "det_b", "pose", "lift" (called in
         that order): a weight blob that is already resident on the device -- parallel.broadcast_blob_device delivers rank
         0's over RCCL; the *_sd arguments then only define the program structure (ops, buffers, blob offsets).
-        overlap_detector: the detector gets its own context (HIP stream + lanes) and `step(..., prefetch=next chunk)` runs
-        its pass over the NEXT chunk on a worker thread while this chunk's tracking / 2D / 3D stages run -- the detector's
-        big convolutions fill the CUs that HRNet's small maps leave idle, RoIAlign (HBM-bound) overlaps MFMA-bound work.
-        Results are unchanged (same kernels, same order per stage).  Not with the ReID branch (it reads the detector's
-        resident input tensor of the CURRENT chunk).  None = automatic: on when the host has at least 4 cores per local rank
-        (the worker thread spends its time inside a synchronous GPU call, and HIP's waits spin), POSEPIPE_OVERLAP_DETECTOR=0/1
-        overrides."""
+        overlap_detector: the look-ahead of the detector pass -- None / True / "stream" (default): the detector gets its own context
+        (HIP stream + lanes) and `step(..., prefetch=next chunk)` ENQUEUES its pass over the next chunk there (pp_detector_enqueue:
+        asynchronous, no thread); the next step collects it.  "pipeline": the same on the cascade's one stream; False / "off": none.
+        Results are unchanged (same kernels, same order per stage).  Not with the ReID branch (it reads the detector's resident input
+        tensor of the CURRENT chunk) nor with certified ids (synchronous passes).  POSEPIPE_OVERLAP_DETECTOR=0 / 1 / 3 overrides
+        (off / stream / pipeline)."""
         # numerics: "exact" / "split" / None (= the process default at this moment) for EVERY program this cascade creates, passed
         # down explicitly -- two threads building cascades in different modes do not interfere (unlike _lib.default_numerics).
         # id_numerics (round 5): numerics of the programs whose outputs feed INTEGER decisions -- the detector (top-k, NMS, score
@@ -87,9 +86,8 @@ class Cascade:
         id_numerics = numerics if id_numerics is None else id_numerics
         self.ctx = ctx
         self.det_ctx = ctx
-        self._pending = None          # (chunk key, Future of _det_job) started by step(prefetch=...)
+        self._pending = None          # chunk key of the detector pass enqueued by step(prefetch=...)
         self.det_timing = None        # per-stage times of the detector pass this step consumed
-        self._pool = None
         self.src = (src_h, src_w)
         self.chunk = chunk
         self.max_persons = max_persons
@@ -103,11 +101,21 @@ class Cascade:
             self.encoder = mars.MarsEncoder(ctx, det_sd[1], src_h, src_w, max_patches=max(64, chunk * max_persons), numerics=id_numerics)
         else:
             assert tracking == "MMTrack_deepsort", tracking
-            if overlap_detector is None:
-                env = os.environ.get("POSEPIPE_OVERLAP_DETECTOR")
-                ranks = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
-                overlap_detector = (env != "0") if env is not None else (os.cpu_count() or 1) >= 4 * ranks
-            self.det_ctx = L.Context(ctx.device) if (overlap_detector and reid_sd is None) else ctx
+            # look-ahead mode (see the docstring).  Same-box (profiles/r06_lanes_ab.txt): off 575 - 585, pipeline 578 - 587, stream
+            # 600 frames/s (the worker-thread form of rounds 3 - 5: 595) -- what pays is the SECOND QUEUE (one program's launches fill the
+            # drain / launch gaps between the other's dependent kernels: ~700 boundaries per step), not host-side overlap; the kernel
+            # trace shows the two families executing at once for only ~1 % of the time (profiles/r06_overlap_lookahead_*.txt).
+            env = os.environ.get("POSEPIPE_OVERLAP_DETECTOR")
+            if env is not None:
+                overlap_detector = {"0": "off", "1": "stream", "3": "pipeline"}.get(env, "stream")
+            elif overlap_detector is None or overlap_detector is True:
+                overlap_detector = "stream"
+            elif overlap_detector is False:
+                overlap_detector = "off"
+            if reid_sd is not None or self.certified:
+                overlap_detector = "off"
+            self.lookahead = overlap_detector
+            self.det_ctx = L.Context(ctx.device) if overlap_detector == "stream" else ctx
             self.detector = fr.Detector(self.det_ctx, det_sd, src_h, src_w, max_frames=chunk, blob_fn=blob_fn, numerics=id_numerics)
             if self.certified:
                 self.certify_eps = dict(CERTIFY_EPS if certify_eps is None else certify_eps)
@@ -156,16 +164,11 @@ class Cascade:
 
     def _drop_prefetch(self):
         if self._pending is not None:
-            try:
-                self._pending[1].result()
-            finally:
-                self._pending = None
+            self._pending = None
+            self.detector.collect()
 
     def close(self):
         self._drop_prefetch()
-        if self._pool is not None:
-            self._pool.shutdown(wait=True)
-            self._pool = None
         if self.tail_dev is not None and getattr(self.ctx, "handle", None):
             self.ctx.free(self.tail_dev)
         self.tail_dev = None
@@ -228,9 +231,8 @@ class Cascade:
     def _detect(self, frames, frames_dev):
         """the detector's pass over this chunk: the prefetched one if step(prefetch=) of the previous call started it"""
         if self._pending is not None:
-            key, fut = self._pending
-            self._pending = None
-            dets, timing = fut.result()
+            key, self._pending = self._pending, None
+            dets, timing = self.detector.collect(), self.detector.timing()
             if key == self._chunk_key(frames, frames_dev):
                 self.det_timing = timing
                 return dets
@@ -238,7 +240,7 @@ class Cascade:
         return dets
 
     def _det_job(self, frames, frames_dev):
-        """detector pass + its per-stage HIP-event times (read on the thread that ran it: the next pass re-records the events)"""
+        """detector pass + its per-stage HIP-event times"""
         if self.certified:
             return self._det_job_certified(frames, frames_dev)
         dets = self.detector.run(frames, frames_dev=frames_dev)
@@ -291,13 +293,11 @@ class Cascade:
         return dets, timing
 
     def _prefetch(self, frames, frames_dev):
-        if self.det_ctx is self.ctx:
-            return                       # no second stream: nothing to overlap with
-        if self._pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="posepipe-detector")
-        self._pending = (self._chunk_key(frames, frames_dev),
-                         self._pool.submit(self._det_job, frames, frames_dev))
+        if getattr(self, "lookahead", "off") == "off" or not hasattr(self.detector, "enqueue"):
+            return
+        self._held = frames                  # (host frames must outlive the pass)
+        self.detector.enqueue(frames, frames_dev=frames_dev)
+        self._pending = self._chunk_key(frames, frames_dev)
 
     def _track_chunk(self, frames, frames_dev, replay, dets):
         chunk_tracks = []

@@ -104,20 +104,7 @@ int pp_ctx_create(int device, pp_ctx** out) {
     PP_HIP_CHECK(hipSetDevice(device));
     std::unique_ptr<pp_ctx> c(new pp_ctx());
     c->device = device;
-    {   // POSEPIPE_CTX_PRIO="p0,p1,..": stream priority of the k-th context this process creates (default 0 for all)
-        static std::atomic<int> n_created{0};
-        const int k = n_created.fetch_add(1);
-        if (const char* pe = getenv("POSEPIPE_CTX_PRIO")) {
-            std::vector<int> pr;
-            for (const char* q = pe; *q;) {
-                pr.push_back(atoi(q));
-                while (*q && *q != ',') ++q;
-                if (*q == ',') ++q;
-            }
-            if (k < (int)pr.size()) c->priority = pr[k];
-        }
-    }
-    PP_HIP_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, c->priority));
+    PP_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     PP_HIP_CHECK(hipEventCreate(&c->ev_start));
     PP_HIP_CHECK(hipEventCreate(&c->ev_stop));
     PP_HIP_CHECK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -808,7 +795,7 @@ static int net_make_lanes(pp_net* net, int n_lanes) {
     if (n_lanes > 1 && n_ops >= 8) {
         net_plan_lanes(net, n_lanes);
         net->lanes.resize(n_lanes);
-        for (auto& l : net->lanes) PP_HIP_CHECK(hipStreamCreateWithPriority(&l, hipStreamNonBlocking, net->ctx->priority));
+        for (auto& l : net->lanes) PP_HIP_CHECK(hipStreamCreateWithFlags(&l, hipStreamNonBlocking));
         net->op_done.assign(n_ops, nullptr);
         for (int i = 0; i < n_ops; ++i)
             if (net->op_needs_event[i]) PP_HIP_CHECK(hipEventCreateWithFlags(&net->op_done[i], hipEventDisableTiming));

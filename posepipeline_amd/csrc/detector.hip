@@ -48,6 +48,12 @@ struct pp_detector {
     unsigned char *kflag1 = nullptr, *kflag2 = nullptr;
     std::vector<float> h_margins;
     int h_margins_frames = 0;
+    // asynchronous form (pp_detector_enqueue / pp_detector_collect): page-locked staging of the pass's outputs and its completion event
+    float *h_dets = nullptr, *h_props = nullptr;
+    int32_t *h_ndets = nullptr, *h_nprops = nullptr;
+    hipEvent_t ev_done = nullptr;
+    int pending_frames = 0;      // > 0: a pass is in flight (enqueued, not collected)
+    bool pending_props = false;
     float ms[6];
     hipEvent_t ev[7];
 };
@@ -239,6 +245,11 @@ int pp_detector_create(pp_net* netA, pp_net* netB, const int32_t* bufs_a, const 
     d->kflag1 = (unsigned char*)(base + o_k1); d->kflag2 = (unsigned char*)(base + o_kf2);
     d->h_margins.assign((size_t)F * PP_DET_N_MARGINS, 0.f);
     for (auto& e : d->ev) PP_HIP_CHECK(hipEventCreate(&e));
+    PP_HIP_CHECK(hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming));
+    PP_HIP_CHECK(hipHostMalloc((void**)&d->h_dets, (size_t)F * d->max_det * 5 * sizeof(float)));
+    PP_HIP_CHECK(hipHostMalloc((void**)&d->h_ndets, (size_t)F * sizeof(int32_t)));
+    PP_HIP_CHECK(hipHostMalloc((void**)&d->h_props, (size_t)F * d->max_rois * 16));
+    PP_HIP_CHECK(hipHostMalloc((void**)&d->h_nprops, (size_t)F * sizeof(int32_t)));
     PP_HIP_CHECK(hipStreamSynchronize(s));
     *out = d.release();
     return PP_OK;
@@ -251,15 +262,21 @@ void pp_detector_destroy(pp_detector* d) {
         if (p) (void)hipFree(p);
     for (auto& e : d->ev)
         if (e) (void)hipEventDestroy(e);
+    if (d->ev_done) (void)hipEventDestroy(d->ev_done);
+    for (void* p : {(void*)d->h_dets, (void*)d->h_ndets, (void*)d->h_props, (void*)d->h_nprops})
+        if (p) (void)hipHostFree(p);
     delete d;
 }
 
-// which: 0 preprocessed input is already in the program's input buffer (skip the resize), frames may be NULL
-int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int frames_mem, float* dets, int32_t* n_dets,
-                    float* proposals, int32_t* n_proposals) {
-    PP_REQUIRE(d && dets && n_dets, "pp_detector_run: NULL argument");
-    PP_REQUIRE(n_frames >= 0 && n_frames <= d->max_frames, "pp_detector_run: %d frames exceed capacity %d", n_frames, d->max_frames);
-    if (n_frames == 0) return PP_OK;
+// frames == NULL: the preprocessed input is already in the program's input buffer (skip the resize)
+int pp_detector_enqueue(pp_detector* d, const uint8_t* frames, int n_frames, int frames_mem, int want_proposals) {
+    PP_REQUIRE(d, "pp_detector_enqueue: detector is NULL");
+    PP_REQUIRE(n_frames > 0 && n_frames <= d->max_frames, "pp_detector_enqueue: %d frames not in (0, %d]", n_frames, d->max_frames);
+    PP_REQUIRE(d->pending_frames == 0, "pp_detector_enqueue: the previous pass has not been collected");
+    float* dets = d->h_dets;
+    int32_t* n_dets = d->h_ndets;
+    float* proposals = want_proposals ? d->h_props : nullptr;
+    int32_t* n_proposals = want_proposals ? d->h_nprops : nullptr;
     hipStream_t s = d->ctx->stream;
     const int F = n_frames;
     PP_HIP_CHECK(hipEventRecord(d->ev[0], s));
@@ -377,9 +394,35 @@ int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int fra
     PP_HIP_CHECK(hipMemcpyAsync(n_dets, d->n_out, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost, s));
     if (proposals) PP_HIP_CHECK(hipMemcpyAsync(proposals, d->rois, (size_t)F * d->max_rois * 16, hipMemcpyDeviceToHost, s));
     if (n_proposals) PP_HIP_CHECK(hipMemcpyAsync(n_proposals, d->n_rois, (size_t)F * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    PP_HIP_CHECK(hipStreamSynchronize(s));
+    PP_HIP_CHECK(hipEventRecord(d->ev_done, s));
+    d->pending_frames = F;
+    d->pending_props = want_proposals != 0;
+    return PP_OK;
+}
+
+int pp_detector_collect(pp_detector* d, float* dets, int32_t* n_dets, float* proposals, int32_t* n_proposals) {
+    PP_REQUIRE(d && dets && n_dets, "pp_detector_collect: NULL argument");
+    PP_REQUIRE(d->pending_frames > 0, "pp_detector_collect: no pass in flight");
+    PP_REQUIRE(!(proposals || n_proposals) || d->pending_props, "pp_detector_collect: the pass was enqueued without proposals");
+    const int F = d->pending_frames;
+    PP_HIP_CHECK(hipEventSynchronize(d->ev_done));
+    d->pending_frames = 0;
+    memcpy(dets, d->h_dets, (size_t)F * d->max_det * 5 * sizeof(float));
+    memcpy(n_dets, d->h_ndets, (size_t)F * sizeof(int32_t));
+    if (proposals) memcpy(proposals, d->h_props, (size_t)F * d->max_rois * 16);
+    if (n_proposals) memcpy(n_proposals, d->h_nprops, (size_t)F * sizeof(int32_t));
     for (int i = 0; i < 6; ++i) (void)hipEventElapsedTime(&d->ms[i], d->ev[i], d->ev[i + 1]);
     return PP_OK;
+}
+
+int pp_detector_run(pp_detector* d, const uint8_t* frames, int n_frames, int frames_mem, float* dets, int32_t* n_dets,
+                    float* proposals, int32_t* n_proposals) {
+    PP_REQUIRE(d && dets && n_dets, "pp_detector_run: NULL argument");
+    PP_REQUIRE(n_frames >= 0 && n_frames <= d->max_frames, "pp_detector_run: %d frames exceed capacity %d", n_frames, d->max_frames);
+    if (n_frames == 0) return PP_OK;
+    int rc = pp_detector_enqueue(d, frames, n_frames, frames_mem, proposals || n_proposals);
+    if (rc != PP_OK) return rc;
+    return pp_detector_collect(d, dets, n_dets, proposals, n_proposals);
 }
 
 int pp_detector_enable_margins(pp_detector* d, int enable, float score_weight) {

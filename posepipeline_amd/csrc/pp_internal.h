@@ -46,7 +46,6 @@ struct PpPerDeviceOnce {
 };
 
 struct pp_ctx {
-    int priority = 0;             // HIP stream priority of the ctx stream and of the lanes of its programs (POSEPIPE_CTX_PRIO, experiments)
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = true;

@@ -270,6 +270,35 @@ class Detector:
             return out, [props[i, : nprops[i]].copy() for i in range(f)]
         return out
 
+    def enqueue(self, frames, want_proposals=False, frames_dev=None):
+        """the pass of `run`, queued on the context's stream without waiting (pp_detector_enqueue); `collect()` returns what `run`
+        would have.  One pass in flight; host `frames` must stay alive until the collect."""
+        if frames_dev is not None:
+            ptr, f = frames_dev
+            fptr, mem, keep = C.c_void_p(ptr), L.PP_MEM_DEVICE, None
+        else:
+            frames = np.ascontiguousarray(frames, np.uint8)
+            f = frames.shape[0]
+            assert frames.shape[1:] == (self.src[0], self.src[1], 3)
+            fptr, mem, keep = L.ptr(frames), L.PP_MEM_HOST, frames
+        L.check(self.ctx.lib.pp_detector_enqueue(self.handle, fptr, f, mem, int(bool(want_proposals))), "pp_detector_enqueue")
+        self._inflight = (f, want_proposals, keep)
+
+    def collect(self):
+        if getattr(self, "_inflight", None) is None:
+            raise L.PosePipeHipError("pp_detector_collect: no pass in flight")
+        f, want_proposals, _keep = self._inflight
+        self._inflight = None
+        dets = np.zeros((f, self.MAX_DET, 5), np.float32)
+        n = np.zeros((f,), np.int32)
+        props = np.zeros((f, self.MAX_ROIS, 4), np.float32) if want_proposals else None
+        nprops = np.zeros((f,), np.int32) if want_proposals else None
+        L.check(self.ctx.lib.pp_detector_collect(self.handle, L.ptr(dets), L.ptr(n), L.ptr(props), L.ptr(nprops)), "pp_detector_collect")
+        out = [dets[i, : n[i]].copy() for i in range(f)]
+        if want_proposals:
+            return out, [props[i, : nprops[i]].copy() for i in range(f)]
+        return out
+
     def timing(self):
         ms = np.zeros(6, np.float32)
         L.check(self.ctx.lib.pp_detector_timing(self.handle, L.ptr(ms)), "pp_detector_timing")

@@ -308,3 +308,43 @@ def test_cascade_steady_state_keeps_device_memory_flat(ctx):
     assert not cas.persons.streams
     assert abs(used[-1] - used[3]) <= 2 << 20, [u >> 20 for u in used]
     assert max(used[3:]) - min(used[3:]) <= 8 << 20, [u >> 20 for u in used]
+
+
+def test_detector_enqueue_collect_and_lookahead_modes(ctx):
+    """pp_detector_enqueue / pp_detector_collect (ABI 10) == pp_detector_run bit for bit, one pass in flight at a time (a second enqueue
+    is refused), proposals on request; and a cascade gives the same tracks / key points / 3D in every look-ahead mode -- "stream" (the
+    next chunk's pass enqueued on the detector's own context while this chunk's stages run), "pipeline" (same stream), "off"."""
+    from posepipeline_amd import _lib as L
+    from posepipeline_amd.cascade import Cascade, collect
+    det_sd, pose_spec, pose_sd, lift_sd = _setup(135, 240)
+    rng = np.random.default_rng(17)
+    frames = np.stack([synth_frame(rng, 135, 240) for _ in range(8)])
+    det = fr.Detector(ctx, det_sd, 135, 240, max_frames=4, numerics="exact")
+    ref, ref_p = det.run(frames[:4], want_proposals=True)
+    det.enqueue(frames[:4], want_proposals=True)
+    with pytest.raises(L.PosePipeHipError, match="has not been collected"):
+        det.enqueue(frames[4:])
+    got, got_p = det.collect()
+    assert all(np.array_equal(a, b) for a, b in zip(got, ref)) and all(np.array_equal(a, b) for a, b in zip(got_p, ref_p))
+    with pytest.raises(L.PosePipeHipError, match="no pass in flight"):
+        det.collect()
+    det.enqueue(frames[4:])
+    assert all(np.array_equal(a, b) for a, b in zip(det.collect(), det.run(frames[4:])))
+    outs = {}
+    for mode in ("stream", "pipeline", "off"):
+        cas = Cascade(ctx, det_sd, pose_sd, lift_sd, 135, 240, chunk=4, max_persons=2, pose_spec=pose_spec, overlap_detector=mode, numerics="exact")
+        assert cas.lookahead == mode and (cas.det_ctx is not cas.ctx) == (mode == "stream")
+        res = [cas.step(frames[:4], prefetch=(frames[4:], None)), cas.step(frames[4:]), cas.flush()]
+        outs[mode] = ([t for o in res for t in o["tracks"]], collect(res, "keypoints"), collect(res, "keypoints_3d"))
+        # a prefetch that is never consumed (the caller stops, or asks for another chunk) is drained, not leaked
+        cas.reset()
+        cas.step(frames[:4], prefetch=(frames[4:], None))
+        o2 = cas.step(frames[:4])            # NOT the prefetched chunk: its pass is collected and dropped, this one runs now
+        assert [r[0] for fr_ in o2["tracks"] for r in fr_] is not None
+        cas.release()
+    for mode in ("pipeline", "off"):
+        assert outs[mode][0] == outs["stream"][0]
+        for a, b in ((outs[mode][1], outs["stream"][1]), (outs[mode][2], outs["stream"][2])):
+            assert sorted(a) == sorted(b)
+            for tid in a:
+                assert a[tid][0] == b[tid][0] and np.array_equal(a[tid][1], b[tid][1])

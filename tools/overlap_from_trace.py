@@ -50,39 +50,35 @@ def intersect_len(a, b):
 
 def main():
     rows = list(csv.DictReader(open(sys.argv[1], newline="")))
-    qkey = "Queue_Id" if "Queue_Id" in rows[0] else "Stream_Id"
     t0 = min(int(r["Start_Timestamp"]) for r in rows)
     t1 = max(int(r["End_Timestamp"]) for r in rows)
     lo = t0 + (t1 - t0) // 2
     rows = [r for r in rows if int(r["Start_Timestamp"]) >= lo]
-    by_q = defaultdict(list)
-    names = defaultdict(set)
+    # HIP maps many streams to a few hardware queues and rocprofv3 reports one Thread_Id: the STREAM separates the families.  The
+    # detector's context stream carries its pre / post-processing kernels, the pose context's the crop / decode / lifting kernels; a
+    # program's lane streams carry only its layer kernels -- HRNet's are the ones with fuse sums (upsample_add), the others the detector's
+    DET = ("det_preprocess", "roi_align", "rpn_select", "final_decode", "rpn_compact")
+    POSE = ("crop_affine", "flip_merge_decode", "upsample_add", "lifting")
+    by_s = defaultdict(list)
+    mark = defaultdict(lambda: [0, 0])
     for r in rows:
-        q = r[qkey]
-        by_q[q].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
-        names[q].add(r["Kernel_Name"].split("(")[0][-60:])
-    det_q = {q for q, ns in names.items() if any(k in n for n in ns for k in ("det_preprocess", "roi_align", "rpn_select", "final_decode"))}
-    pose_q = {q for q, ns in names.items() if any(k in n for n in ns for k in ("crop_affine", "flip_merge_decode"))} - det_q
-    # lanes: a program's lane streams carry only conv / pool kernels; attach each to the family whose main queue it overlaps most
-    fam = {q: ("det" if q in det_q else "pose" if q in pose_q else None) for q in by_q}
-    for q in by_q:
-        if fam[q] is None:
-            d = sum(intersect_len(by_q[q], by_q[x]) for x in det_q)
-            p = sum(intersect_len(by_q[q], by_q[x]) for x in pose_q)
-            # a lane runs BETWEEN its program's main-stream kernels: use adjacency in time instead when there is no overlap
-            fam[q] = "det" if d >= p else "pose"
-    det = [iv for q in by_q if fam[q] == "det" for iv in by_q[q]]
-    pose = [iv for q in by_q if fam[q] == "pose" for iv in by_q[q]]
+        q = r["Stream_Id"]
+        by_s[q].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        mark[q][0] += any(k in r["Kernel_Name"] for k in DET)
+        mark[q][1] += any(k in r["Kernel_Name"] for k in POSE)
+    fam = {q: ("det" if mark[q][0] > 0 else "pose" if mark[q][1] > 0 else "det-lane") for q in by_s}
+    det = [x for q in by_s if fam[q] != "pose" for x in by_s[q]]
+    pose = [x for q in by_s if fam[q] == "pose" for x in by_s[q]]
     span = (t1 - lo) / 1e6
     u_all = union_len(det + pose) / 1e6
     u_det, u_pose = union_len(det) / 1e6, union_len(pose) / 1e6
     both = intersect_len(det, pose) / 1e6
-    print(f"window {span:.1f} ms ({len(rows)} kernels on {len(by_q)} queues: {sum(f == 'det' for f in fam.values())} detector, {sum(f == 'pose' for f in fam.values())} pose)")
-    print(f"some kernel executing          {u_all:8.1f} ms  ({100 * u_all / span:.1f} % of the window)")
-    print(f"detector kernels executing     {u_det:8.1f} ms")
-    print(f"pose / lifting kernels executing {u_pose:6.1f} ms")
-    print(f"BOTH families executing at once {both:7.1f} ms  ({100 * both / max(u_pose, 1e-9):.1f} % of the pose stage's time runs beside detector kernels)")
-    print(f"serial sum {u_det + u_pose:.1f} ms vs union {u_all:.1f} ms: {100 * (1 - u_all / (u_det + u_pose)):.1f} % saved by co-running")
+    print(f"window {span:.1f} ms ({len(rows)} kernels on {len(by_s)} streams: " + ", ".join(f"{q}:{fam[q]}" for q in sorted(by_s)) + ")")
+    print(f"some kernel executing            {u_all:8.1f} ms  ({100 * u_all / span:.1f} % of the window)")
+    print(f"detector kernels executing       {u_det:8.1f} ms")
+    print(f"pose / lifting kernels executing {u_pose:8.1f} ms")
+    print(f"BOTH families executing at once  {both:8.1f} ms  ({100 * both / max(u_pose, 1e-9):.1f} % of the pose stage's kernel time runs beside detector kernels)")
+    print(f"serial sum {u_det + u_pose:.1f} ms vs union {u_all:.1f} ms: {100 * (1 - u_all / (u_det + u_pose)):.1f} % of the serial time saved by co-running")
 
 
 if __name__ == "__main__":

@@ -9,13 +9,19 @@ python $R/bench.py > $O/bench_cascade.json 2> $O/bench_cascade.err
 python $R/bench.py --workload c2 > $O/bench_c2.json 2> $O/bench_c2.err
 python $R/bench.py --mode shard --steps 6 --warmup 2 > $O/bench_shard.json 2> $O/bench_shard.err
 python $R/bench.py --persons 4 --steps 6 --warmup 2 --cpu-frames 0 > $O/bench_cascade_p4.json 2> $O/bench_cascade_p4.err
+python $R/bench.py --persons 8 --steps 4 --warmup 1 --cpu-frames 0 --no-secondary > $O/bench_cascade_p8.json 2> $O/bench_cascade_p8.err
 cd $R
 # the roofline evidence: ONE run under rocprofv3 with every launch on one stream and no detector look-ahead (--profile-serial), so that
 # AverageNs of conv_split_* x launches_per_step reproduces the line's ms_per_step_serial (tools/roofline_check.py prints both)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/serial -- python bench.py --profile-serial --steps 5 --warmup 1 > $O/serial.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes4 -- python bench.py --steps 5 --warmup 1 --cpu-frames 0 > $O/lanes4.log 2>&1
 cp $(ls -t $(find $O/serial -name "*kernel_stats.csv") | head -1) $O/cascade_serial_kernel_stats.csv
-cp $(ls -t $(find $O/lanes4 -name "*kernel_stats.csv") | head -1) $O/cascade_lanes4_kernel_stats.csv
+cp $(ls -t $(find $O/lanes4 -name "*kernel_stats.csv") | head -1) $O/cascade_lanes_kernel_stats.csv
+# which kernels co-run (detector look-ahead + lanes): interval arithmetic over the kernel trace of the default run
+python tools/overlap_from_trace.py $(ls -t $(find $O/lanes4 -name "*kernel_trace.csv") | head -1) > $O/overlap_lookahead_on.txt 2>&1
+POSEPIPE_OVERLAP_DETECTOR=0 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/lanes_off -- python bench.py --steps 5 --warmup 1 --cpu-frames 0 --light > $O/lanes_off.log 2>&1
+python tools/overlap_from_trace.py $(ls -t $(find $O/lanes_off -name "*kernel_trace.csv") | head -1) > $O/overlap_lookahead_off.txt 2>&1
+rm -rf $O/lanes_off
 grep '^{' $O/serial.log | tail -1 > $O/bench_cascade_profile_serial.json
 python tools/roofline_check.py $O/cascade_serial_kernel_stats.csv $O/bench_cascade_profile_serial.json > $O/roofline_check.txt 2>&1; cat $O/roofline_check.txt
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --profile-serial --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1
@@ -34,6 +40,9 @@ NV12_ONE=1 bash tools/hbm_kernel_profile.sh nv12_to_bgr nv12_1080p 597196800 pyt
 bash tools/hbm_kernel_profile.sh det_preprocess det_preprocess 1111228416 python bench.py --steps 3 --warmup 1 --light --cpu-frames 0 > /dev/null 2>&1; cp gpurun_out/hbm_det_preprocess.txt $O/hbm_det_preprocess.txt
 python bench.py --workload c5 --cpu-frames 0 > $O/bench_c5.json 2> $O/bench_c5.err
 python bench.py --workload cascade5 --cpu-frames 0 --steps 6 --warmup 2 > $O/bench_cascade5.json 2> $O/bench_cascade5.err
+python tools/margin_probe.py 16 > $O/margin_probe.txt 2>&1
+bash tools/pmc_kernel.sh "conv_split_kernel<9, 6, 4, 2, 4, true, true, false>" tap4 python tools/profile_net.py det 64 > /dev/null 2>&1; cp gpurun_out/pmc_tap4/summary.txt $O/tap_kernel_pmc.txt
+bash tools/pmc_kernel.sh "true, true, true>" s2p python tools/profile_net.py det 64 > /dev/null 2>&1; cp gpurun_out/pmc_s2p/summary.txt $O/s2_kernel_pmc.txt
 python tools/split_check.py > $O/conv_split_accuracy.txt 2>&1
 python -m pytest tests/test_gpu_split.py -q -s -k reordering 2>&1 | grep "heat-maps\|joints\|passed\|failed" > $O/conv_split_control.txt
 # keep only the small files
