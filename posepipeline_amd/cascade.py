@@ -101,10 +101,10 @@ class Cascade:
             self.encoder = mars.MarsEncoder(ctx, det_sd[1], src_h, src_w, max_patches=max(64, chunk * max_persons), numerics=id_numerics)
         else:
             assert tracking == "MMTrack_deepsort", tracking
-            # look-ahead mode (see the docstring).  Same-box (profiles/r06_lanes_ab.txt): off 575 - 585, pipeline 578 - 587, stream
-            # 600 frames/s (the worker-thread form of rounds 3 - 5: 595) -- what pays is the SECOND QUEUE (one program's launches fill the
-            # drain / launch gaps between the other's dependent kernels: ~700 boundaries per step), not host-side overlap; the kernel
-            # trace shows the two families executing at once for only ~1 % of the time (profiles/r06_overlap_lookahead_*.txt).
+            # look-ahead mode (see the docstring).  Same-box (profiles/r06_lookahead_modes.txt): off 578, pipeline 582, stream 603 frames/s
+            # (the worker-thread form of rounds 3 - 5: 595 against 600 for stream).  What pays is the SECOND QUEUE: the kernel trace
+            # (profiles/r06_overlap_lookahead.txt) shows the next chunk's detector kernels executing beside this chunk's pose kernels for
+            # 35 % of the pose stage's kernel time; on one stream nothing co-runs and only the host-side gaps (~0.7 %) are recovered.
             env = os.environ.get("POSEPIPE_OVERLAP_DETECTOR")
             if env is not None:
                 overlap_detector = {"0": "off", "1": "stream", "3": "pipeline"}.get(env, "stream")
