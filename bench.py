@@ -122,7 +122,7 @@ def kernel_families(nets_batches, reps=3):
     HIP-event durations of ONE pass of the given (net, batch) programs, serial on one stream (pp_net_profile: events around
     every op -- the same per-launch durations rocprofv3 --kernel-trace reports for the serial profile)."""
     fam = {1: dict(launches=0, flops=0.0, bytes=0.0, ms=0.0), 2: dict(launches=0, flops=0.0, bytes=0.0, ms=0.0),
-           "products": split_products([n for n, _ in nets_batches])}
+           "products": split_products([n for n, _ in nets_batches]), "classes": {}}
     for net, batch in nets_batches:
         net.profile(batch)
         ms = np.median(np.stack([net.profile(batch) for _ in range(reps)]), axis=0)
@@ -135,6 +135,15 @@ def kernel_families(nets_batches, reps=3):
                 f["flops"] += net.prog.op_flops[i] * batch
                 f["bytes"] += ab[i]
                 f["ms"] += float(ms[i])
+            if k == 2:       # the split family by layer form: each form has its own roof (round 6)
+                op = net.prog.ops[i]
+                name = ("3x3 stride 1 (tap kernels)" if op.kh == 3 and op.stride == 1 else "3x3 stride 2 (strided-patch / tap-gather)" if op.kh == 3 else
+                        "7x7 stride-2 stem" if op.kh == 7 and op.stride == 2 else "1x1 / full-cover (product and one-tap kernels; fc6 / fc7)")
+                c = fam["classes"].setdefault(name, dict(launches=0, flops=0.0, bytes=0.0, ms=0.0))
+                c["launches"] += 1
+                c["flops"] += net.prog.op_flops[i] * batch
+                c["bytes"] += ab[i]
+                c["ms"] += float(ms[i])
     return fam
 
 
@@ -163,6 +172,20 @@ def roofline_families(fam):
     else:
         roof = dict(fp32_line or {})
         roof.update({"bound": "mfma", "kernel": "conv_igemm_kernel / conv_p3_kernel (v_mfma_f32_16x16x4_f32)", "split_kernel": split_line})
+    # the family by layer form, each priced against BOTH roofs: the 3x3 layers are matrix work, the 1x1 layers move X + residual + Y once
+    # per tile and sit at the memory roof -- the family's single `frac` above averages the two
+    HBM_PEAK_TBS = 8.0
+    classes = []
+    for name, c in sorted(fam.get("classes", {}).items(), key=lambda kv: -kv[1]["ms"]):
+        if c["ms"] <= 0:
+            continue
+        tf, tb = c["flops"] / (c["ms"] * 1e-3) / 1e12, c["bytes"] / (c["ms"] * 1e-3) / 1e12
+        classes.append({"layers": name, "launches_per_step": c["launches"], "ms_per_step_serial": c["ms"], "tflops": tf, "frac_mfma": tf / split_peak,
+                        "algorithmic_tb_per_s": tb, "frac_hbm": tb / HBM_PEAK_TBS, "bound": "mfma" if tf / split_peak >= tb / HBM_PEAK_TBS else "hbm"})
+    if classes:
+        roof["by_layer_form"] = classes
+        roof["by_layer_form_note"] = ("the conv_split* launches of one step by layer form, serial HIP-event times; frac_mfma against 2500 / products "
+                                      "TFLOP/s, frac_hbm = algorithmic bytes / time against 8 TB/s (a float4 copy reaches 6.29); `bound` = the larger fraction")
     roof["measurement"] = ("HIP events around every launch of one pass of the step's conv programs, serial on one stream "
                            "(pp_net_profile), median of 3 passes; outside the timed region")
     roof["algorithmic_bytes_note"] = ("per launch: every conv operand (input, weights, bias, residuals) read once and every output "
