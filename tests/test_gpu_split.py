@@ -509,6 +509,34 @@ def test_split_stride_2_inside_a_program(ctx, lib, monkeypatch):
     assert not np.array_equal(exact, split) and np.abs(split - exact).max() <= 1e-5 * np.abs(exact).max()
 
 
+def test_f16_form_strided_patch_inside_a_program(ctx, lib16):
+    """the strided-patch form where HRNet uses it: reading a ZERO-HALO buffer (producer: a 3x3 stride-1 layer), writing one, with two
+    residuals, on ODD maps (49 x 73 -> 25 x 37: the last output row / column's far taps leave the image) -- large enough for the
+    selection rule to pick the form (>= 400 output pixels with 96 output channels), every layer on the split kernels, same result as the
+    float32 MFMA kernels to 1e-5, per-sample maxima tracked across the strided layers (samples at different magnitudes)"""
+    rng = np.random.default_rng(29)
+    c = 48
+    pb = ProgramBuilder()
+    x = pb.buf(49, 73, c, name="input")
+    w = [(rng.standard_normal((co, ci, 3, 3)) / np.sqrt(9 * ci)).astype(np.float32) for co, ci in ((c, c), (96, c), (96, 96), (192, 96))]
+    b = [rng.standard_normal(co).astype(np.float32) for co in (c, 96, 96, 192)]
+    y1 = pb.conv(x, w[0], b[0], pad=1, relu=L.PP_RELU_LAST)
+    y2 = pb.conv(y1, w[1], b[1], pad=1, stride=2, relu=L.PP_RELU_LAST)                  # strided patch, halo in, halo out
+    y3 = pb.conv(y2, w[2], b[2], pad=1, relu=L.PP_RELU_LAST)
+    y4 = pb.conv(y1, w[1], b[1], pad=1, stride=2, relu=L.PP_RELU_LAST, res1=y2, res2=y3)   # two residuals
+    pb.conv(y4, w[3], b[3], pad=1, stride=2, relu=L.PP_RELU_LAST, out=pb.buf(13, 19, 192, name="output"))   # 247 outputs: the tap-gather form
+    prog = pb.build()
+    xin = (rng.standard_normal((4, 49, 73, c)) * (10.0 ** np.arange(-2, 2)).reshape(-1, 1, 1, 1)).astype(np.float32)
+
+    def run():
+        net = Net(ctx, prog, max_batch=4)
+        return net.forward(xin), net.conv_kinds()
+    (exact, k_e), (split, k_s) = both(lib16, run)
+    assert (k_e == 1).all() and (k_s == 2).all(), (k_e, k_s)
+    scale = np.abs(exact).reshape(4, -1).max(1).reshape(4, 1, 1, 1)
+    assert not np.array_equal(exact, split) and (np.abs(split - exact) <= 1e-5 * scale).all()
+
+
 def test_split_1x1_with_shifted_residual(ctx, lib):
     """FPN's lateral convs: 1x1 + (top-down map read at (y >> 1, x >> 1)) -- on the product kernel the coarse residual is read with
     the shift in the epilogue, odd fine maps included"""
