@@ -18,10 +18,12 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lanes4 --
 cp $(ls -t $(find $O/serial -name "*kernel_stats.csv") | head -1) $O/cascade_serial_kernel_stats.csv
 cp $(ls -t $(find $O/lanes4 -name "*kernel_stats.csv") | head -1) $O/cascade_lanes_kernel_stats.csv
 # which kernels co-run (detector look-ahead + lanes): interval arithmetic over the kernel trace of the default run
-python tools/overlap_from_trace.py $(ls -t $(find $O/lanes4 -name "*kernel_trace.csv") | head -1) > $O/overlap_lookahead_stream.txt 2>&1
-POSEPIPE_OVERLAP_DETECTOR=0 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/lanes_off -- python bench.py --steps 5 --warmup 1 --cpu-frames 0 --light > $O/lanes_off.log 2>&1
-python tools/overlap_from_trace.py $(ls -t $(find $O/lanes_off -name "*kernel_trace.csv") | head -1) > $O/overlap_lookahead_off.txt 2>&1
-rm -rf $O/lanes_off
+# (--light runs: the timed cascade only, so that the trace's second half is the timed steps of ONE cascade)
+for m in 1 3 0; do
+    POSEPIPE_OVERLAP_DETECTOR=$m timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/ov$m -- python bench.py --steps 8 --warmup 2 --cpu-frames 0 --light > $O/ov$m.log 2>&1
+    python tools/overlap_from_trace.py $(ls -t $(find $O/ov$m -name "*kernel_trace.csv") | head -1) > $O/overlap_lookahead_mode$m.txt 2>&1
+    rm -rf $O/ov$m
+done
 # the same line with the look-ahead off / on the cascade's own stream, for the record beside bench_cascade.json (same box)
 for m in 0 3 1; do POSEPIPE_OVERLAP_DETECTOR=$m python bench.py --light --cpu-frames 0 --steps 8 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lookahead', d['config']['detector_lookahead'], round(d['value'],1), 'frames/s', round(d['ms_per_step'],2), 'ms')"; done > $O/lookahead_modes.txt 2>&1
 bash tools/pmc_clock.sh det python tools/profile_net.py det 64 > /dev/null 2>&1; cp gpurun_out/pmc_clock_det/summary.txt $O/clock.txt
