@@ -827,3 +827,27 @@ def test_kernel_selection_does_not_depend_on_the_batch_capacity(ctx, lib16):
         kinds = [Net(ctx, prog, max_batch=b, numerics="split_f16").conv_kinds() for b in (1, 5)]
         assert np.array_equal(kinds[0], kinds[1])
         assert (kinds[0] == 2).sum() >= 50
+
+
+def test_lane_count_does_not_change_results(ctx, lib16):
+    """pp_net_set_lane_count (ABI 10): the op -> stream plan of an existing program re-made for 1, 2, 4 and 7 lanes -- HRNet's branches
+    spread differently each time, every dependency (RAW on inputs / residuals, WAR / WAW on recycled buffers) an event wait -- same bits,
+    in the exact and in the default numerics, and a captured graph is dropped rather than replayed with the old plan"""
+    spec = hrnet.HRNetSpec(32, 17, 128, 96)
+    sd = synth.synth_state_dict(hrnet.hrnet_param_shapes(spec), seed=1)
+    rng = np.random.default_rng(31)
+    x = np.zeros((5, 128, 96, 4), np.float32)
+    x[..., :3] = rng.standard_normal((5, 128, 96, 3))
+    for numerics in ("exact", "split"):
+        net = Net(ctx, hrnet.build_hrnet_program(spec, sd), max_batch=5, numerics=numerics)
+        ref = net.forward(x)
+        for lanes in (1, 2, 7, 4):
+            net.set_lane_count(lanes)
+            assert np.array_equal(net.forward(x), ref), (numerics, lanes)
+        net.capture(5)
+        assert np.array_equal(net.forward(x), ref)
+        net.set_lane_count(2)                       # drops the graph
+        assert np.array_equal(net.forward(x), ref)
+        with pytest.raises(L.PosePipeHipError):
+            net.set_lane_count(0)
+        net.close()
