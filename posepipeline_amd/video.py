@@ -7,6 +7,9 @@ below exist because neither OpenCV nor ffmpeg is installed in the build / GPU im
   *.ppvid  32-byte header (magic 'PPVID001', N, H, W, fps*1000 as little-endian int32) + raw BGR frames;
            magic 'PPVID002' carries a pixel-format word after the four ints (0 = bgr24, 1 = nv12)
   *_<W>x<H>.nv12   header-less NV12 frames (`ffmpeg -i in.mp4 -pix_fmt nv12 -f rawvideo out_1920x1080.nv12`), 30 fps
+  *.y4m    YUV4MPEG2, 8-bit 4:2:0 (`ffmpeg -i in.mp4 -pix_fmt yuv420p out.y4m`, what mplayer / x264 / libvpx tools read and write):
+           a standard uncompressed container any ffmpeg can produce from the reference's .mp4 files; its planar U / V are
+           interleaved on the host (numpy) and take the NV12 path
 BGR sources yield frames in BGR order, like `cap.read()`.  NV12 sources (a decoder's native output: Y plane [H][W], then
 interleaved UV [H/2][W]; half the bytes) hand their raw planes to streaming.FrameStreamer, which uploads them as they are and
 converts on the device (csrc/nv12.hip, OpenCV's COLOR_YUV2BGR_NV12 arithmetic) -- there is no host conversion path.
@@ -93,6 +96,112 @@ class Nv12Video:
         pass
 
 
+class Y4mVideo:
+    """YUV4MPEG2 file, 8-bit 4:2:0 planar (I420): header line `YUV4MPEG2 W<w> H<h> F<num>:<den> [I?] [A?:?] [C420*] [X...]`, then per
+    frame `FRAME[ params]\n` + Y [h][w] + U [h/2][w/2] + V [h/2][w/2].  Frames are handed on as NV12 planes (U / V interleaved here),
+    so streaming.FrameStreamer uploads half the bytes of BGR and converts on the device like any NV12 source."""
+    pixfmt = "nv12"
+
+    def __init__(self, path):
+        self.path = path
+        self.f = open(path, "rb")
+        head = self.f.readline(4096)
+        if not head.startswith(b"YUV4MPEG2 ") or not head.endswith(b"\n"):
+            raise ValueError(f"{path}: not a YUV4MPEG2 file")
+        w = h = None
+        fps, cs = 30.0, "420jpeg"
+        for tok in head[:-1].split(b" ")[1:]:
+            if not tok:
+                continue
+            k, v = tok[:1], tok[1:].decode("ascii", "replace")
+            if k == b"W":
+                w = int(v)
+            elif k == b"H":
+                h = int(v)
+            elif k == b"F":
+                num, _, den = v.partition(":")
+                fps = float(num) / float(den or 1) if float(den or 1) else 30.0
+            elif k == b"C":
+                cs = v
+        if not w or not h:
+            raise ValueError(f"{path}: YUV4MPEG2 header without W / H")
+        if not cs.startswith("420") or cs.startswith("420p1") or cs in ("420p9",):       # 420jpeg / 420mpeg2 / 420paldv: 8-bit 4:2:0
+            raise ValueError(f"{path}: colourspace C{cs} is not supported (8-bit 4:2:0 only: transcode with -pix_fmt yuv420p)")
+        if h % 2 or w % 2:
+            raise ValueError(f"Y4M source {w}x{h}: height and width must be even")
+        self.width, self.height, self.fps = int(w), int(h), float(fps)
+        self.payload = w * h * 3 // 2
+        self.data0 = len(head)
+        # frame offsets: writers emit a bare b"FRAME\n"; a file whose frame headers carry parameters is indexed by a scan
+        size = os.path.getsize(path)
+        self.offsets = []
+        pos = self.data0
+        first = self._frame_header(pos)
+        if first == 6 and (size - self.data0) % (6 + self.payload) in range(0, 6 + self.payload):
+            n = (size - self.data0) // (6 + self.payload)
+            self.offsets = [self.data0 + i * (6 + self.payload) + 6 for i in range(n)]
+            # verify the last announced frame header (cheap): a mismatch means variable headers -> scan
+            if n and self._frame_header(self.offsets[-1] - 6) != 6:
+                self.offsets = []
+        if not self.offsets and first:
+            while True:
+                hl = self._frame_header(pos)
+                if not hl or pos + hl + self.payload > size:          # truncated last frame: the stream ends before it
+                    break
+                self.offsets.append(pos + hl)
+                pos += hl + self.payload
+        self.pos = 0
+
+    def _frame_header(self, pos):
+        self.f.seek(pos)
+        line = self.f.readline(256)
+        return len(line) if line.startswith(b"FRAME") and line.endswith(b"\n") else 0
+
+    @property
+    def num_frames(self):
+        return len(self.offsets)
+
+    def read(self):
+        raise RuntimeError("Y4M source: frames are converted on the device (streaming.FrameStreamer / pp_upload_begin_nv12); "
+                           "there is no host-side cap.read()")
+
+    def read_batch(self, n):
+        """up to n consecutive frames as NV12 planes [k][H * 3 / 2][W] (U / V interleaved from the file's planar chroma)"""
+        h, w = self.height, self.width
+        k = max(0, min(n, self.num_frames - self.pos))
+        out = np.empty((k, h * 3 // 2, w), np.uint8)
+        for i in range(k):
+            self.f.seek(self.offsets[self.pos + i])
+            buf = np.frombuffer(self.f.read(self.payload), np.uint8)
+            out[i, :h] = buf[: w * h].reshape(h, w)
+            u = buf[w * h: w * h + w * h // 4].reshape(h // 2, w // 2)
+            v = buf[w * h + w * h // 4:].reshape(h // 2, w // 2)
+            uv = out[i, h:].reshape(h // 2, w // 2, 2)
+            uv[..., 0] = u
+            uv[..., 1] = v
+        self.pos += k
+        return out
+
+    def release(self):
+        if self.f:
+            self.f.close()
+            self.f = None
+
+
+def write_y4m(path, frames: np.ndarray, fps: float = 30.0, frame_params: bytes = b""):
+    """frames [N][H][W][3] BGR -> YUV4MPEG2 C420jpeg (tests / synthetic clips; the chroma arithmetic of bgr_to_nv12)"""
+    nv = bgr_to_nv12(frames)
+    n, h, w = frames.shape[:3]
+    with open(path, "wb") as f:
+        f.write(b"YUV4MPEG2 W%d H%d F%d:1000 Ip A1:1 C420jpeg\n" % (w, h, int(round(fps * 1000))))
+        for i in range(n):
+            f.write(b"FRAME" + frame_params + b"\n")
+            f.write(nv[i, :h].tobytes())
+            uv = nv[i, h:].reshape(h // 2, w // 2, 2)
+            f.write(np.ascontiguousarray(uv[..., 0]).tobytes())
+            f.write(np.ascontiguousarray(uv[..., 1]).tobytes())
+
+
 def bgr_to_nv12(frames: np.ndarray) -> np.ndarray:
     """[N][H][W][3] u8 BGR -> [N][H * 3 / 2][W] u8 NV12, ITU-R BT.601 limited range (the encoder side: only used to WRITE
     test / synthetic containers; chroma is the rounded mean of each 2 x 2 block)"""
@@ -166,7 +275,7 @@ def robust_path(path, run=None):
     `run`: subprocess.run stand-in (tests)."""
     import subprocess
     import tempfile
-    if isinstance(path, np.ndarray) or os.path.splitext(path)[1].lower() in (".npy", ".ppvid", ".nv12"):
+    if isinstance(path, np.ndarray) or os.path.splitext(path)[1].lower() in (".npy", ".ppvid", ".nv12", ".y4m"):
         return path
     st = os.stat(path)
     key = (os.path.abspath(path), st.st_size, st.st_mtime_ns)
@@ -249,8 +358,10 @@ def open_video(path):
         w, h = int(m.group(1)), int(m.group(2))
         n = os.path.getsize(path) // (h * w * 3 // 2)
         return Nv12Video(np.memmap(path, dtype=np.uint8, mode="r", shape=(n, h * 3 // 2, w)), h, w)
+    if ext == ".y4m":
+        return Y4mVideo(path)
     try:
         import cv2  # noqa: F401
     except ImportError as e:
-        raise RuntimeError(f"cannot decode {path}: OpenCV is not installed and the file is not .npy/.ppvid/.nv12") from e
+        raise RuntimeError(f"cannot decode {path}: OpenCV is not installed and the file is not .npy/.ppvid/.nv12/.y4m") from e
     return _Cv2Video(path)  # pragma: no cover

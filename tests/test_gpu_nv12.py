@@ -96,3 +96,35 @@ def test_cascade_on_an_nv12_clip_equals_the_cascade_on_the_converted_frames(ctx,
     cas.reset()
     g1 = next(iter(cas.run_video(video.open_video(path))))
     assert r1["tracks"] == g1["tracks"] and len(r1["tracks"]) > 0
+
+
+def test_y4m_clip_takes_the_nv12_path(ctx, tmp_path):
+    """a YUV4MPEG2 file (8-bit 4:2:0, what ffmpeg writes with -pix_fmt yuv420p) streams like an NV12 source: every chunk on the device
+    equals the oracle's conversion of the same planes, and the cascade on the .y4m clip == the cascade on the converted frames"""
+    from posepipeline_amd.cascade import Cascade
+    from tests.test_gpu_cascade import _setup, synth_frame
+    rng = np.random.default_rng(6)
+    h, w = 136, 240
+    frames = np.stack([synth_frame(rng, h, w) for _ in range(5)])
+    path = str(tmp_path / "clip.y4m")
+    video.write_y4m(path, frames, fps=30.0)
+    bgr = onv.nv12_to_bgr(video.bgr_to_nv12(frames), h, w)
+    st = FrameStreamer(ctx, video.open_video(path), 2)
+    for dev, n, first in st:
+        got = np.empty((n, h, w, 3), np.uint8)
+        ctx.d2h(got, dev)
+        assert np.array_equal(got, bgr[first:first + n])
+        st.release()
+    st.close()
+    det_sd, pose_spec, pose_sd, lift_sd = _setup(h, w)
+    cas = Cascade(ctx, det_sd, pose_sd, lift_sd, h, w, chunk=2, max_persons=1, pose_spec=pose_spec)
+    ref = list(cas.run_video(video.open_video(bgr)))
+    cas.reset()
+    got = list(cas.run_video(video.open_video(path)))
+    assert len(ref[0]["tracks"]) > 0
+    for a, b in zip(ref, got):
+        assert a["tracks"] == b["tracks"]
+        for what in ("keypoints", "keypoints_3d"):
+            assert a[what].keys() == b[what].keys()
+            for tid in a[what]:
+                assert np.array_equal(a[what][tid], b[what][tid])

@@ -1,5 +1,6 @@
 """Video.get_robust_reader's validation + ffmpeg fallback (pose_pipeline/pipeline.py:47-87) on stand-ins for cv2 and ffmpeg
 (neither is installed here): control flow, the exact transcode command, one validation per file, raw containers."""
+import os
 import sys
 import types
 
@@ -121,3 +122,42 @@ def test_raw_containers_need_no_decoder(tmp_path):
         f.truncate(32 + 2 * 6 * 8 * 3 + 5)
     v = video.open_video(path)
     assert v.num_frames == 2 and np.array_equal(v.read_batch(10), frames[:2])
+
+
+def test_y4m_container(tmp_path):
+    """YUV4MPEG2 (8-bit 4:2:0): what `ffmpeg -i in.mp4 -pix_fmt yuv420p out.y4m` writes -- a standard container readable without any
+    decoder.  Header parameters in any order, frame headers with and without parameters, a truncated last frame, colourspaces that
+    are not 8-bit 4:2:0 refused; the planes come out as NV12 (U / V interleaved) for the device conversion path."""
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 256, (5, 12, 16, 3)).astype(np.uint8)
+    ref = video.bgr_to_nv12(frames)
+    for params in (b"", b" Ixyz"):
+        path = str(tmp_path / "c.y4m")
+        video.write_y4m(path, frames, fps=25.0, frame_params=params)
+        assert video.robust_path(path) == path
+        v = video.open_video(path)
+        assert (v.num_frames, v.height, v.width, v.fps, v.pixfmt) == (5, 12, 16, 25.0, "nv12")
+        assert np.array_equal(np.concatenate([v.read_batch(2), v.read_batch(2), v.read_batch(9)]), ref)
+        assert v.read_batch(3).shape == (0, 18, 16)
+        with pytest.raises(RuntimeError, match="converted on the device"):
+            v.read()
+        v.release()
+    with open(path, "r+b") as f:
+        f.truncate(os.path.getsize(path) - 7)
+    assert video.open_video(path).num_frames == 4
+    # header variants: parameters in another order, no colourspace tag (= 420jpeg), extension tags
+    body = open(path, "rb").read().split(b"\n", 1)[1]
+    open(path, "wb").write(b"YUV4MPEG2 H12 W16 A1:1 Ip F30000:1001 XYSCSS=420JPEG\n" + body)
+    v = video.open_video(path)
+    assert (v.height, v.width, v.num_frames) == (12, 16, 4) and abs(v.fps - 29.97) < 0.01
+    assert np.array_equal(v.read_batch(9), ref[:4])
+    for cs in (b"C444", b"C422", b"C420p10", b"Cmono"):
+        open(path, "wb").write(b"YUV4MPEG2 W16 H12 F25:1 " + cs + b"\n" + body)
+        with pytest.raises(ValueError, match="not supported"):
+            video.open_video(path)
+    open(path, "wb").write(b"RIFF....AVI LIST")
+    with pytest.raises(ValueError, match="not a YUV4MPEG2"):
+        video.open_video(path)
+    open(path, "wb").write(b"YUV4MPEG2 W15 H12 F25:1\n")
+    with pytest.raises(ValueError, match="must be even"):
+        video.open_video(path)
