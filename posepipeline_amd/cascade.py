@@ -101,10 +101,10 @@ class Cascade:
             self.encoder = mars.MarsEncoder(ctx, det_sd[1], src_h, src_w, max_patches=max(64, chunk * max_persons), numerics=id_numerics)
         else:
             assert tracking == "MMTrack_deepsort", tracking
-            # look-ahead mode (see the docstring).  Same-box (profiles/r06_lookahead_modes.txt): off 578, pipeline 582, stream 603 frames/s
+            # look-ahead mode (see the docstring).  Same-box (profiles/r06_lookahead_modes.txt): off 580, pipeline 588, stream 610 frames/s
             # (the worker-thread form of rounds 3 - 5: 595 against 600 for stream).  What pays is the SECOND QUEUE: the kernel trace
-            # (profiles/r06_overlap_lookahead.txt) shows the next chunk's detector kernels executing beside this chunk's pose kernels for
-            # 35 % of the pose stage's kernel time; on one stream nothing co-runs and only the host-side gaps (~0.7 %) are recovered.
+            # (profiles/r06_overlap_lookahead_stream.txt) shows the next chunk's detector kernels executing beside this chunk's pose kernels
+            # for 18 - 35 % of the pose stage's kernel time; on one stream nothing co-runs and only the host-side gaps (~1 %) are recovered.
             env = os.environ.get("POSEPIPE_OVERLAP_DETECTOR")
             if env is not None:
                 overlap_detector = {"0": "off", "1": "stream", "3": "pipeline"}.get(env, "stream")
