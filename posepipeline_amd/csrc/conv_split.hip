@@ -201,13 +201,24 @@ __device__ __forceinline__ void split4(const float4 v, uint2& p0, uint2& p1, uin
 // values down to 2^-17 of the sample's maximum keep their 22 bits and smaller ones are off by <= 2^-39 of it -- whatever the
 // magnitude of the data (1e-30 .. 1e30 alike).  Non-finite inputs stay non-finite (inf s = inf in float16, NaN stays NaN).
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+// (round 6) two elements -> their (h0, h1) register pair in FOUR instructions: v_fma_mixlo / mixhi_f16 evaluate fma(x, s, c) in float32
+// with c read as float16 and round the result into one half of the destination -- h0 = f16(x s + 0), h1 = f16(x s - h0) -- where the
+// plain sequence takes six (v_pk_mul, v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add, v_cvt_pk_f16_f32).  x s is exact (s a power of two)
+// and so is the difference: the same bits as before, except the sign of an exact zero (tools/dbg/mix_test.hip: 4M random bit patterns,
+// four scales, 0 mismatches).  The split is the VALU work of every fp16-form kernel: the product kernel converts at each fragment read
+// (ablation: 3.3 ms of a 105 ms step go into it), the strided-patch kernel stages four input pixels per output (3.6 VALU per MFMA).
+__device__ __forceinline__ void split2h(const float x0, const float x1, const float s, unsigned& h0, unsigned& h1) {
+    unsigned d, e;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(d) : "v"(x0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(d) : "v"(x1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(e) : "v"(x0), "v"(s), "v"(d));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(e) : "v"(x1), "v"(s), "v"(d));
+    h0 = d;
+    h1 = e;
+}
 __device__ __forceinline__ void split4h(const float4 v, const float s, uint2& p0, uint2& p1) {
-    const f32x2_t a = f32x2_t{v.x, v.y} * s, b = f32x2_t{v.z, v.w} * s;
-    const f16x2_t a0 = __builtin_convertvector(a, f16x2_t), b0 = __builtin_convertvector(b, f16x2_t);
-    const f32x2_t ra = a - __builtin_convertvector(a0, f32x2_t), rb = b - __builtin_convertvector(b0, f32x2_t);   // exact
-    const f16x2_t a1 = __builtin_convertvector(ra, f16x2_t), b1 = __builtin_convertvector(rb, f16x2_t);
-    p0 = make_uint2(__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, b0));
-    p1 = make_uint2(__builtin_bit_cast(unsigned, a1), __builtin_bit_cast(unsigned, b1));
+    split2h(v.x, v.y, s, p0.x, p1.x);
+    split2h(v.z, v.w, s, p0.y, p1.y);
 }
 
 // Activations of the DeepSortYOLOv4 / YOLOX programs, as conv_igemm_p3.hip: every transcendental is evaluated in double precision
@@ -1526,16 +1537,11 @@ __global__ __launch_bounds__(64 * WM * WN, 512 / (64 * WM * WN)) void conv_split
         const float4 q0 = *reinterpret_cast<const float4*>(sx_ + (fofs + pb * 2048));
         const float4 q1 = *reinterpret_cast<const float4*>(sx_ + ((fofs + pb * 2048) ^ 16));
         const float sc = xsc[pb];
-        const f32x2_t v[4] = {f32x2_t{q0.x, q0.y} * sc, f32x2_t{q0.z, q0.w} * sc, f32x2_t{q1.x, q1.y} * sc, f32x2_t{q1.z, q1.w} * sc};
-        unsigned a_[4], b_[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const f16x2_t c0 = __builtin_convertvector(v[e], f16x2_t);
-            const f32x2_t r = v[e] - __builtin_convertvector(c0, f32x2_t);                                     // exact
-            const f16x2_t c1 = __builtin_convertvector(r, f16x2_t);
-            a_[e] = __builtin_bit_cast(unsigned, c0);
-            b_[e] = __builtin_bit_cast(unsigned, c1);
-        }
+        unsigned a_[4], b_[4];       // (split2h: 16 vector instructions per fragment instead of 24)
+        split2h(q0.x, q0.y, sc, a_[0], b_[0]);
+        split2h(q0.z, q0.w, sc, a_[1], b_[1]);
+        split2h(q1.x, q1.y, sc, a_[2], b_[2]);
+        split2h(q1.z, q1.w, sc, a_[3], b_[3]);
         h[0] = make_uint4(a_[0], a_[1], a_[2], a_[3]);
         h[1] = make_uint4(b_[0], b_[1], b_[2], b_[3]);
     };
